@@ -1,0 +1,46 @@
+# Build everything in-tree (the built .so files travel to the GPU box with the snapshot).
+#   make            -> front-end lib, HIP engine lib, turbo CLI, oracle
+#   make oracle     -> oracle/liboracle.so only (test infrastructure)
+ROCM ?= /opt/rocm
+HIPCC ?= $(ROCM)/bin/hipcc
+CXX ?= g++
+CC ?= gcc
+ARCH ?= gfx950
+
+LIBDIR := turbo_amd/lib
+BINDIR := turbo_amd/bin
+FRONT_SRC := turbo_amd/csrc/front/fzn_parser.cpp turbo_amd/csrc/front/tcn_lower.cpp turbo_amd/csrc/front/front_capi.cpp
+FRONT_HDR := turbo_amd/csrc/front/fzn_ast.hpp turbo_amd/csrc/front/tcn.hpp include/turbo_front.h include/turbo_hip.h
+HIP_SRC := turbo_amd/csrc/hip/engine.hip
+HIP_HDR := $(wildcard turbo_amd/csrc/hip/*.hpp) include/turbo_hip.h
+HOST_SRC := $(wildcard turbo_amd/csrc/host/*.cpp)
+HOST_HDR := $(wildcard turbo_amd/csrc/host/*.hpp)
+
+CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter
+
+all: front hip cli oracle
+
+front: $(LIBDIR)/libturbo_front.so
+hip: $(LIBDIR)/libturbo_hip.so
+cli: $(BINDIR)/turbo
+oracle:
+	$(MAKE) -C oracle
+
+$(LIBDIR)/libturbo_front.so: $(FRONT_SRC) $(FRONT_HDR)
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(FRONT_SRC)
+
+$(LIBDIR)/libturbo_hip.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+$(BINDIR)/turbo: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libturbo_front.so $(LIBDIR)/libturbo_hip.so
+	@mkdir -p $(BINDIR)
+	$(CXX) $(CXXFLAGS) -fPIE -o $@ $(HOST_SRC) -Iinclude -L$(LIBDIR) -lturbo_front -lturbo_hip -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(ROCM)/lib -lpthread
+
+clean:
+	rm -rf $(LIBDIR) $(BINDIR)
+	$(MAKE) -C oracle clean
+
+.PHONY: all front hip cli oracle clean

@@ -1,0 +1,162 @@
+/*
+ * turbo_hip.h -- C-ABI of the MI355X-native dive-and-solve engine (libturbo_hip.so).
+ *
+ * This is the drop-in boundary for ptal/turbo's GPU solving path.  The reference has no FFI
+ * today (header-only templates in one translation unit, src/turbo.cpp:4-18); the cut is made
+ * after `CP<Itv>::preprocess()` and before the kernel launch, i.e. it replaces
+ *   include/gpu_dive_and_solve.hpp:671-676  (configure_and_run: memory config + launch + wait)
+ *   include/barebones_dive_and_solve.hpp:479-497 (configure_gpu_barebones, launch, wait, reduce)
+ *   include/memory_gpu.hpp:27-84,174-196    (MemoryConfig, wait_solving_ends)
+ * What crosses is the preprocessed ternary constraint network (TCN) as plain arrays; what
+ * comes back is the best store, the statistics and the exhaustive flag.
+ * INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions: POD only; the caller owns every host buffer; the callee owns all device memory;
+ * every entry point returns 0 on success or a negative tb_error, never throws, never exits,
+ * writes nothing to stdout.  tb_last_error() gives a message for the calling thread.
+ */
+#ifndef TURBO_HIP_H
+#define TURBO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TB_NINF INT32_MIN /* -inf sentinel of Interval<ZLB<int>> (common_solving.hpp:45-54, TURBO_ITV_BITS=32) */
+#define TB_PINF INT32_MAX /* +inf sentinel */
+
+/* `x = y op z` operators of the PIR bytecode (common_solving.hpp:739-771). */
+enum tb_op { TB_ADD = 0, TB_MUL = 1, TB_TDIV = 2, TB_TMOD = 3, TB_MIN = 4, TB_MAX = 5, TB_EQ = 6, TB_LEQ = 7, TB_NUM_OPS = 8 };
+
+/* lala VariableOrder / ValueOrder as used by barebones_dive_and_solve.hpp:193-221,362-387
+ * (RANDOM is INPUT_ORDER over an already shuffled variable list, common_solving.hpp:632-633). */
+enum tb_var_order { TB_INPUT_ORDER = 0, TB_FIRST_FAIL = 1, TB_ANTI_FIRST_FAIL = 2, TB_SMALLEST = 3, TB_LARGEST = 4 };
+enum tb_val_order { TB_VAL_MIN = 0, TB_VAL_MAX = 1, TB_VAL_SPLIT = 2, TB_VAL_REVERSE_SPLIT = 3 };
+
+/* memory_gpu.hpp:18-22 */
+enum tb_mem_kind { TB_MEM_GLOBAL = 0, TB_MEM_STORE_SHARED = 1, TB_MEM_TCN_SHARED = 2 };
+
+enum tb_error {
+  TB_OK = 0,
+  TB_ERR_INVALID = -1,   /* bad argument */
+  TB_ERR_NO_DEVICE = -2, /* no gfx950 device / HIP runtime failure at init */
+  TB_ERR_HIP = -3,       /* HIP runtime error while running (see tb_last_error) */
+  TB_ERR_OOM = -4,
+  TB_ERR_STATE = -5      /* session used out of order */
+};
+
+typedef struct { int32_t lb, ub; } tb_itv;          /* VStore element: 8 B */
+typedef struct { int32_t op, x, y, z; } tb_prop;    /* PIR bytecode_type: 16 B, 16-B aligned */
+
+/* The scalars of Configuration<> (include/config.hpp:35-59) that reach the GPU path. */
+typedef struct {
+  uint64_t timeout_ms;              /* -t; 0 = none */
+  uint64_t or_nodes;                /* -or: number of workgroups; 0 = auto (barebones:538-546) */
+  uint64_t subproblems_factor;      /* -subfactor (default 300), barebones:550-555 */
+  uint64_t stop_after_n_nodes;      /* -cutnodes, per workgroup (barebones:1024); 0 = no limit */
+  uint64_t stop_after_n_solutions;  /* -n, satisfaction problems only; 0 = all */
+  uint64_t wac1_threshold;          /* -wac1_threshold (barebones:939) */
+  int32_t subproblems_power;        /* -sub; -1 = auto */
+  int32_t fixpoint;                 /* 0 = AC1, 1 = WAC1 (config.hpp:22-25) */
+  int32_t only_global_memory;       /* -globalmem */
+  int32_t verbose;
+  int32_t has_eps_strategy;         /* strategy 0 is the EPS strategy (barebones:434,747-750) */
+  int32_t threads_per_block;        /* 0 = auto (reference: CMakeLists.txt:93 fixes 256) */
+  int32_t device;                   /* HIP device ordinal */
+  int32_t rank, world_size;         /* EPS index space sharding across GPUs; 0/1 = single GPU */
+  int32_t use_fixed_bound;          /* 1: first-solution search under obj <= fixed_bound, lowest subproblem wins (canonical pass) */
+  int32_t fixed_bound;
+  int32_t deterministic;            /* tb_solve only: after B&B, run the canonical pass so the returned solution is the
+                                       DFS-first optimal one (bit-identical to the sequential oracle) */
+  int32_t snapshot_levels;          /* per-workgroup snapshot stack depth in HBM; 0 = auto, 1 = reference behaviour (recompute from subproblem root) */
+  int32_t reserved[3];
+} tb_config;
+
+/* Statistics<> (include/statistics.hpp:134-154) + TimingStatistics (statistics.hpp:13-29). */
+typedef struct {
+  uint64_t nodes, fails, solutions, fixpoint_iterations, num_deductions;
+  uint64_t eps_num_subproblems, eps_solved_subproblems, eps_skipped_subproblems, num_blocks_done;
+  int64_t timers_ns[11];            /* indexed by tb_timer, summed over workgroups like statistics.hpp:72-77 */
+  int64_t cumulative_time_block_ns;
+  int64_t kernel_ns;                /* wall time of the persistent kernel (HIP events) */
+  uint64_t store_writes;            /* number of narrowed bounds written by deduce (roofline write term) */
+  int32_t depth_max, num_blocks, threads_per_block, exhaustive;
+  int32_t mem_kind, shared_bytes, subproblems_power, best_bound;
+  int32_t best_subproblem, interrupted;
+  int32_t reserved[2];
+} tb_stats;
+
+enum tb_timer { /* enum class Timer, statistics.hpp:13-29 (same order, 11 timers) */
+  TB_T_OVERALL = 0, TB_T_PREPROCESSING = 1, TB_T_SEARCH = 2, TB_T_FIXPOINT = 3, TB_T_TRANSFER_CPU2GPU = 4,
+  TB_T_TRANSFER_GPU2CPU = 5, TB_T_SELECT_FP_FUNCTIONS = 6, TB_T_WAIT_CPU = 7, TB_T_DIVE = 8,
+  TB_T_LATEST_BEST_OBJ_FOUND = 9, TB_T_FIRST_BLOCK_IDLE = 10, TB_NUM_TIMERS = 11
+};
+
+typedef struct {
+  char name[256];
+  int32_t compute_units, lds_bytes_per_cu, wavefront_size, clock_khz;
+  int64_t total_global_mem;
+  int32_t is_gfx950, xcc_count;
+} tb_device_info;
+
+/* Library identification and per-thread error text. */
+const char* tb_version(void);
+const char* tb_last_error(void);
+int tb_device_count(void);
+int tb_get_device_info(int device, tb_device_info* out);
+
+/*
+ * One search node for a batch of independent stores: block-parallel fixpoint of all propagators
+ * (AC1 / WAC1) followed by the entailment test.  Replaces the device function `propagate`
+ * (gpu_dive_and_solve.hpp:287-368, barebones_dive_and_solve.hpp:903-1031) minus bookkeeping.
+ * One store per workgroup.  stores_inout holds n_stores * n_vars intervals and is overwritten
+ * with the fixpoint.  Any *_out pointer may be NULL.
+ */
+int tb_propagate(const tb_config* cfg, int32_t n_vars, int32_t n_props, const tb_prop* props,
+                 int32_t n_stores, tb_itv* stores_inout, int32_t* failed_out, int32_t* all_entailed_out,
+                 uint64_t* iterations_out, uint64_t* deductions_out, int64_t* kernel_ns_out);
+
+/*
+ * Full dive-and-solve.  Replaces gpu_dive_and_solve (gpu_dive_and_solve.hpp:680-700 after preprocess)
+ * and barebones_dive_and_solve (barebones_dive_and_solve.hpp:479-497).  Always minimises obj_var
+ * (obj_var = -1: satisfaction), like barebones (common_solving.hpp:277-279).
+ * Strategies are flattened: strategy s branches on strat_vars[strat_off[s] .. strat_off[s+1]); an empty
+ * range means every variable of the store (barebones:242-243).
+ * Blocks until the search ends, the timeout expires, or *host_stop_flag becomes non-zero
+ * (set by the caller's SIGINT logic, common_solving.hpp:56-104).
+ */
+int tb_solve(const tb_config* cfg, int32_t n_vars, const tb_itv* root_store,
+             int32_t n_props, const tb_prop* props,
+             int32_t n_strats, const int32_t* strat_var_order, const int32_t* strat_val_order,
+             const int32_t* strat_off, const int32_t* strat_vars,
+             int32_t obj_var, volatile int32_t* host_stop_flag,
+             tb_itv* best_store_out, int32_t* has_solution_out, tb_stats* stats_out);
+
+/*
+ * Asynchronous form of tb_solve (what a multi-GPU host uses: one session per device / process).
+ * create: uploads the TCN, sizes LDS/HBM buffers (replaces configure_memory / configure_gpu_barebones,
+ * gpu_dive_and_solve.hpp:534-584, barebones:527-606).  start: launches the persistent kernel.
+ * poll: non-blocking; returns the device's current incumbent bound and whether the kernel finished.
+ * push_bound: imports a foreign incumbent (the only payload exchanged between GPUs).
+ * stop: asks every workgroup to stop at its next node.  finish: waits, reduces the workgroups
+ * (replaces reduce_blocks, barebones:1033-1067) and copies the results out.
+ */
+typedef struct tb_session tb_session;
+int tb_session_create(const tb_config* cfg, int32_t n_vars, const tb_itv* root_store,
+                      int32_t n_props, const tb_prop* props,
+                      int32_t n_strats, const int32_t* strat_var_order, const int32_t* strat_val_order,
+                      const int32_t* strat_off, const int32_t* strat_vars,
+                      int32_t obj_var, tb_session** out);
+int tb_session_start(tb_session* s);
+int tb_session_poll(tb_session* s, int32_t* local_best_out, int32_t* done_out);
+int tb_session_push_bound(tb_session* s, int32_t bound);
+int tb_session_stop(tb_session* s);
+int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_solution_out, tb_stats* stats_out);
+void tb_session_destroy(tb_session* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

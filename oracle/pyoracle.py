@@ -1,0 +1,101 @@
+"""ctypes loader of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under turbo_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+ITV = np.dtype([("lb", np.int32), ("ub", np.int32)])
+PROP = np.dtype([("op", np.int32), ("x", np.int32), ("y", np.int32), ("z", np.int32)])
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [("subproblems_power", C.c_int32), ("has_eps_strategy", C.c_int32),
+                ("use_fixed_bound", C.c_int32), ("fixed_bound", C.c_int32),
+                ("stop_after_n_nodes", C.c_uint64), ("stop_after_n_solutions", C.c_uint64),
+                ("timeout_ms", C.c_uint64)]
+
+
+class OrcStats(C.Structure):
+    _fields_ = [("nodes", C.c_uint64), ("fails", C.c_uint64), ("solutions", C.c_uint64),
+                ("fixpoint_iterations", C.c_uint64), ("num_deductions", C.c_uint64),
+                ("eps_num_subproblems", C.c_uint64), ("eps_solved_subproblems", C.c_uint64),
+                ("eps_skipped_subproblems", C.c_uint64),
+                ("depth_max", C.c_int32), ("exhaustive", C.c_int32),
+                ("best_bound", C.c_int32), ("best_subproblem", C.c_int32),
+                ("solve_seconds", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "oracle.c")):
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_deduce.restype = C.c_int
+        L.orc_deduce.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.orc_ask.restype = C.c_int
+        L.orc_ask.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_propagate.restype = C.c_int
+        L.orc_propagate.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        L.orc_solve.restype = C.c_int
+        L.orc_solve.argtypes = [C.POINTER(OrcConfig), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(OrcStats)]
+        _lib = L
+    return _lib
+
+
+def propagate(store: np.ndarray, props: np.ndarray):
+    """One node.  Returns (store_out, failed, all_entailed, iterations, deductions)."""
+    st = np.ascontiguousarray(store, dtype=ITV).copy()
+    pr = np.ascontiguousarray(props, dtype=PROP)
+    it, de, ent = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+    failed = lib().orc_propagate(st.shape[0], st.ctypes.data, pr.shape[0], pr.ctypes.data,
+                                 C.byref(it), C.byref(de), C.byref(ent))
+    return st, bool(failed), bool(ent.value), it.value, de.value
+
+
+def solve(tcn, subproblems_power: int = 0, cutnodes: int = 0, timeout_ms: int = 0,
+          stop_after_n_solutions: int = 1, fixed_bound=None):
+    """Full sequential search over a turbo_amd.frontend.TCN-like object.
+    Returns (has_solution, best_store, stats_dict)."""
+    cfg = OrcConfig(subproblems_power=subproblems_power, has_eps_strategy=int(bool(getattr(tcn, "has_eps_strategy", False))),
+                    use_fixed_bound=int(fixed_bound is not None), fixed_bound=int(fixed_bound or 0),
+                    stop_after_n_nodes=cutnodes, stop_after_n_solutions=stop_after_n_solutions, timeout_ms=timeout_ms)
+    store = np.ascontiguousarray(tcn.store, dtype=ITV)
+    props = np.ascontiguousarray(tcn.props, dtype=PROP)
+    vo = np.ascontiguousarray(tcn.strat_var_order, dtype=np.int32)
+    vl = np.ascontiguousarray(tcn.strat_val_order, dtype=np.int32)
+    off = np.ascontiguousarray(tcn.strat_off, dtype=np.int32)
+    sv = np.ascontiguousarray(tcn.strat_vars, dtype=np.int32)
+    best = np.zeros(store.shape[0], dtype=ITV)
+    has = C.c_int32(0)
+    stats = OrcStats()
+    rc = lib().orc_solve(C.byref(cfg), store.shape[0], store.ctypes.data, props.shape[0], props.ctypes.data,
+                         vo.shape[0], vo.ctypes.data, vl.ctypes.data, off.ctypes.data, sv.ctypes.data,
+                         int(tcn.obj_var), best.ctypes.data, C.byref(has), C.byref(stats))
+    if rc != 0:
+        raise RuntimeError(f"orc_solve failed with {rc}")
+    return bool(has.value), best, stats.as_dict()

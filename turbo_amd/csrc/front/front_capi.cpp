@@ -1,0 +1,123 @@
+// C-ABI of the front-end (include/turbo_front.h).
+#include "../../../include/turbo_front.h"
+
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "tcn.hpp"
+
+using namespace turbo_front;
+
+struct tf_model {
+  TCN tcn;
+};
+
+namespace {
+
+void set_err(char* err, int32_t err_len, const std::string& msg) {
+  if (!err || err_len <= 0) return;
+  std::strncpy(err, msg.c_str(), (size_t)err_len - 1);
+  err[err_len - 1] = '\0';
+}
+
+tf_model* build(const std::string& text, char* err, int32_t err_len) {
+  try {
+    Model m = parse_flatzinc(text);
+    tf_model* out = new tf_model;
+    out->tcn = lower_to_tcn(m);
+    return out;
+  } catch (const std::exception& e) {
+    set_err(err, err_len, e.what());
+    return nullptr;
+  }
+}
+
+std::string value_text(const tb_itv& d, bool is_bool) {
+  // A solution box may leave a variable unassigned when every propagator is already entailed
+  // (barebones:971-993): every point of the box is a solution and we print its lower corner.
+  int64_t v = d.lb;
+  if (is_bool) return v != 0 ? "true" : "false";
+  return std::to_string(v);
+}
+
+}  // namespace
+
+extern "C" {
+
+tf_model* tf_load_fzn(const char* path, char* err, int32_t err_len) {
+  std::ifstream in(path);
+  if (!in) { set_err(err, err_len, std::string("Could not open input file ") + (path ? path : "(null)")); return nullptr; }
+  std::stringstream ss;
+  ss << in.rdbuf();
+  return build(ss.str(), err, err_len);
+}
+
+tf_model* tf_load_fzn_string(const char* text, char* err, int32_t err_len) { return build(text ? text : "", err, err_len); }
+
+void tf_free(tf_model* m) { delete m; }
+
+int32_t tf_num_vars(const tf_model* m) { return (int32_t)m->tcn.store.size(); }
+int32_t tf_num_props(const tf_model* m) { return (int32_t)m->tcn.props.size(); }
+const tb_itv* tf_store(const tf_model* m) { return m->tcn.store.data(); }
+const tb_prop* tf_props(const tf_model* m) { return m->tcn.props.data(); }
+int32_t tf_num_strategies(const tf_model* m) { return (int32_t)m->tcn.strategies.size(); }
+const int32_t* tf_strat_var_order(const tf_model* m) { return m->tcn.f_var_order.data(); }
+const int32_t* tf_strat_val_order(const tf_model* m) { return m->tcn.f_val_order.data(); }
+const int32_t* tf_strat_off(const tf_model* m) { return m->tcn.f_off.data(); }
+const int32_t* tf_strat_vars(const tf_model* m) { return m->tcn.f_vars.data(); }
+
+int32_t tf_push_eps_strategy(tf_model* m, int32_t var_order, int32_t val_order) {
+  if (var_order < TB_INPUT_ORDER || var_order > TB_LARGEST || val_order < TB_VAL_MIN || val_order > TB_VAL_REVERSE_SPLIT) return -1;
+  Strategy s;
+  s.var_order = var_order; s.val_order = val_order;
+  // The EPS strategy ranges over the variables of the model's first search annotation (whole store if none).
+  if (m->tcn.strategies.size() > 1) s.vars = m->tcn.strategies.front().vars;
+  m->tcn.strategies.insert(m->tcn.strategies.begin(), s);
+  m->tcn.flatten_strategies();
+  return 0;
+}
+
+int32_t tf_obj_var(const tf_model* m) { return m->tcn.obj_var; }
+int32_t tf_goal(const tf_model* m) { return m->tcn.goal; }
+int32_t tf_goal_var(const tf_model* m) { return m->tcn.goal_var; }
+int32_t tf_trivially_unsat(const tf_model* m) { return m->tcn.trivially_unsat ? 1 : 0; }
+int32_t tf_parsed_variables(const tf_model* m) { return m->tcn.parsed_variables; }
+int32_t tf_parsed_constraints(const tf_model* m) { return m->tcn.parsed_constraints; }
+
+int64_t tf_objective_of(const tf_model* m, const tb_itv* store) {
+  if (m->tcn.goal_var < 0) return 0;
+  const tb_itv d = store[m->tcn.goal_var];
+  return m->tcn.goal == 2 ? d.ub : d.lb;
+}
+
+int32_t tf_format_solution(const tf_model* m, const tb_itv* store, char* buf, int32_t buf_len) {
+  std::string out;
+  for (const OutputItem& o : m->tcn.outputs) {
+    if (!o.is_array) {
+      out += o.name + " = " + value_text(store[o.vars[0]], o.is_bool) + ";\n";
+      continue;
+    }
+    out += o.name + " = array" + std::to_string(o.dims.size()) + "d(";
+    for (auto& d : o.dims) out += std::to_string(d.first) + ".." + std::to_string(d.second) + ", ";
+    out += "[";
+    for (size_t i = 0; i < o.vars.size(); ++i) {
+      if (i) out += ", ";
+      out += value_text(store[o.vars[i]], o.is_bool);
+    }
+    out += "]);\n";
+  }
+  if (buf && buf_len > 0) {
+    size_t n = std::min((size_t)buf_len - 1, out.size());
+    std::memcpy(buf, out.data(), n);
+    buf[n] = '\0';
+  }
+  return (int32_t)out.size();
+}
+
+const char* tf_var_name(const tf_model* m, int32_t var) {
+  if (var < 0 || var >= (int32_t)m->tcn.names.size()) return "";
+  return m->tcn.names[(size_t)var].c_str();
+}
+
+}  // extern "C"

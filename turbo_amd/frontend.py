@@ -1,0 +1,181 @@
+"""ctypes binding of the host front-end (libturbo_front.so, include/turbo_front.h).
+
+FlatZinc -> ternary constraint network, the stand-in for the reference's
+``AbstractDomains::preprocess()`` (include/common_solving.hpp:605-637) in its
+``-disable_simplify`` pipeline.  The arrays it returns are exactly what crosses the
+C-ABI of the engine (include/turbo_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libturbo_front.so")
+
+ITV_DTYPE = np.dtype([("lb", np.int32), ("ub", np.int32)])
+PROP_DTYPE = np.dtype([("op", np.int32), ("x", np.int32), ("y", np.int32), ("z", np.int32)])
+
+OP_NAMES = ["ADD", "MUL", "TDIV", "TMOD", "MIN", "MAX", "EQ", "LEQ"]
+VAR_ORDERS = {"input_order": 0, "first_fail": 1, "anti_first_fail": 2, "smallest": 3, "largest": 4}
+VAL_ORDERS = {"min": 0, "max": 1, "split": 2, "reverse_split": 3}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: build it with `make front` (or `python -c 'import __graft_entry__ as g; g.build()'`)")
+        L = C.CDLL(_LIB_PATH)
+        L.tf_load_fzn.restype = C.c_void_p
+        L.tf_load_fzn.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
+        L.tf_load_fzn_string.restype = C.c_void_p
+        L.tf_load_fzn_string.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
+        L.tf_free.argtypes = [C.c_void_p]
+        for name in ("tf_num_vars", "tf_num_props", "tf_num_strategies", "tf_obj_var", "tf_goal", "tf_goal_var",
+                     "tf_trivially_unsat", "tf_parsed_variables", "tf_parsed_constraints"):
+            getattr(L, name).restype = C.c_int32
+            getattr(L, name).argtypes = [C.c_void_p]
+        for name in ("tf_store", "tf_props", "tf_strat_var_order", "tf_strat_val_order", "tf_strat_off", "tf_strat_vars"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.tf_push_eps_strategy.restype = C.c_int32
+        L.tf_push_eps_strategy.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.tf_objective_of.restype = C.c_int64
+        L.tf_objective_of.argtypes = [C.c_void_p, C.c_void_p]
+        L.tf_format_solution.restype = C.c_int32
+        L.tf_format_solution.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32]
+        L.tf_var_name.restype = C.c_char_p
+        L.tf_var_name.argtypes = [C.c_void_p, C.c_int32]
+        _lib = L
+    return _lib
+
+
+def _copy(ptr: int, n: int, dtype) -> np.ndarray:
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+@dataclass
+class TCN:
+    """The preprocessed problem that crosses the engine's C-ABI (plain arrays)."""
+    store: np.ndarray            # ITV_DTYPE[n_vars]
+    props: np.ndarray            # PROP_DTYPE[n_props]
+    strat_var_order: np.ndarray  # int32[n_strats]
+    strat_val_order: np.ndarray  # int32[n_strats]
+    strat_off: np.ndarray        # int32[n_strats + 1]
+    strat_vars: np.ndarray       # int32[total]
+    obj_var: int = -1            # variable to minimise (-1: satisfaction)
+    goal: int = 0                # 0 satisfy, 1 minimize, 2 maximize (as written)
+    goal_var: int = -1
+    trivially_unsat: bool = False
+    has_eps_strategy: bool = False
+    parsed_variables: int = 0
+    parsed_constraints: int = 0
+    _model: "Model | None" = field(default=None, repr=False)
+
+    @property
+    def n_vars(self) -> int:
+        return int(self.store.shape[0])
+
+    @property
+    def n_props(self) -> int:
+        return int(self.props.shape[0])
+
+    @property
+    def n_strats(self) -> int:
+        return int(self.strat_var_order.shape[0])
+
+    def objective_of(self, store: np.ndarray) -> int:
+        """Objective as the reference prints it (statistics.hpp:378-388)."""
+        if self.goal_var < 0:
+            return 0
+        d = store[self.goal_var]
+        return int(d["ub"] if self.goal == 2 else d["lb"])
+
+    def format_solution(self, store: np.ndarray) -> str:
+        if self._model is None:
+            return ""
+        return self._model.format_solution(store)
+
+
+class Model:
+    """Owns a tf_model handle."""
+
+    def __init__(self, handle: int):
+        self._h = handle
+
+    @classmethod
+    def from_file(cls, path: str) -> "Model":
+        err = C.create_string_buffer(1024)
+        h = lib().tf_load_fzn(os.fsencode(path), err, len(err))
+        if not h:
+            raise ValueError(err.value.decode(errors="replace") or "Could not parse input file.")
+        return cls(h)
+
+    @classmethod
+    def from_string(cls, text: str) -> "Model":
+        err = C.create_string_buffer(1024)
+        h = lib().tf_load_fzn_string(text.encode(), err, len(err))
+        if not h:
+            raise ValueError(err.value.decode(errors="replace") or "Could not parse input file.")
+        return cls(h)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.tf_free(h)
+
+    def push_eps_strategy(self, var_order: str, val_order: str) -> None:
+        if var_order not in VAR_ORDERS:
+            raise ValueError(f"Unrecognized option `-eps_var_order {var_order}`")
+        if val_order not in VAL_ORDERS:
+            raise ValueError(f"Unrecognized option `-eps_value_order {val_order}`")
+        lib().tf_push_eps_strategy(self._h, VAR_ORDERS[var_order], VAL_ORDERS[val_order])
+        self._eps = True
+
+    def tcn(self) -> TCN:
+        L, h = lib(), self._h
+        nv, np_, ns = L.tf_num_vars(h), L.tf_num_props(h), L.tf_num_strategies(h)
+        off = _copy(L.tf_strat_off(h), ns + 1, np.int32)
+        return TCN(
+            store=_copy(L.tf_store(h), nv, ITV_DTYPE),
+            props=_copy(L.tf_props(h), np_, PROP_DTYPE),
+            strat_var_order=_copy(L.tf_strat_var_order(h), ns, np.int32),
+            strat_val_order=_copy(L.tf_strat_val_order(h), ns, np.int32),
+            strat_off=off,
+            strat_vars=_copy(L.tf_strat_vars(h), max(int(off[-1]), 1), np.int32),
+            obj_var=L.tf_obj_var(h), goal=L.tf_goal(h), goal_var=L.tf_goal_var(h),
+            trivially_unsat=bool(L.tf_trivially_unsat(h)),
+            has_eps_strategy=bool(getattr(self, "_eps", False)),
+            parsed_variables=L.tf_parsed_variables(h), parsed_constraints=L.tf_parsed_constraints(h),
+            _model=self,
+        )
+
+    def format_solution(self, store: np.ndarray) -> str:
+        store = np.ascontiguousarray(store, dtype=ITV_DTYPE)
+        n = lib().tf_format_solution(self._h, store.ctypes.data, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib().tf_format_solution(self._h, store.ctypes.data, buf, n + 1)
+        return buf.value.decode()
+
+    def var_name(self, v: int) -> str:
+        return lib().tf_var_name(self._h, v).decode()
+
+
+def load_fzn(path: str, eps_var_order: str = "default", eps_value_order: str = "default") -> TCN:
+    """Parse + lower a FlatZinc file; optional EPS strategy like `-eps_var_order/-eps_value_order`."""
+    m = Model.from_file(path)
+    if (eps_var_order == "default") != (eps_value_order == "default"):
+        raise ValueError("-eps_var_order and -eps_value_order must be specified together.")
+    if eps_var_order != "default":
+        m.push_eps_strategy(eps_var_order, eps_value_order)
+    return m.tcn()
