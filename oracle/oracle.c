@@ -362,8 +362,10 @@ static int propagate(engine_t* e, int is_dive) {
     if (ent) {
       leaf = 1;
       int accept;
-      if (e->obj_var >= 0) accept = e->best_bound > e->store[e->obj_var].lb;
-      else accept = 1;
+      if (e->obj_var >= 0) {
+        accept = e->best_bound > e->store[e->obj_var].lb;
+        if (e->cfg->use_fixed_bound && e->store[e->obj_var].lb > e->cfg->fixed_bound) accept = 0; /* dive leaves carry no bound */
+      } else accept = 1;
       if (accept) {
         if (e->obj_var >= 0) e->best_bound = e->store[e->obj_var].lb;
         memcpy(e->best_store, e->store, sizeof(orc_itv) * (size_t)e->n_vars);

@@ -1,0 +1,164 @@
+"""GPU parity tests: the HIP engine (through the C-ABI) against the CPU oracle on the same inputs.
+
+Bar: bit-exact.  The fixpoint of a node is unique (monotone contracting propagators), so the store
+after `tb_propagate` must equal the oracle's Gauss-Seidel fixpoint on every non-failed node, and the
+failed / all-entailed flags must agree on every node.
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import BENCH, SLOW_FOR_ORACLE, known_answers
+from oracle import pyoracle
+from turbo_amd import capi, frontend
+
+pytestmark = pytest.mark.gpu
+
+ROWS = known_answers()
+FAST = [r for r in ROWS if r[0] not in SLOW_FOR_ORACLE]
+HEADLINE = ["example_wordpress7_500.fzn", "accap_a3.fzn"]
+
+
+def load(rel):
+    return frontend.load_fzn(os.path.join(BENCH, rel))
+
+
+def random_nodes(tcn, n_nodes, seed, max_decisions=12):
+    """Stores of random search nodes: root fixpoint + a random sequence of branching decisions
+    (each re-propagated by the oracle so the next decision is taken on a consistent store)."""
+    rng = np.random.default_rng(seed)
+    root, failed, _, _, _ = pyoracle.propagate(tcn.store, tcn.props)
+    out = [tcn.store.copy()]
+    if failed:
+        return np.stack(out)
+    for _ in range(n_nodes - 1):
+        st = root.copy()
+        k = int(rng.integers(1, max_decisions + 1))
+        for _ in range(k):
+            free = np.flatnonzero((st["lb"] < st["ub"]) & (st["lb"] > capi.TB_NINF) & (st["ub"] < capi.TB_PINF))
+            if free.size == 0:
+                break
+            v = int(rng.choice(free))
+            lo, hi = int(st["lb"][v]), int(st["ub"][v])
+            mid = int(rng.integers(lo, hi + 1))
+            if rng.random() < 0.5:
+                st["ub"][v] = mid
+            else:
+                st["lb"][v] = mid
+            pre = st.copy()
+            st, failed, _, _, _ = pyoracle.propagate(st, tcn.props)
+            if failed:
+                st = pre  # keep the un-propagated store: the GPU must detect the failure itself
+                break
+            if rng.random() < 0.3:
+                st = pre  # hand over a store that still needs propagation
+        out.append(st)
+    return np.stack(out)
+
+
+def check_batch(tcn, stores, **cfg):
+    got, failed, ent, iters, ded, _ = capi.propagate(tcn.props, stores, capi.make_config(**cfg))
+    for i in range(stores.shape[0]):
+        exp, efailed, eent, _, _ = pyoracle.propagate(stores[i], tcn.props)
+        assert bool(failed[i]) == efailed, f"store {i}: failed flag differs"
+        if not efailed:
+            assert bool(ent[i]) == eent, f"store {i}: entailment flag differs"
+            np.testing.assert_array_equal(got[i]["lb"], exp["lb"], err_msg=f"store {i}: lower bounds differ")
+            np.testing.assert_array_equal(got[i]["ub"], exp["ub"], err_msg=f"store {i}: upper bounds differ")
+        assert iters[i] >= 1 or efailed
+
+
+@pytest.mark.parametrize("rel", [r[0] for r in ROWS] + HEADLINE)
+@pytest.mark.parametrize("fixpoint", [0, 1], ids=["ac1", "wac1"])
+def test_root_fixpoint_bit_exact(rel, fixpoint):
+    tcn = load(rel)
+    check_batch(tcn, tcn.store[None, :], fixpoint=fixpoint)
+
+
+@pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pennies5.fzn",
+                                 "test_data/triangular9.fzn", "test_data/bug4.fzn", "accap_a3.fzn"])
+@pytest.mark.parametrize("mode", ["wac1", "ac1", "globalmem", "t1024"])
+def test_random_nodes_bit_exact(rel, mode):
+    tcn = load(rel)
+    stores = random_nodes(tcn, 48, seed=zlib.crc32(rel.encode()) % 1000)
+    cfg = {"wac1": dict(fixpoint=1), "ac1": dict(fixpoint=0), "globalmem": dict(fixpoint=1, only_global_memory=1),
+           "t1024": dict(fixpoint=1, threads_per_block=1024)}[mode]
+    check_batch(tcn, stores, **cfg)
+
+
+def test_wordpress_nodes_bit_exact():
+    tcn = load("example_wordpress7_500.fzn")
+    stores = random_nodes(tcn, 12, seed=7, max_decisions=6)
+    check_batch(tcn, stores, fixpoint=1)
+
+
+@pytest.mark.parametrize("rel,expected", FAST)
+def test_sequential_tree_identical(rel, expected):
+    """One workgroup, one subproblem: the GPU explores exactly the oracle's DFS tree."""
+    tcn = load(rel)
+    has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=0, timeout_ms=120000)
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=0, timeout_ms=120000))
+    assert has_g == has_o and st_g["exhaustive"] == st_o["exhaustive"] == 1
+    assert tcn.objective_of(best_g) == expected
+    for k in ("nodes", "fails", "solutions", "depth_max"):
+        assert st_g[k] == st_o[k], k
+    np.testing.assert_array_equal(best_g, best_o)
+
+
+@pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pat7.fzn", "test_data/sudoku_opt_p0.fzn"])
+@pytest.mark.parametrize("power", [3, 6])
+def test_sequential_eps_identical(rel, power):
+    """One workgroup walking 2^d subproblems in index order == the oracle's sequential dive-and-solve."""
+    tcn = load(rel)
+    has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power)
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=power, timeout_ms=120000))
+    assert has_g == has_o
+    for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
+        assert st_g[k] == st_o[k], k
+    np.testing.assert_array_equal(best_g, best_o)
+
+
+@pytest.mark.parametrize("rel,expected", ROWS)
+def test_parallel_objective_matches_known_answer(rel, expected):
+    """Reference regression contract (test_turbo.sh:34-67): the objective of every instance."""
+    tcn = load(rel)
+    has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=60000))
+    assert has
+    assert tcn.objective_of(best) == expected
+    assert st["exhaustive"] == 1, "optimality must be proved within the reference's 60 s budget"
+
+
+@pytest.mark.parametrize("rel,expected", FAST)
+def test_parallel_canonical_solution_bit_exact(rel, expected):
+    """deterministic=1: the returned solution is the DFS-first optimal one, identical to the oracle's."""
+    tcn = load(rel)
+    power = 8
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(timeout_ms=60000, deterministic=1, subproblems_power=power))
+    assert has_g and st_g["exhaustive"] == 1
+    has_b, best_b, st_b = pyoracle.solve(tcn, subproblems_power=power)
+    assert st_b["best_bound"] == st_g["best_bound"]
+    has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power, fixed_bound=st_b["best_bound"])
+    assert has_o
+    np.testing.assert_array_equal(best_g, best_o)
+    assert st_g["best_subproblem"] == st_o["best_subproblem"]
+
+
+def test_unsat_and_errors():
+    tcn = frontend.Model.from_string("var 1..3: x; var 1..3: y; constraint int_lt(x,y); constraint int_lt(y,x); solve satisfy;").tcn()
+    has, _, st = capi.solve(tcn, capi.make_config(timeout_ms=20000))
+    assert not has and st["exhaustive"] == 1 and st["solutions"] == 0
+    bad = tcn.props.copy()
+    bad["x"][0] = 10 ** 6
+    with pytest.raises(capi.TurboHipError):
+        capi.propagate(bad, tcn.store[None, :])
+
+
+def test_satisfaction_first_solution():
+    tcn = frontend.Model.from_string(
+        "var 1..4: a; var 1..4: b; var 1..4: c; constraint int_lin_eq([1,1,1],[a,b,c],7); constraint int_lt(a,b); solve satisfy;").tcn()
+    has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=20000))
+    assert has
+    a, b, c = (int(best["lb"][i]) for i in range(3, 6))
+    assert a + b + c == 7 and a < b

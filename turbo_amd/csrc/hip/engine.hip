@@ -1,0 +1,586 @@
+// libturbo_hip.so -- host shim of the MI355X dive-and-solve engine (C-ABI in include/turbo_hip.h).
+//
+// Replaces the host halves of the reference's GPU path:
+//   include/memory_gpu.hpp:27-84        MemoryConfig (what lives in LDS)             -> plan_launch()
+//   include/barebones_dive_and_solve.hpp:527-606  configure_gpu_barebones           -> plan_launch()
+//   include/barebones_dive_and_solve.hpp:479-497  launch / wait / reduce_blocks      -> tb_session_*
+//   include/memory_gpu.hpp:174-196      wait_solving_ends (100 ms poll)             -> tb_solve()
+// No managed memory and no device-side malloc: every buffer is sized on the host and the only
+// host<->device traffic during the search is one pinned 16-byte mailbox.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace tb;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+  do {                                                                                                      \
+    hipError_t _e = (expr);                                                                                 \
+    if (_e != hipSuccess) {                                                                                 \
+      if (_e == hipErrorOutOfMemory) return fail(TB_ERR_OOM, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+      return fail(TB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                           \
+    }                                                                                                       \
+  } while (0)
+
+struct DeviceCaps {
+  int cus = 0, lds_per_cu = 0, wall_khz = 100000;
+  size_t free_mem = 0, total_mem = 0;
+  std::string arch;
+};
+
+int query_caps(int device, DeviceCaps* caps) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(TB_ERR_NO_DEVICE, "no HIP device is visible: the MI355X engine has no CPU fallback");
+  if (device < 0 || device >= n) return fail(TB_ERR_INVALID, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  caps->cus = prop.multiProcessorCount;
+  caps->arch = prop.gcnArchName;
+  int lds = 0;
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) != hipSuccess || lds <= 0) lds = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (lds <= 0) lds = 64 * 1024;
+  caps->lds_per_cu = lds;
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) caps->wall_khz = khz;
+  HIP_TRY(hipMemGetInfo(&caps->free_mem, &caps->total_mem));
+  return TB_OK;
+}
+
+// ---- launch planning -----------------------------------------------------------------------------
+
+struct LaunchPlan {
+  int threads = 256, tmax = 256;
+  int blocks_per_cu = 1, num_blocks = 1;
+  int mem_kind = TB_MEM_GLOBAL;
+  int shared_bytes = 0;
+  int subproblems_power = 0;
+  int snapshot_levels = 1;
+  int max_depth = 16384;
+};
+
+inline size_t align16(size_t x) { return (x + 15) / 16 * 16; }
+
+// Which memory holds what (the MemoryKind decision of memory_gpu.hpp:56-83 with CDNA4 numbers:
+// 160 KiB of LDS per CU, wave64, at most 32 waves per CU) and how many workgroups to launch
+// (barebones:530-546: occupancy x CUs, capped by -or).
+int plan_launch(const tb_config& cfg, const DeviceCaps& caps, int n_vars, int n_props, LaunchPlan* plan) {
+  LaunchPlan p;
+  int T = cfg.threads_per_block;
+  if (T == 0) T = n_props >= 16384 ? 1024 : (n_props >= 2048 ? 512 : 256);
+  if (T != 64 && T != 128 && T != 256 && T != 512 && T != 1024) return fail(TB_ERR_INVALID, "threads_per_block must be 64, 128, 256, 512 or 1024");
+  p.threads = T;
+  p.tmax = T <= 256 ? 256 : 1024;
+  const size_t lds = (size_t)caps.lds_per_cu;
+  const size_t store_b = align16((size_t)n_vars * 8), props_b = align16((size_t)n_props * 16);
+  const size_t fixed = SH_BYTES;
+  int bpc_max = std::min(8, 2048 / T);  // 32 waves per CU
+  if (bpc_max < 1) bpc_max = 1;
+  if (cfg.only_global_memory) {
+    p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)fixed;
+  } else if ((fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
+    p.mem_kind = TB_MEM_TCN_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b + props_b);
+  } else if ((fixed + store_b) * (size_t)bpc_max <= lds) {
+    p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b);
+  } else if (fixed + store_b <= lds) {
+    p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / (fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
+  } else {
+    p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)fixed;
+  }
+  long long blocks = (long long)p.blocks_per_cu * caps.cus;
+  if (cfg.or_nodes != 0) blocks = std::min<long long>(blocks, (long long)cfg.or_nodes);
+  blocks = std::min<long long>(blocks, std::max<long long>(1, 200000000ll / std::max(1, n_vars)));  // barebones:584
+  p.num_blocks = (int)std::max<long long>(1, blocks);
+  // II. number of subproblems: 2^d >= subfactor x blocks (x GPUs) (barebones:550-555)
+  p.subproblems_power = cfg.subproblems_power;
+  if (p.subproblems_power < 0) {
+    const unsigned long long world = (unsigned long long)std::max(1, cfg.world_size);
+    const unsigned long long target = std::max<unsigned long long>(1, cfg.subproblems_factor) * (unsigned long long)p.num_blocks * world;
+    int d = 0;
+    while (d < 40 && (1ull << d) < target) ++d;
+    p.subproblems_power = d;
+  }
+  if (p.subproblems_power > 62) return fail(TB_ERR_INVALID, "subproblems_power must be <= 62");
+  // snapshot stack: as deep as 1/4 of the free HBM allows (288 GB per GPU makes copying cheaper than
+  // recomputing from the subproblem root)
+  p.max_depth = 16384;
+  int L = cfg.snapshot_levels;
+  if (L <= 0) {
+    const size_t per_level = (size_t)p.num_blocks * (size_t)std::max(1, n_vars) * 8;
+    size_t budget = caps.free_mem / 4;
+    L = (int)std::min<size_t>(256, std::max<size_t>(1, budget / std::max<size_t>(1, per_level)));
+  }
+  p.snapshot_levels = std::max(1, std::min(L, p.max_depth));
+  *plan = p;
+  return TB_OK;
+}
+
+int validate_network(int32_t n_vars, const tb_itv* store, int32_t n_props, const tb_prop* props) {
+  if (n_vars < 0 || n_props < 0 || (n_vars > 0 && !store) || (n_props > 0 && !props)) return fail(TB_ERR_INVALID, "null or negative-sized network");
+  for (int32_t i = 0; i < n_props; ++i) {
+    const tb_prop& p = props[i];
+    if (p.op < 0 || p.op >= TB_NUM_OPS) return fail(TB_ERR_INVALID, "propagator " + std::to_string(i) + ": unknown operator");
+    if (p.x < 0 || p.x >= n_vars || p.y < 0 || p.y >= n_vars || p.z < 0 || p.z >= n_vars) return fail(TB_ERR_INVALID, "propagator " + std::to_string(i) + ": variable out of range");
+  }
+  return TB_OK;
+}
+
+template <int MEM, int TMAX>
+int set_lds_limit_solve(int bytes) {
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<MEM, TMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return TB_OK;
+}
+template <int MEM, int TMAX>
+int set_lds_limit_prop(int bytes) {
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<MEM, TMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return TB_OK;
+}
+
+#define DISPATCH_KERNEL(FN, mem, tmax, ...)                                                          \
+  do {                                                                                               \
+    if (tmax == 256) {                                                                               \
+      if (mem == TB_MEM_GLOBAL) FN<TB_MEM_GLOBAL, 256> __VA_ARGS__;                                  \
+      else if (mem == TB_MEM_STORE_SHARED) FN<TB_MEM_STORE_SHARED, 256> __VA_ARGS__;                 \
+      else FN<TB_MEM_TCN_SHARED, 256> __VA_ARGS__;                                                   \
+    } else {                                                                                         \
+      if (mem == TB_MEM_GLOBAL) FN<TB_MEM_GLOBAL, 1024> __VA_ARGS__;                                 \
+      else if (mem == TB_MEM_STORE_SHARED) FN<TB_MEM_STORE_SHARED, 1024> __VA_ARGS__;                \
+      else FN<TB_MEM_TCN_SHARED, 1024> __VA_ARGS__;                                                  \
+    }                                                                                                \
+  } while (0)
+
+int set_lds_limit(bool solve, int mem, int tmax, int bytes) {
+  int rc = TB_OK;
+  if (solve) DISPATCH_KERNEL(rc = set_lds_limit_solve, mem, tmax, (bytes));
+  else DISPATCH_KERNEL(rc = set_lds_limit_prop, mem, tmax, (bytes));
+  return rc;
+}
+
+struct DevBuffers {
+  std::vector<void*> ptrs;
+  ~DevBuffers() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+  template <class Tp>
+  int alloc(Tp** out, size_t count) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(16, count * sizeof(Tp)));
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? TB_ERR_OOM : TB_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    ptrs.push_back(p);
+    *out = static_cast<Tp*>(p);
+    return TB_OK;
+  }
+};
+
+}  // namespace
+
+// ---- session -------------------------------------------------------------------------------------
+
+struct tb_session {
+  tb_config cfg{};
+  DeviceCaps caps;
+  LaunchPlan plan;
+  DevProblem P{};
+  DevBuffers bufs;
+  Mailbox* mbox_host = nullptr;
+  Mailbox* mbox_dev = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  int32_t n_vars = 0, obj_var = -1;
+  bool started = false, finished = false;
+  int host_best = TB_PINF;
+  std::chrono::steady_clock::time_point t_start;
+  ~tb_session() {
+    if (ev_start) (void)hipEventDestroy(ev_start);
+    if (ev_stop) (void)hipEventDestroy(ev_stop);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (mbox_host) (void)hipHostFree(mbox_host);
+  }
+};
+
+extern "C" {
+
+const char* tb_version(void) { return "turbo-hip 0.1.0 (gfx950)"; }
+const char* tb_last_error(void) { return g_last_error.c_str(); }
+
+int tb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int tb_get_device_info(int device, tb_device_info* out) {
+  if (!out) return fail(TB_ERR_INVALID, "null output");
+  DeviceCaps caps;
+  int rc = query_caps(device, &caps);
+  if (rc != TB_OK) return rc;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  std::memset(out, 0, sizeof(*out));
+  std::snprintf(out->name, sizeof(out->name), "%s (%s)", prop.name, prop.gcnArchName);
+  out->compute_units = caps.cus;
+  out->lds_bytes_per_cu = caps.lds_per_cu;
+  out->wavefront_size = prop.warpSize;
+  out->clock_khz = prop.clockRate;
+  out->total_global_mem = (int64_t)prop.totalGlobalMem;
+  out->is_gfx950 = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+  out->xcc_count = 0;
+  return TB_OK;
+}
+
+int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const tb_prop* props,
+                 int32_t n_stores, tb_itv* stores_inout, int32_t* failed_out, int32_t* all_entailed_out,
+                 uint64_t* iterations_out, uint64_t* deductions_out, int64_t* kernel_ns_out) {
+  if (!cfg_in) return fail(TB_ERR_INVALID, "null config");
+  if (n_stores < 0 || (n_stores > 0 && !stores_inout)) return fail(TB_ERR_INVALID, "null stores");
+  tb_config cfg = *cfg_in;
+  int rc = validate_network(n_vars, stores_inout, n_props, props);
+  if (rc != TB_OK) return rc;
+  if (n_stores == 0) return TB_OK;
+  DeviceCaps caps;
+  if ((rc = query_caps(cfg.device, &caps)) != TB_OK) return rc;
+  LaunchPlan plan;
+  if ((rc = plan_launch(cfg, caps, n_vars, n_props, &plan)) != TB_OK) return rc;
+
+  DevBuffers bufs;
+  DevProblem P{};
+  int4* d_props = nullptr; int2* d_stores = nullptr; PropagateOut* d_out = nullptr;
+  if ((rc = bufs.alloc(&d_props, (size_t)n_props)) != TB_OK) return rc;
+  if ((rc = bufs.alloc(&d_stores, (size_t)n_stores * (size_t)n_vars)) != TB_OK) return rc;
+  if ((rc = bufs.alloc(&d_out, (size_t)n_stores)) != TB_OK) return rc;
+  if (n_props) HIP_TRY(hipMemcpy(d_props, props, (size_t)n_props * sizeof(tb_prop), hipMemcpyHostToDevice));
+  if (n_vars) HIP_TRY(hipMemcpy(d_stores, stores_inout, (size_t)n_stores * (size_t)n_vars * sizeof(tb_itv), hipMemcpyHostToDevice));
+  P.n_vars = n_vars; P.n_props = n_props; P.props = d_props;
+  P.fixpoint = cfg.fixpoint; P.wac1_threshold = (int)std::min<uint64_t>(cfg.wac1_threshold, 0x7fffffffu);
+  P.mem_kind = plan.mem_kind;
+  const uint64_t timeout_ms = cfg.timeout_ms ? cfg.timeout_ms : 60000;
+  // watchdog deadline in device wall-clock ticks (read the counter through a tiny query below)
+  if ((rc = set_lds_limit(false, plan.mem_kind, plan.tmax, plan.shared_bytes)) != TB_OK) return rc;
+  hipStream_t stream;
+  HIP_TRY(hipStreamCreate(&stream));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  (void)timeout_ms;
+  P.deadline_ticks = 0;
+  const int grid = std::min(n_stores, plan.num_blocks);
+  HIP_TRY(hipEventRecord(e0, stream));
+  DISPATCH_KERNEL(propagate_kernel, plan.mem_kind, plan.tmax, <<<dim3(grid), dim3(plan.threads), plan.shared_bytes, stream>>>(P, d_stores, d_out, n_stores));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e1, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  if (kernel_ns_out) *kernel_ns_out = (int64_t)((double)ms * 1e6);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(stream);
+  std::vector<PropagateOut> outs((size_t)n_stores);
+  HIP_TRY(hipMemcpy(outs.data(), d_out, (size_t)n_stores * sizeof(PropagateOut), hipMemcpyDeviceToHost));
+  if (n_vars) HIP_TRY(hipMemcpy(stores_inout, d_stores, (size_t)n_stores * (size_t)n_vars * sizeof(tb_itv), hipMemcpyDeviceToHost));
+  for (int32_t s = 0; s < n_stores; ++s) {
+    if (failed_out) failed_out[s] = outs[(size_t)s].failed;
+    if (all_entailed_out) all_entailed_out[s] = outs[(size_t)s].all_entailed;
+    if (iterations_out) iterations_out[s] = outs[(size_t)s].iterations;
+    if (deductions_out) deductions_out[s] = outs[(size_t)s].deductions;
+  }
+  return TB_OK;
+}
+
+int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* root_store,
+                      int32_t n_props, const tb_prop* props,
+                      int32_t n_strats, const int32_t* strat_var_order, const int32_t* strat_val_order,
+                      const int32_t* strat_off, const int32_t* strat_vars,
+                      int32_t obj_var, tb_session** out) {
+  if (!cfg_in || !out) return fail(TB_ERR_INVALID, "null argument");
+  *out = nullptr;
+  int rc = validate_network(n_vars, root_store, n_props, props);
+  if (rc != TB_OK) return rc;
+  if (n_strats < 0 || (n_strats > 0 && (!strat_var_order || !strat_val_order || !strat_off))) return fail(TB_ERR_INVALID, "null strategies");
+  if (obj_var < -1 || obj_var >= n_vars) return fail(TB_ERR_INVALID, "objective variable out of range");
+  int32_t total_svars = n_strats > 0 ? strat_off[n_strats] : 0;
+  for (int32_t s = 0; s < n_strats; ++s) {
+    if (strat_off[s] > strat_off[s + 1] || strat_off[s] < 0) return fail(TB_ERR_INVALID, "strategy offsets must be non-decreasing");
+    if (strat_var_order[s] < TB_INPUT_ORDER || strat_var_order[s] > TB_LARGEST) return fail(TB_ERR_INVALID, "unknown variable order");
+    if (strat_val_order[s] < TB_VAL_MIN || strat_val_order[s] > TB_VAL_REVERSE_SPLIT) return fail(TB_ERR_INVALID, "unknown value order");
+  }
+  if (total_svars > 0 && !strat_vars) return fail(TB_ERR_INVALID, "null strategy variables");
+  for (int32_t i = 0; i < total_svars; ++i)
+    if (strat_vars[i] < 0 || strat_vars[i] >= n_vars) return fail(TB_ERR_INVALID, "strategy variable out of range");
+  if (cfg_in->world_size > 1 && (cfg_in->rank < 0 || cfg_in->rank >= cfg_in->world_size)) return fail(TB_ERR_INVALID, "rank out of range");
+
+  std::unique_ptr<tb_session> s(new tb_session);
+  s->cfg = *cfg_in;
+  s->n_vars = n_vars; s->obj_var = obj_var;
+  if ((rc = query_caps(s->cfg.device, &s->caps)) != TB_OK) return rc;
+  if ((rc = plan_launch(s->cfg, s->caps, n_vars, n_props, &s->plan)) != TB_OK) return rc;
+  const LaunchPlan& plan = s->plan;
+  DevProblem& P = s->P;
+  const size_t V = (size_t)n_vars, B = (size_t)plan.num_blocks;
+
+  int4* d_props = nullptr; int2* d_root = nullptr; int *d_vo = nullptr, *d_vl = nullptr, *d_off = nullptr, *d_sv = nullptr;
+  if ((rc = s->bufs.alloc(&d_props, (size_t)n_props)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&d_root, V)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&d_vo, (size_t)n_strats)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&d_vl, (size_t)n_strats)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&d_off, (size_t)n_strats + 1)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&d_sv, (size_t)total_svars)) != TB_OK) return rc;
+  if (n_props) HIP_TRY(hipMemcpy(d_props, props, (size_t)n_props * sizeof(tb_prop), hipMemcpyHostToDevice));
+  if (n_vars) HIP_TRY(hipMemcpy(d_root, root_store, V * sizeof(tb_itv), hipMemcpyHostToDevice));
+  if (n_strats) {
+    HIP_TRY(hipMemcpy(d_vo, strat_var_order, (size_t)n_strats * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_vl, strat_val_order, (size_t)n_strats * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_off, strat_off, ((size_t)n_strats + 1) * 4, hipMemcpyHostToDevice));
+  } else {
+    int zero = 0;
+    HIP_TRY(hipMemcpy(d_off, &zero, 4, hipMemcpyHostToDevice));
+  }
+  if (total_svars) HIP_TRY(hipMemcpy(d_sv, strat_vars, (size_t)total_svars * 4, hipMemcpyHostToDevice));
+
+  if (plan.mem_kind == TB_MEM_GLOBAL) { if ((rc = s->bufs.alloc(&P.g_store, B * V)) != TB_OK) return rc; }
+  if ((rc = s->bufs.alloc(&P.g_snap, B * (size_t)plan.snapshot_levels * V)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&P.g_best, B * V)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&P.g_dec, B * (size_t)plan.max_depth)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&P.g_stats, B)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&P.ctrl, 1)) != TB_OK) return rc;
+
+  P.n_vars = n_vars; P.n_props = n_props; P.n_strats = n_strats; P.obj_var = obj_var;
+  P.props = d_props; P.root_store = d_root;
+  P.strat_var_order = d_vo; P.strat_val_order = d_vl; P.strat_off = d_off; P.strat_vars = d_sv;
+  P.fixpoint = s->cfg.fixpoint;
+  P.wac1_threshold = (int)std::min<uint64_t>(s->cfg.wac1_threshold, 0x7fffffffu);
+  P.subproblems_power = plan.subproblems_power;
+  P.has_eps_strategy = s->cfg.has_eps_strategy;
+  P.use_fixed_bound = s->cfg.use_fixed_bound; P.fixed_bound = s->cfg.fixed_bound;
+  P.mem_kind = plan.mem_kind; P.snapshot_levels = plan.snapshot_levels; P.max_depth = plan.max_depth;
+  const unsigned long long nsub = 1ull << plan.subproblems_power;
+  const unsigned long long world = (unsigned long long)std::max(1, s->cfg.world_size), rank = (unsigned long long)std::max(0, s->cfg.rank);
+  // contiguous slices keep the subtree skip `((idx >> r) + 1) << r` local to a GPU (clamped at the slice end)
+  P.sub_lo = (unsigned long long)(((unsigned __int128)nsub * rank) / world);
+  P.sub_hi = (unsigned long long)(((unsigned __int128)nsub * (rank + 1)) / world);
+  P.cut_nodes = s->cfg.stop_after_n_nodes;
+  P.stop_after_n_solutions = s->cfg.stop_after_n_solutions;
+
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->mbox_host), sizeof(Mailbox), hipHostMallocMapped));
+  s->mbox_host->stop = 0; s->mbox_host->foreign_bound = TB_PINF; s->mbox_host->local_best = TB_PINF; s->mbox_host->pad = 0;
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->mbox_dev), s->mbox_host, 0));
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&s->ev_start));
+  HIP_TRY(hipEventCreate(&s->ev_stop));
+  if ((rc = set_lds_limit(true, plan.mem_kind, plan.tmax, plan.shared_bytes)) != TB_OK) return rc;
+  *out = s.release();
+  return TB_OK;
+}
+
+int tb_session_start(tb_session* s) {
+  if (!s) return fail(TB_ERR_INVALID, "null session");
+  if (s->started) return fail(TB_ERR_STATE, "session already started");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  Ctrl c{};
+  c.next_subproblem = s->P.sub_lo;
+  c.first_sol_idx = ~0ull;
+  c.best_bound = TB_PINF; c.foreign_bound = TB_PINF;
+  HIP_TRY(hipMemcpy(s->P.ctrl, &c, sizeof(c), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(s->P.g_stats, 0, sizeof(BlockStats) * (size_t)s->plan.num_blocks));
+  // in-kernel watchdog: device wall clock "now" + timeout + 2 s of margin
+  s->P.deadline_ticks = 0;
+  if (s->cfg.timeout_ms != 0) {
+    long long* d_now = nullptr;
+    int rc = s->bufs.alloc(&d_now, 1);
+    if (rc != TB_OK) return rc;
+    clock_kernel<<<1, 1, 0, s->stream>>>(d_now);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    long long now = 0;
+    HIP_TRY(hipMemcpy(&now, d_now, sizeof(now), hipMemcpyDeviceToHost));
+    s->P.deadline_ticks = now + (long long)(s->cfg.timeout_ms + 2000) * (long long)s->caps.wall_khz;
+  }
+  s->t_start = std::chrono::steady_clock::now();
+  HIP_TRY(hipEventRecord(s->ev_start, s->stream));
+  const LaunchPlan& plan = s->plan;
+  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->mbox_dev));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->ev_stop, s->stream));
+  s->started = true;
+  return TB_OK;
+}
+
+int tb_session_poll(tb_session* s, int32_t* local_best_out, int32_t* done_out) {
+  if (!s || !s->started) return fail(TB_ERR_STATE, "session not started");
+  const int lb = __atomic_load_n(&s->mbox_host->local_best, __ATOMIC_RELAXED);
+  s->host_best = std::min(s->host_best, lb);  // the mailbox word may be overwritten out of order; keep the minimum seen
+  if (local_best_out) *local_best_out = s->host_best;
+  if (done_out) {
+    hipError_t e = hipEventQuery(s->ev_stop);
+    if (e == hipSuccess) *done_out = 1;
+    else if (e == hipErrorNotReady) *done_out = 0;
+    else return fail(TB_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+  }
+  return TB_OK;
+}
+
+int tb_session_push_bound(tb_session* s, int32_t bound) {
+  if (!s) return fail(TB_ERR_INVALID, "null session");
+  int cur = __atomic_load_n(&s->mbox_host->foreign_bound, __ATOMIC_RELAXED);
+  if (bound < cur) __atomic_store_n(&s->mbox_host->foreign_bound, bound, __ATOMIC_RELEASE);
+  return TB_OK;
+}
+
+int tb_session_stop(tb_session* s) {
+  if (!s) return fail(TB_ERR_INVALID, "null session");
+  __atomic_store_n(&s->mbox_host->stop, 1, __ATOMIC_RELEASE);
+  return TB_OK;
+}
+
+int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_solution_out, tb_stats* stats_out) {
+  if (!s || !s->started) return fail(TB_ERR_STATE, "session not started");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->finished = true;
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
+  const size_t B = (size_t)s->plan.num_blocks, V = (size_t)s->n_vars;
+  std::vector<BlockStats> bst(B);
+  HIP_TRY(hipMemcpy(bst.data(), s->P.g_stats, B * sizeof(BlockStats), hipMemcpyDeviceToHost));
+  Ctrl c{};
+  HIP_TRY(hipMemcpy(&c, s->P.ctrl, sizeof(c), hipMemcpyDeviceToHost));
+  if (c.error != 0) return fail(TB_ERR_HIP, "device error: decision stack overflow (search deeper than " + std::to_string(s->plan.max_depth) + ")");
+
+  // reduce_blocks (barebones:1033-1067): sum the statistics, pick the winning workgroup.
+  tb_stats st;
+  std::memset(&st, 0, sizeof(st));
+  st.exhaustive = 1;
+  const double ns_per_tick = 1e6 / (double)s->caps.wall_khz;
+  long long best_block = -1;
+  long long first_idle = -1;
+  for (size_t b = 0; b < B; ++b) {
+    const BlockStats& x = bst[b];
+    st.nodes += x.nodes; st.fails += x.fails; st.solutions += x.solutions;
+    st.fixpoint_iterations += x.fixpoint_iterations; st.num_deductions += x.num_deductions;
+    st.eps_solved_subproblems += x.eps_solved; st.eps_skipped_subproblems += x.eps_skipped;
+    st.num_blocks_done += (uint64_t)x.num_blocks_done;
+    st.store_writes += x.store_writes;
+    st.depth_max = std::max(st.depth_max, x.depth_max);
+    st.exhaustive = st.exhaustive && x.exhaustive;
+    for (int t = 0; t < TB_NUM_TIMERS; ++t)
+      if (t != TB_T_FIRST_BLOCK_IDLE && t != TB_T_LATEST_BEST_OBJ_FOUND) st.timers_ns[t] += (int64_t)((double)x.timers[t] * ns_per_tick);
+    st.cumulative_time_block_ns += (int64_t)((double)x.timers[TB_T_FIRST_BLOCK_IDLE] * ns_per_tick);
+    if (first_idle < 0 || x.timers[TB_T_FIRST_BLOCK_IDLE] < first_idle) first_idle = x.timers[TB_T_FIRST_BLOCK_IDLE];
+    if (x.solutions > 0) {
+      bool better;
+      if (best_block < 0) better = true;
+      else {
+        const BlockStats& y = bst[(size_t)best_block];
+        if (s->obj_var < 0 || s->cfg.use_fixed_bound) better = x.best_sub < y.best_sub;  // lowest subproblem index wins
+        else better = x.best_bound < y.best_bound || (x.best_bound == y.best_bound && x.best_sub < y.best_sub);
+      }
+      if (better) best_block = (long long)b;
+    }
+  }
+  st.timers_ns[TB_T_FIRST_BLOCK_IDLE] = first_idle < 0 ? 0 : (int64_t)((double)first_idle * ns_per_tick);
+  st.best_bound = TB_PINF; st.best_subproblem = -1;
+  if (best_block >= 0) {
+    const BlockStats& w = bst[(size_t)best_block];
+    st.best_bound = s->obj_var >= 0 ? w.best_bound : 0;
+    st.best_subproblem = (int32_t)std::min<long long>(w.best_sub, 0x7fffffffll);
+    st.timers_ns[TB_T_LATEST_BEST_OBJ_FOUND] = (int64_t)((double)w.best_time * ns_per_tick);
+    if (best_store_out && V) HIP_TRY(hipMemcpy(best_store_out, s->P.g_best + (size_t)best_block * V, V * sizeof(tb_itv), hipMemcpyDeviceToHost));
+  }
+  if (has_solution_out) *has_solution_out = best_block >= 0 ? 1 : 0;
+  st.eps_num_subproblems = 1ull << s->plan.subproblems_power;
+  st.kernel_ns = (int64_t)((double)ms * 1e6);
+  st.num_blocks = s->plan.num_blocks; st.threads_per_block = s->plan.threads;
+  st.mem_kind = s->plan.mem_kind; st.shared_bytes = s->plan.shared_bytes; st.subproblems_power = s->plan.subproblems_power;
+  st.interrupted = (c.stop != 0) ? 1 : 0;
+  if (st.interrupted) st.exhaustive = 0;
+  // a slice that was not fully consumed is not exhaustive either (stop raised by a workgroup)
+  if (stats_out) *stats_out = st;
+  return TB_OK;
+}
+
+void tb_session_destroy(tb_session* s) {
+  if (!s) return;
+  if (s->started && !s->finished) {
+    __atomic_store_n(&s->mbox_host->stop, 1, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(s->stream);
+  }
+  delete s;
+}
+
+int tb_solve(const tb_config* cfg_in, int32_t n_vars, const tb_itv* root_store,
+             int32_t n_props, const tb_prop* props,
+             int32_t n_strats, const int32_t* strat_var_order, const int32_t* strat_val_order,
+             const int32_t* strat_off, const int32_t* strat_vars,
+             int32_t obj_var, volatile int32_t* host_stop_flag,
+             tb_itv* best_store_out, int32_t* has_solution_out, tb_stats* stats_out) {
+  if (!cfg_in) return fail(TB_ERR_INVALID, "null config");
+  const auto t0 = std::chrono::steady_clock::now();
+  auto run = [&](const tb_config& cfg, tb_itv* best, int32_t* has, tb_stats* st) -> int {
+    tb_session* s = nullptr;
+    int rc = tb_session_create(&cfg, n_vars, root_store, n_props, props, n_strats, strat_var_order, strat_val_order, strat_off, strat_vars, obj_var, &s);
+    if (rc != TB_OK) return rc;
+    rc = tb_session_start(s);
+    if (rc != TB_OK) { tb_session_destroy(s); return rc; }
+    // wait_solving_ends (memory_gpu.hpp:174-196): poll, stop on timeout or on the caller's flag
+    int32_t done = 0;
+    auto sleep_us = std::chrono::microseconds(50);
+    while (!done) {
+      rc = tb_session_poll(s, nullptr, &done);
+      if (rc != TB_OK) break;
+      if (done) break;
+      const auto now = std::chrono::steady_clock::now();
+      const uint64_t el = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(now - t0).count();
+      if ((cfg.timeout_ms != 0 && el >= cfg.timeout_ms) || (host_stop_flag && *host_stop_flag)) tb_session_stop(s);
+      std::this_thread::sleep_for(sleep_us);
+      if (sleep_us < std::chrono::microseconds(2000)) sleep_us *= 2;
+    }
+    if (rc == TB_OK) rc = tb_session_finish(s, best, has, st);
+    tb_session_destroy(s);
+    return rc;
+  };
+  tb_config cfg = *cfg_in;
+  tb_stats st;
+  int32_t has = 0;
+  int rc = run(cfg, best_store_out, &has, &st);
+  if (rc != TB_OK) return rc;
+  // Canonical pass: the B&B above proved `best_bound` optimal; the DFS-first solution under the constant
+  // constraint obj <= best_bound is unique, so the answer no longer depends on the race between workgroups.
+  if (cfg.deterministic && !cfg.use_fixed_bound && obj_var >= 0 && has && st.exhaustive) {
+    tb_config c2 = cfg;
+    c2.use_fixed_bound = 1; c2.fixed_bound = st.best_bound; c2.stop_after_n_nodes = 0;
+    if (cfg.timeout_ms != 0) {
+      const uint64_t el = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+      c2.timeout_ms = el + 1 < cfg.timeout_ms ? cfg.timeout_ms : el + 1000;
+    }
+    tb_stats st2;
+    int32_t has2 = 0;
+    std::vector<tb_itv> best2((size_t)std::max(1, n_vars));
+    rc = run(c2, best2.data(), &has2, &st2);
+    if (rc != TB_OK) return rc;
+    if (has2 && !st2.interrupted) {
+      if (best_store_out) std::memcpy(best_store_out, best2.data(), (size_t)n_vars * sizeof(tb_itv));
+      st.best_subproblem = st2.best_subproblem;
+    }
+    st.nodes += st2.nodes; st.fails += st2.fails; st.fixpoint_iterations += st2.fixpoint_iterations;
+    st.num_deductions += st2.num_deductions; st.kernel_ns += st2.kernel_ns; st.store_writes += st2.store_writes;
+  }
+  if (has_solution_out) *has_solution_out = has;
+  if (stats_out) *stats_out = st;
+  return TB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,578 @@
+// HIP kernels of the dive-and-solve engine for gfx950 (MI355X, CDNA4).
+//
+// One EPS subproblem per workgroup at a time; the variable-domain store of the subproblem lives in
+// LDS (int2 {lb,ub} per variable, ds_read_b64 / ds_max_i32 / ds_min_i32), the propagator bytecodes
+// are 16-byte records read one per lane (coalesced global_load_dwordx4, or ds_read_b128 when they fit
+// in LDS too), the "has changed" flag of the fixpoint is reduced per wave with a ballot and published
+// through one LDS word, and one s_barrier separates two sweeps.
+//
+// Mirrors, without their data structures:
+//   gpu_barebones_solve   include/barebones_dive_and_solve.hpp:620-901   (workgroup main loop)
+//   propagate             include/barebones_dive_and_solve.hpp:903-1031, include/gpu_dive_and_solve.hpp:287-368
+//   split / push_decision include/barebones_dive_and_solve.hpp:187-405
+#pragma once
+
+#include "device_types.hpp"
+#include "propagators.hpp"
+
+namespace tb {
+
+#define TB_RLX __ATOMIC_RELAXED
+#define TB_WG __HIP_MEMORY_SCOPE_WORKGROUP
+#define TB_AGENT __HIP_MEMORY_SCOPE_AGENT
+#define TB_SYS __HIP_MEMORY_SCOPE_SYSTEM
+
+constexpr int MAX_WAVES = 16;          // 1024 threads
+constexpr int MAILBOX_PERIOD = 64;     // nodes between two polls of the host mailbox
+
+// Host-pinned page shared with the host thread (replaces the managed-memory flags of
+// barebones UnifiedData::stop, barebones:64, and the 100 ms wait loop of memory_gpu.hpp:174-196).
+struct Mailbox {
+  int stop;           // host -> device
+  int foreign_bound;  // host -> device: incumbent found by another GPU
+  int local_best;     // device -> host: incumbent found on this GPU
+  int pad;
+};
+
+// Workgroup control block, first bytes of the dynamic LDS segment.
+struct alignas(16) BlockShared {
+  int flag[3];    // "some domain changed during sweep k", rotating so one barrier per sweep is enough
+  int unent[3];   // "some propagator is not entailed", computed in the same sweep
+  int bot;        // VStore::is_bot
+  int leaf, stop, depth, remaining;
+  int cur_strategy, next_unassigned, snap_strategy, snap_next_unassigned;
+  int best_bound;  // best objective found by this workgroup (BlockData::best_bound, barebones:116)
+  int found, sol, skip, abort;
+  int new_depth, pad0, pad1, pad2;
+  unsigned long long sub_idx;
+  unsigned long long red_key[MAX_WAVES];
+  int red_first[MAX_WAVES];
+  BlockStats bs;  // written by thread 0 only
+};
+
+__device__ __forceinline__ int ld(const int* p) { return __hip_atomic_load(p, TB_RLX, TB_WG); }
+__device__ __forceinline__ void st(int* p, int v) { __hip_atomic_store(p, v, TB_RLX, TB_WG); }
+
+__device__ __forceinline__ Itv load_dom(const int2* store, int v) {
+  long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + v), TB_RLX, TB_WG);
+  Itv d;
+  d.lb = (int)(raw & 0xffffffffll);
+  d.ub = (int)(raw >> 32);
+  return d;
+}
+__device__ __forceinline__ void raise_lb(int2* store, int v, int val) { (void)__hip_atomic_fetch_max(&store[v].x, val, TB_RLX, TB_WG); }
+__device__ __forceinline__ void lower_ub(int2* store, int v, int val) { (void)__hip_atomic_fetch_min(&store[v].y, val, TB_RLX, TB_WG); }
+
+// Per-thread counters kept in registers for the whole kernel and reduced once at the end.
+struct ThreadCounters {
+  unsigned long long writes = 0;      // narrowed bounds written
+  unsigned long long deductions = 0;  // deduce calls (per-wave counter held by lane 0, WAC1)
+};
+
+// One propagator application: load 3 domains, evaluate, write the narrowed bounds.
+// `un` is only meaningful when the sweep it belongs to changed nothing.
+__device__ __forceinline__ void apply(const int4 pr, int2* store, int* bot, bool& changed, bool& un, ThreadCounters& tc) {
+  const Itv X = load_dom(store, pr.y), Y = load_dom(store, pr.z), Z = load_dom(store, pr.w);
+  if (X.lb > X.ub || Y.lb > Y.ub || Z.lb > Z.ub) { st(bot, 1); return; }
+  const Cand c = evaluate(pr.x, X, Y, Z);
+  int w = 0;
+  if (c.xl > X.lb) { raise_lb(store, pr.y, c.xl); ++w; }
+  if (c.xu < X.ub) { lower_ub(store, pr.y, c.xu); ++w; }
+  if (c.yl > Y.lb) { raise_lb(store, pr.z, c.yl); ++w; }
+  if (c.yu < Y.ub) { lower_ub(store, pr.z, c.yu); ++w; }
+  if (c.zl > Z.lb) { raise_lb(store, pr.w, c.zl); ++w; }
+  if (c.zu < Z.ub) { lower_ub(store, pr.w, c.zu); ++w; }
+  if (imax(c.xl, X.lb) > imin(c.xu, X.ub) || imax(c.yl, Y.lb) > imin(c.yu, Y.ub) || imax(c.zl, Z.lb) > imin(c.zu, Z.ub)) st(bot, 1);
+  tc.writes += (unsigned)w;
+  changed |= (w != 0);
+  un |= !c.ent;
+}
+
+// Block-parallel fixpoint of all propagators + entailment test, fused.
+// (BlockAsynchronousFixpointGPU::fixpoint + warp_fixpoint + the `ask` scan: barebones:920-982.)
+// Precondition: the store is ready and a barrier separates its last write from this call.
+// Returns the number of block-level sweeps.  After the call (which ends with a barrier):
+//   sh.bot          the node failed
+//   *all_entailed   no propagator is un-entailed (only meaningful when !sh.bot)
+__device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
+                                        ThreadCounters& tc, bool& all_entailed) {
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
+  const int n = P.n_props;
+  const bool wac1 = P.fixpoint == 1 && n > P.wac1_threshold;
+  if (tid == 0) { st(&sh.flag[0], 0); st(&sh.unent[0], 0); }
+  __syncthreads();
+  int it = 0, k = 0;
+  for (;;) {
+    k = it % 3;
+    bool changed = false, un = false;
+    if (!wac1) {
+      for (int i = tid; i < n; i += T) apply(props[i], store, &sh.bot, changed, un, tc);
+    } else {
+      // WAC1: a wave iterates its 64 propagators to a local fixpoint before moving on (config.cpp:26,
+      // warp_fixpoint at barebones:955; the wave is 64 wide on CDNA).
+      for (int base = tid - lane; base < n; base += T) {
+        const int i = base + lane;
+        const bool act = i < n;
+        int4 pr = make_int4(0, 0, 0, 0);
+        if (act) pr = props[i];
+        for (;;) {
+          bool ch = false, un_i = false;
+          if (act) apply(pr, store, &sh.bot, ch, un_i, tc);
+          if (lane == 0) tc.deductions += 64;  // barebones:958-960 counts warp iterations x warp width
+          const bool any = __any(ch);
+          if (!any) { un |= un_i; break; }
+          changed = true;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          if (ld(&sh.bot)) break;
+        }
+      }
+    }
+    const bool any_changed = __any(changed), any_un = __any(un);
+    if (lane == 0) {
+      if (any_changed) st(&sh.flag[k], 1);
+      if (any_un) st(&sh.unent[k], 1);
+    }
+    if (tid == 0) {
+      const int k1 = (k + 1) % 3;
+      st(&sh.flag[k1], 0); st(&sh.unent[k1], 0);
+      // watchdog: a pathological network (x < y < x over 2^31 values) must not outlive the deadline
+      if ((it & 255) == 255 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
+    }
+    __syncthreads();
+    ++it;
+    if (!ld(&sh.flag[k]) || ld(&sh.bot) || ld(&sh.abort)) break;
+  }
+  if (!wac1 && tid == 0) tc.deductions += (unsigned long long)it * (unsigned long long)n;  // barebones:934
+  all_entailed = !ld(&sh.unent[k]);
+  return it;
+}
+
+// ---- small helpers -------------------------------------------------------------------------------
+
+__device__ __forceinline__ void copy_store(int2* dst, const int2* src, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned long long o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    int o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// Thread 0 only: VStore::embed of one interval (decisions, objective bound).
+__device__ __forceinline__ void embed0(int2* store, int* bot, int v, int lb, int ub) {
+  Itv d = load_dom(store, v);
+  if (lb > d.lb) { raise_lb(store, v, lb); d.lb = lb; }
+  if (ub < d.ub) { lower_ub(store, v, ub); d.ub = ub; }
+  if (d.lb > d.ub) st(bot, 1);
+}
+
+// Key to MINIMISE for each variable order (barebones:193-221); ties resolve to the lowest index
+// because the index sits in the low half of the packed 64-bit key (barebones:322-338).
+__device__ __forceinline__ unsigned order_key(int var_order, const Itv d) {
+  switch (var_order) {
+    case TB_FIRST_FAIL: return (unsigned)d.ub - (unsigned)d.lb;
+    case TB_ANTI_FIRST_FAIL: return ~((unsigned)d.ub - (unsigned)d.lb);
+    case TB_SMALLEST: return (unsigned)d.lb ^ 0x80000000u;
+    case TB_LARGEST: return ~((unsigned)d.ub ^ 0x80000000u);
+    default: return 0u;  // input order
+  }
+}
+
+// Thread 0 only (barebones:355-405).
+__device__ __forceinline__ bool push_decision(const DevProblem& P, BlockShared& sh, Decision* dec, const int2* store, int val_order, int var) {
+  const int depth = sh.depth;
+  if (depth + 1 >= P.max_depth) { __hip_atomic_store(&P.ctrl->error, 1, TB_RLX, TB_AGENT); return false; }
+  Decision d;
+  const Itv dom = load_dom(store, var);
+  d.var = var;
+  d.cur = -1;
+  const int mid = (int)((long long)dom.lb + ((long long)dom.ub - (long long)dom.lb) / 2);
+  switch (val_order) {
+    case TB_VAL_MIN: d.child[0] = make_int2(dom.lb, dom.lb); d.child[1] = make_int2(dom.lb + 1, dom.ub); break;
+    case TB_VAL_MAX: d.child[0] = make_int2(dom.ub, dom.ub); d.child[1] = make_int2(dom.lb, dom.ub - 1); break;
+    case TB_VAL_SPLIT: d.child[0] = make_int2(dom.lb, mid); d.child[1] = make_int2(mid + 1, dom.ub); break;
+    default: d.child[0] = make_int2(mid + 1, dom.ub); d.child[1] = make_int2(dom.lb, mid); break;
+  }
+  d.rope[0] = depth + 1;
+  d.rope[1] = depth > 0 ? dec[depth - 1].rope[dec[depth - 1].cur] : -1;
+  dec[depth] = d;
+  sh.depth = depth + 1;
+  return true;
+}
+
+// Block-parallel variable selection.  Replaces the three-barrier lattice fixpoint loops of
+// input_order_split / lattice_smallest_split (barebones:240-349) by one strided scan, a wave-level
+// min reduction (DPP/bpermute shuffles) and one LDS round per strategy.
+// Ends with a barrier; sh.found tells whether a decision was pushed at sh.depth-1.
+__device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Decision* dec, const int2* store) {
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+  for (;;) {
+    const int s = sh.cur_strategy;  // uniform: read after a barrier
+    if (s >= P.n_strats) { if (tid == 0) sh.found = 0; __syncthreads(); return; }
+    const int off = P.strat_off[s];
+    int n = P.strat_off[s + 1] - off;
+    const bool in_store = (n == 0);
+    if (in_store) n = P.n_vars;
+    const int vo = P.strat_var_order[s];
+    unsigned long long best = ~0ull;
+    int first = n;
+    for (int i = sh.next_unassigned + tid; i < n; i += T) {
+      const int v = in_store ? i : P.strat_vars[off + i];
+      const Itv d = load_dom(store, v);
+      if (d.lb != d.ub && !is_inf(d.lb) && !is_inf(d.ub)) {
+        const unsigned long long key = ((unsigned long long)order_key(vo, d) << 32) | (unsigned)i;
+        best = key < best ? key : best;
+        first = i < first ? i : first;
+      }
+    }
+    best = wave_min_u64(best);
+    first = wave_min_i32(first);
+    if (lane == 0) { sh.red_key[wave] = best; sh.red_first[wave] = first; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < nw; ++w) {
+        best = sh.red_key[w] < best ? sh.red_key[w] : best;
+        first = sh.red_first[w] < first ? sh.red_first[w] : first;
+      }
+      sh.next_unassigned = first;
+      if (best != ~0ull) {
+        const int i = (int)(best & 0xffffffffu);
+        const int v = in_store ? i : P.strat_vars[off + i];
+        sh.found = push_decision(P, sh, dec, store, P.strat_val_order[s], v) ? 1 : 0;
+        if (!sh.found) sh.stop = 1;
+        sh.skip = 1;  // leave the strategy loop
+      } else {
+        sh.cur_strategy = s + 1;
+        sh.next_unassigned = 0;
+        sh.skip = 0;
+      }
+    }
+    __syncthreads();
+    if (sh.skip) return;
+  }
+}
+
+// ---- one search node (barebones:903-1031) ---------------------------------------------------------
+
+struct NodeTimers { long long t_last; };
+
+__device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
+                                               int2* best_store, Mailbox* mbox, ThreadCounters& tc,
+                                               long long& t_mark, long long t_start) {
+  const int tid = threadIdx.x;
+  BlockStats& bs = sh.bs;
+  long long t0 = 0;
+  if (tid == 0) { t0 = wall_clock64(); bs.timers[TB_T_SEARCH] += t0 - t_mark; }
+  bool all_entailed = false;
+  const int iters = fixpoint(P, sh, store, props, tc, all_entailed);
+  const bool aborted = ld(&sh.abort) != 0;
+  const bool failed = !aborted && ld(&sh.bot) != 0;
+  if (aborted) all_entailed = false;
+  if (tid == 0) {
+    const long long t1 = wall_clock64();
+    bs.timers[TB_T_FIXPOINT] += t1 - t0;
+    t_mark = t1;
+    int leaf = failed ? 1 : 0, sol = 0;
+    if (!failed && all_entailed) {
+      leaf = 1;
+      if (P.obj_var >= 0) {
+        const int obj = load_dom(store, P.obj_var).lb;
+        if (sh.best_bound > obj && (!P.use_fixed_bound || obj <= P.fixed_bound)) {  // barebones:994
+          sh.best_bound = obj;
+          sol = 1;
+          if (!P.use_fixed_bound) {
+            const int old = __hip_atomic_fetch_min(&P.ctrl->best_bound, obj, TB_RLX, TB_AGENT);  // appx_best_bound.meet
+            if (obj < old) __hip_atomic_store(&mbox->local_best, obj, TB_RLX, TB_SYS);
+          }
+        }
+      } else {
+        sol = 1;
+      }
+      if (sol) {
+        bs.solutions++;
+        bs.best_sub = (long long)sh.sub_idx;
+        bs.best_time = t1 - t_start;
+        if (P.use_fixed_bound) {
+          __hip_atomic_fetch_min(&P.ctrl->first_sol_idx, sh.sub_idx, TB_RLX, TB_AGENT);
+          sh.stop = 1;
+        } else if (P.obj_var < 0 && P.stop_after_n_solutions != 0) {
+          const unsigned long long nsol = __hip_atomic_fetch_add(&P.ctrl->solutions, 1ull, TB_RLX, TB_AGENT) + 1;
+          if (nsol >= P.stop_after_n_solutions) {  // common_solving.hpp:858-867
+            bs.exhaustive = 0;
+            sh.stop = 1;
+            __hip_atomic_store(&P.ctrl->gpu_stop, 1, TB_RLX, TB_AGENT);
+          }
+        }
+      }
+    }
+    sh.leaf = leaf;
+    sh.sol = sol;
+    bs.fixpoint_iterations += (unsigned long long)iters;
+    bs.nodes++;
+    bs.fails += failed ? 1 : 0;
+    bs.depth_max = sh.depth > bs.depth_max ? sh.depth : bs.depth_max;
+    // stopping conditions (barebones:1024-1029)
+    bool must_stop = (P.cut_nodes != 0 && bs.nodes >= P.cut_nodes);
+    must_stop |= __hip_atomic_load(&P.ctrl->gpu_stop, TB_RLX, TB_AGENT) != 0;
+    if ((bs.nodes % MAILBOX_PERIOD) == 0) {
+      if (__hip_atomic_load(&mbox->stop, TB_RLX, TB_SYS) != 0) { __hip_atomic_store(&P.ctrl->stop, 1, TB_RLX, TB_AGENT); }
+      const int fb = __hip_atomic_load(&mbox->foreign_bound, TB_RLX, TB_SYS);
+      if (fb != PINF) __hip_atomic_fetch_min(&P.ctrl->foreign_bound, fb, TB_RLX, TB_AGENT);
+      if (P.deadline_ticks != 0 && t1 > P.deadline_ticks) __hip_atomic_store(&P.ctrl->stop, 1, TB_RLX, TB_AGENT);
+    }
+    if (__hip_atomic_load(&P.ctrl->stop, TB_RLX, TB_AGENT) != 0) must_stop = true;
+    if (P.use_fixed_bound && __hip_atomic_load(&P.ctrl->first_sol_idx, TB_RLX, TB_AGENT) < sh.sub_idx) { sh.stop = 1; }
+    if (aborted) { must_stop = true; __hip_atomic_store(&P.ctrl->stop, 1, TB_RLX, TB_AGENT); }
+    if (must_stop) { bs.exhaustive = 0; sh.stop = 1; }
+  }
+  __syncthreads();
+  if (sh.sol) {  // uniform
+    copy_store(best_store, store, P.n_vars);
+    __syncthreads();
+  }
+}
+
+// ---- the persistent search kernel ----------------------------------------------------------------
+
+constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 255) / 256 * 256);
+
+template <int MEM, int TMAX>
+__global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
+  const int tid = threadIdx.x, b = blockIdx.x, V = P.n_vars;
+  int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : P.g_store + (size_t)b * V;
+  const int4* props = P.props;
+  if (MEM == TB_MEM_TCN_SHARED) {
+    int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + (((size_t)V * 8 + 15) / 16) * 16);
+    for (int i = tid; i < P.n_props; i += blockDim.x) lprops[i] = P.props[i];
+    props = lprops;
+  }
+  int2* snap = P.g_snap + (size_t)b * P.snapshot_levels * V;
+  int2* best_store = P.g_best + (size_t)b * V;
+  Decision* dec = P.g_dec + (size_t)b * P.max_depth;
+  BlockStats& bs = sh.bs;
+  ThreadCounters tc;
+  long long t_start = 0, t_mark = 0;
+  if (tid == 0) {
+    for (int i = 0; i < TB_NUM_TIMERS; ++i) bs.timers[i] = 0;
+    bs.nodes = bs.fails = bs.solutions = bs.fixpoint_iterations = bs.num_deductions = 0;
+    bs.eps_solved = bs.eps_skipped = bs.store_writes = 0;
+    bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
+    sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0;
+    sh.abort = 0; sh.new_depth = 0;
+    sh.sub_idx = __hip_atomic_fetch_add(&P.ctrl->next_subproblem, 1ull, TB_RLX, TB_AGENT);
+    t_start = t_mark = wall_clock64();
+  }
+  __syncthreads();
+
+  // B. dive-and-solve loop (barebones:656-886)
+  while (sh.sub_idx < P.sub_hi && !sh.stop) {
+    // C. restore the root
+    copy_store(store, P.root_store, V);
+    long long t_dive = 0;
+    if (tid == 0) {
+      sh.cur_strategy = 0; sh.next_unassigned = 0; sh.depth = 0; sh.bot = 0;
+      sh.remaining = P.subproblems_power; sh.leaf = 0;
+      t_dive = wall_clock64();
+      if (P.use_fixed_bound && __hip_atomic_load(&P.ctrl->first_sol_idx, TB_RLX, TB_AGENT) < sh.sub_idx) sh.stop = 1;
+    }
+    __syncthreads();
+    // D. dive: no objective bound while diving (gpu_dive_and_solve.hpp:370-372)
+    while (sh.remaining > 0 && !sh.leaf && !sh.stop) {
+      propagate_node(P, sh, store, props, best_store, mbox, tc, t_mark, t_start);
+      if (!sh.leaf && !sh.stop) {
+        split(P, sh, dec, store);
+        if (tid == 0) {
+          if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; }  // unsplittable infinite domains (barebones:688-694)
+          else {
+            --sh.remaining;
+            --sh.depth;  // decisions are not recorded while diving
+            const int bit = (int)((sh.sub_idx >> sh.remaining) & 1ull);
+            embed0(store, &sh.bot, dec[0].var, dec[0].child[bit].x, dec[0].child[bit].y);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) bs.timers[TB_T_DIVE] += wall_clock64() - t_dive;
+    if (sh.leaf && !sh.stop) {
+      // E. a leaf above the subproblem: skip the whole subtree (barebones:718-741)
+      if (tid == 0) {
+        unsigned long long next_idx = ((sh.sub_idx >> sh.remaining) + 1ull) << sh.remaining;
+        if (next_idx > P.sub_hi) next_idx = P.sub_hi;
+        __hip_atomic_fetch_max(&P.ctrl->next_subproblem, next_idx, TB_RLX, TB_AGENT);
+        if ((sh.sub_idx & ((1ull << sh.remaining) - 1ull)) == 0ull) bs.eps_skipped += next_idx - sh.sub_idx;
+      }
+    } else if (!sh.stop) {
+      // F. solve the subproblem (barebones:742-871)
+      if (tid == 0 && P.has_eps_strategy) { sh.cur_strategy = sh.cur_strategy > 1 ? sh.cur_strategy : 1; sh.next_unassigned = 0; }
+      __syncthreads();
+      while (!sh.stop) {
+        // I. tighten the objective with the incumbent (barebones:756-771)
+        if (tid == 0 && P.obj_var >= 0) {
+          if (P.use_fixed_bound) embed0(store, &sh.bot, P.obj_var, NINF, P.fixed_bound);
+          else {
+            int g = __hip_atomic_load(&P.ctrl->best_bound, TB_RLX, TB_AGENT);
+            const int f = __hip_atomic_load(&P.ctrl->foreign_bound, TB_RLX, TB_AGENT);
+            g = f < g ? f : g;
+            g = sh.best_bound < g ? sh.best_bound : g;
+            if (g != PINF) {
+              if (g == NINF) { sh.stop = 1; __hip_atomic_store(&P.ctrl->gpu_stop, 1, TB_RLX, TB_AGENT); }  // unbounded objective
+              else embed0(store, &sh.bot, P.obj_var, NINF, g - 1);
+            }
+          }
+        }
+        __syncthreads();
+        if (sh.stop) break;
+        // II. propagate
+        propagate_node(P, sh, store, props, best_store, mbox, tc, t_mark, t_start);
+        if (sh.stop) break;
+        // III. branch
+        if (!sh.leaf) {
+          const int d0 = sh.depth;
+          if (d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * V, store, V);  // d0 == 0: barebones:785-791
+          if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
+          __syncthreads();
+          split(P, sh, dec, store);
+          if (sh.stop) break;
+          if (tid == 0) {
+            if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; }
+            else {
+              Decision& dd = dec[sh.depth - 1];
+              const int c = ++dd.cur;
+              embed0(store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+            }
+          }
+          __syncthreads();
+        }
+        // IV. backtrack: rope jump, then restore the deepest snapshot and replay (barebones:812-863)
+        if (sh.leaf) {
+          const int dcur = sh.depth;  // stable: last written before a barrier
+          if (dcur == 0) break;
+          if (tid == 0) sh.new_depth = dec[dcur - 1].rope[dec[dcur - 1].cur];
+          __syncthreads();
+          const int depth = sh.new_depth;
+          if (depth == -1) break;
+          const int lvl = (depth - 1) < (P.snapshot_levels - 1) ? (depth - 1) : (P.snapshot_levels - 1);
+          copy_store(store, snap + (size_t)lvl * V, V);
+          if (tid == 0) { sh.bot = 0; sh.depth = depth; }
+          __syncthreads();
+          // re-apply decisions[lvl .. depth-2].current(): distinct decisions may hit the same variable, the
+          // atomic min/max make the order irrelevant (the reference loops to a fixpoint, barebones:839-851)
+          for (int i = lvl + tid; i < depth - 1; i += blockDim.x) {
+            const Decision& di = dec[i];
+            const int2 ch = di.child[di.cur];
+            raise_lb(store, di.var, ch.x);
+            lower_ub(store, di.var, ch.y);
+          }
+          __syncthreads();
+          if (tid == 0) {
+            Decision& dd = dec[depth - 1];
+            const int c = ++dd.cur;
+            embed0(store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+            sh.cur_strategy = sh.snap_strategy;
+            sh.next_unassigned = sh.snap_next_unassigned;
+          }
+          __syncthreads();
+        }
+      }
+      if (tid == 0 && !sh.stop) bs.eps_solved += 1;
+    }
+    // G. next subproblem (barebones:877-884)
+    if (tid == 0 && !sh.stop) sh.sub_idx = __hip_atomic_fetch_add(&P.ctrl->next_subproblem, 1ull, TB_RLX, TB_AGENT);
+    __syncthreads();
+  }
+
+  // reduce the per-thread counters (once per kernel)
+  __syncthreads();
+  if (tid == 0) { sh.red_key[0] = 0; sh.red_key[1] = 0; }
+  __syncthreads();
+  {
+    unsigned long long w = tc.writes, d = tc.deductions;
+    for (int off = 32; off > 0; off >>= 1) { w += __shfl_xor(w, off, 64); d += __shfl_xor(d, off, 64); }
+    if ((tid & 63) == 0) {
+      __hip_atomic_fetch_add(&sh.red_key[0], w, TB_RLX, TB_WG);
+      __hip_atomic_fetch_add(&sh.red_key[1], d, TB_RLX, TB_WG);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    bs.store_writes = sh.red_key[0];
+    bs.num_deductions = sh.red_key[1];
+    bs.best_bound = sh.best_bound;
+    const int stopped = __hip_atomic_load(&P.ctrl->stop, TB_RLX, TB_AGENT);
+    if (!(P.cut_nodes != 0 && bs.nodes >= P.cut_nodes) && !stopped) bs.num_blocks_done = 1;  // barebones:889-891
+    const long long t_end = wall_clock64();
+    bs.timers[TB_T_FIRST_BLOCK_IDLE] = t_end - t_start;
+    bs.timers[TB_T_OVERALL] = t_end - t_start;
+    bs.timers[TB_T_LATEST_BEST_OBJ_FOUND] = bs.best_time;
+    P.g_stats[b] = bs;
+    __hip_atomic_fetch_add(&P.ctrl->blocks_done, 1, TB_RLX, TB_AGENT);
+  }
+}
+
+__global__ void clock_kernel(long long* out) { *out = wall_clock64(); }
+
+// ---- batch propagation kernel: one store per workgroup (tb_propagate) ----------------------------
+
+struct PropagateOut {
+  int failed, all_entailed;
+  unsigned long long iterations, deductions, writes;
+};
+
+template <int MEM, int TMAX>
+__global__ void __launch_bounds__(TMAX) propagate_kernel(DevProblem P, int2* stores, PropagateOut* out, int n_stores) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
+  const int tid = threadIdx.x, V = P.n_vars;
+  const int4* props = P.props;
+  if (MEM == TB_MEM_TCN_SHARED) {
+    int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + (((size_t)V * 8 + 15) / 16) * 16);
+    for (int i = tid; i < P.n_props; i += blockDim.x) lprops[i] = P.props[i];
+    props = lprops;
+  }
+  for (int s = blockIdx.x; s < n_stores; s += gridDim.x) {
+    int2* gstore = stores + (size_t)s * V;
+    int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : gstore;
+    ThreadCounters tc;
+    if (tid == 0) { sh.bot = 0; sh.abort = 0; sh.red_key[0] = 0; sh.red_key[1] = 0; }
+    __syncthreads();
+    if (MEM >= TB_MEM_STORE_SHARED) copy_store(store, gstore, V);
+    for (int i = tid; i < V; i += blockDim.x) { const int2 d = gstore[i]; if (d.x > d.y) st(&sh.bot, 1); }
+    __syncthreads();
+    bool all_entailed = false;
+    int iters = 0;
+    if (!ld(&sh.bot)) iters = fixpoint(P, sh, store, props, tc, all_entailed);
+    if (MEM >= TB_MEM_STORE_SHARED) copy_store(gstore, store, V);
+    unsigned long long w = tc.writes, d = tc.deductions;
+    for (int off = 32; off > 0; off >>= 1) { w += __shfl_xor(w, off, 64); d += __shfl_xor(d, off, 64); }
+    if ((tid & 63) == 0) {
+      __hip_atomic_fetch_add(&sh.red_key[0], w, TB_RLX, TB_WG);
+      __hip_atomic_fetch_add(&sh.red_key[1], d, TB_RLX, TB_WG);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      PropagateOut o;
+      o.failed = ld(&sh.abort) ? -1 : ld(&sh.bot);
+      o.all_entailed = (!o.failed && all_entailed) ? 1 : 0;
+      o.iterations = (unsigned long long)iters;
+      o.deductions = sh.red_key[1];
+      o.writes = sh.red_key[0];
+      out[s] = o;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace tb
