@@ -205,6 +205,7 @@ struct tb_session {
   int32_t n_vars = 0, obj_var = -1;
   bool started = false, finished = false;
   int host_best = TB_PINF;
+  long long* d_now = nullptr;
   std::chrono::steady_clock::time_point t_start;
   ~tb_session() {
     if (ev_start) (void)hipEventDestroy(ev_start);
@@ -357,6 +358,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   if ((rc = s->bufs.alloc(&P.g_dec, B * (size_t)plan.max_depth)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&P.g_stats, B)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&P.ctrl, 1)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&s->d_now, 1)) != TB_OK) return rc;
 
   P.n_vars = n_vars; P.n_props = n_props; P.n_strats = n_strats; P.obj_var = obj_var;
   P.props = d_props; P.root_store = d_root;
@@ -388,8 +390,12 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
 
 int tb_session_start(tb_session* s) {
   if (!s) return fail(TB_ERR_INVALID, "null session");
-  if (s->started) return fail(TB_ERR_STATE, "session already started");
+  if (s->started && !s->finished) return fail(TB_ERR_STATE, "session is running");
   HIP_TRY(hipSetDevice(s->cfg.device));
+  // (re)start: a finished session can be started again on the same resident inputs
+  s->finished = false;
+  s->host_best = TB_PINF;
+  s->mbox_host->stop = 0; s->mbox_host->foreign_bound = TB_PINF; s->mbox_host->local_best = TB_PINF;
   Ctrl c{};
   c.next_subproblem = s->P.sub_lo;
   c.first_sol_idx = ~0ull;
@@ -399,9 +405,7 @@ int tb_session_start(tb_session* s) {
   // in-kernel watchdog: device wall clock "now" + timeout + 2 s of margin
   s->P.deadline_ticks = 0;
   if (s->cfg.timeout_ms != 0) {
-    long long* d_now = nullptr;
-    int rc = s->bufs.alloc(&d_now, 1);
-    if (rc != TB_OK) return rc;
+    long long* d_now = s->d_now;
     clock_kernel<<<1, 1, 0, s->stream>>>(d_now);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -447,7 +451,7 @@ int tb_session_stop(tb_session* s) {
 }
 
 int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_solution_out, tb_stats* stats_out) {
-  if (!s || !s->started) return fail(TB_ERR_STATE, "session not started");
+  if (!s || !s->started || s->finished) return fail(TB_ERR_STATE, "session not running");
   HIP_TRY(hipSetDevice(s->cfg.device));
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->finished = true;
