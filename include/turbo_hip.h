@@ -107,6 +107,10 @@ const char* tb_last_error(void);
 int tb_device_count(void);
 int tb_get_device_info(int device, tb_device_info* out);
 
+/* Slice [lo, hi) of the 2^d EPS subproblems owned by `rank` of `world_size` GPUs (host arithmetic only,
+ * usable without a device).  Contiguous slices keep the subtree skip of barebones:732 local to a GPU. */
+int tb_eps_slice(int32_t subproblems_power, int32_t rank, int32_t world_size, uint64_t* lo_out, uint64_t* hi_out);
+
 /*
  * One search node for a batch of independent stores: block-parallel fixpoint of all propagators
  * (AC1 / WAC1) followed by the entailment test.  Replaces the device function `propagate`

@@ -1,0 +1,190 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, host arithmetic,
+the multi-GPU protocol over gloo (world_size 2), the front-end, and the CLI's error behaviour."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import BENCH, ROOT
+from turbo_amd import capi, frontend
+
+TURBO = os.path.join(ROOT, "turbo_amd", "bin", "turbo")
+
+
+def declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(t[bf]_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    L = capi.lib()
+    syms = declared_symbols("turbo_hip.h")
+    assert set(capi.EXPORTS) <= set(syms)
+    for name in syms:
+        assert hasattr(L, name), f"libturbo_hip.so does not export {name}"
+    assert b"gfx950" in L.tb_version()
+
+
+def test_front_library_exports_every_declared_symbol():
+    L = frontend.lib()
+    for name in declared_symbols("turbo_front.h"):
+        assert hasattr(L, name), f"libturbo_front.so does not export {name}"
+
+
+def test_struct_layouts_match_header():
+    # sizes computed from include/turbo_hip.h by hand: tb_config = 6*8 + 16*4 = 112, tb_stats = 9*8 + 11*8 + 3*8 + 12*4 = 232
+    assert ctypes.sizeof(capi.TbConfig) == 112
+    assert ctypes.sizeof(capi.TbStats) == 232
+
+
+def test_no_device_is_a_loud_error():
+    if capi.lib().tb_device_count() > 0:
+        pytest.skip("a GPU is present")
+    tcn = frontend.load_fzn(os.path.join(BENCH, "test_data", "sudoku_opt2.fzn"))
+    with pytest.raises(capi.TurboHipError) as e:
+        capi.solve(tcn, capi.make_config(timeout_ms=1000))
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+    with pytest.raises(capi.TurboHipError):
+        capi.propagate(tcn.props, tcn.store[None, :])
+
+
+@pytest.mark.parametrize("d,world", [(0, 1), (3, 2), (10, 8), (17, 3), (40, 7)])
+def test_eps_slices_partition_the_index_space(d, world):
+    edges = [capi.eps_slice(d, r, world) for r in range(world)]
+    assert edges[0][0] == 0 and edges[-1][1] == 2 ** d
+    for (lo, hi), (lo2, _) in zip(edges, edges[1:]):
+        assert hi == lo2 and lo <= hi
+    sizes = [hi - lo for lo, hi in edges]
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_frontend_lowering_conventions():
+    tcn = frontend.Model.from_string(
+        "var 0..10: x; var 0..10: y; var bool: b; constraint int_lin_le([2,-3],[x,y],4); "
+        "constraint int_le_reif(x,y,b); solve maximize x;").tcn()
+    # constants 0,1,2 are pre-interned as variables 0,1,2 (common_solving.hpp:521)
+    for v in range(3):
+        assert tcn.store[v]["lb"] == tcn.store[v]["ub"] == v
+    ops = {frontend.OP_NAMES[o] for o in tcn.props["op"]}
+    assert ops <= {"ADD", "MUL", "LEQ", "EQ"}
+    # maximize is rewritten to minimising a negated variable (common_solving.hpp:489-510)
+    assert tcn.goal == 2 and tcn.obj_var != tcn.goal_var and tcn.obj_var >= 0
+    assert tcn.strat_var_order[-1] == 1 and tcn.strat_off[-1] == tcn.strat_off[-2]  # default first_fail over the whole store
+
+
+def test_frontend_errors():
+    with pytest.raises(ValueError):
+        frontend.Model.from_string("var 1..3: x; constraint nope(x); solve satisfy;")
+    with pytest.raises(ValueError):
+        frontend.Model.from_string("var 1..3: x constraint")
+    with pytest.raises(ValueError):
+        frontend.load_fzn(os.path.join(BENCH, "does_not_exist.fzn"))
+
+
+def test_headline_instances_lower():
+    shapes = {"example_wordpress7_500.fzn": (16963, 45967), "accap_a3.fzn": (933, 1060), "trains15.fzn": (24269, 24014)}
+    for name, (v, p) in shapes.items():
+        tcn = frontend.load_fzn(os.path.join(BENCH, name))
+        assert (tcn.n_vars, tcn.n_props) == (v, p)
+        assert int(tcn.props["x"].max()) < v and int(tcn.props["op"].max()) < 8
+
+
+# ---- multi-process protocol over gloo ---------------------------------------------------------------
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["TB_ROOT"])
+import torch.distributed as dist
+from turbo_amd.distributed import exchange_until_done, reduce_results, PINF
+
+class FakeSession:
+    """Scripted device: rank r finds bound b at poll number k, finishes at poll number `end`."""
+    def __init__(self, script, end):
+        self.script, self.end, self.n, self.best, self.pushed = script, end, 0, PINF, []
+    def poll(self):
+        self.n += 1
+        for k, b in self.script:
+            if self.n >= k: self.best = min(self.best, b)
+        return self.best, self.n >= self.end
+    def push_bound(self, b): self.pushed.append(b)
+    def stop(self): pass
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+r = dist.get_rank()
+s = FakeSession([(2, 50), (5, 30)] if r == 0 else [(3, 40), (9, 12)], end=6 if r == 0 else 11)
+gbest, rounds = exchange_until_done(s, dist, period_s=0.0)
+assert gbest == 12, gbest
+assert s.pushed == sorted(s.pushed, reverse=True) and s.pushed[-1] == 12, s.pushed   # monotone import of the incumbent
+assert rounds >= 11                                                                  # nobody leaves before the slowest rank is done
+winner, gb, tot = reduce_results(True, 30 if r == 0 else 12, {"nodes": 10 * (r + 1), "num_deductions": 7}, dist)
+assert (winner, gb, tot["nodes"], tot["num_deductions"]) == (1, 12, 30, 14), (winner, gb, tot)
+winner, gb, _ = reduce_results(True, 5, {}, dist)      # tie on the bound -> lowest rank (lowest subproblem slice)
+assert (winner, gb) == (0, 5)
+winner, gb, _ = reduce_results(False, 0, {}, dist)
+assert winner == -1
+dist.destroy_process_group()
+print("ok", r)
+'''
+
+
+def test_bound_exchange_protocol_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, TB_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "ok" in o
+
+
+# ---- CLI error behaviour (src/config.cpp:128-220, src/turbo.cpp:22-56) --------------------------------
+
+def run_turbo(*args):
+    return subprocess.run([TURBO, *args], capture_output=True, text=True, timeout=60)
+
+
+@pytest.mark.skipif(not os.path.exists(TURBO), reason="turbo CLI not built")
+class TestCli:
+    def test_unknown_arch(self):
+        r = run_turbo("-arch", "tpu", "x.fzn")
+        assert r.returncode == 1 and "Unknown architecture -arch tpu" in r.stderr
+
+    def test_unknown_fixpoint(self):
+        r = run_turbo("-fp", "ac3", "x.fzn")
+        assert r.returncode == 1 and "Unknown fixpoint -fp ac3" in r.stderr
+
+    def test_or_and_p_are_exclusive(self):
+        r = run_turbo("-or", "4", "-p", "4", "x.fzn")
+        assert r.returncode == 1 and "cannot be used at the same time" in r.stderr
+
+    def test_eps_orders_go_together(self):
+        r = run_turbo("-eps_var_order", "input_order", os.path.join(BENCH, "test_data", "sudoku_opt2.fzn"))
+        assert r.returncode == 1 and "must be specified together" in r.stdout
+
+    def test_unparsable_input(self, tmp_path):
+        f = tmp_path / "bad.fzn"
+        f.write_text("var 1..3 x;")
+        r = run_turbo(str(f))
+        assert r.returncode == 1 and "Could not parse input file." in r.stderr
+
+    def test_cpu_arch_is_refused_not_faked(self):
+        r = run_turbo("-arch", "cpu", os.path.join(BENCH, "test_data", "sudoku_opt2.fzn"))
+        assert r.returncode == 1 and "not provided by this build" in r.stderr
+
+    def test_unsat_at_interpretation(self):
+        r = run_turbo("-s", os.path.join(BENCH, "unsolved_bugs_data", "false.fzn"))
+        assert r.returncode == 0 and "=====UNSATISFIABLE=====" in r.stdout
+        assert '%%%mzn-stat: command_line="' in r.stdout and "%%%mzn-stat-end" in r.stdout
+
+    def test_command_line_echo_defaults(self):
+        r = run_turbo("-s", os.path.join(BENCH, "unsolved_bugs_data", "false.fzn"))
+        line = r.stdout.splitlines()[0]
+        for part in ("-t 0", "-n 1", "-arch barebones", "-or 0", "-sub -1", "-subfactor 300", "-fp wac1", "-wac1_threshold 0",
+                     "-seed 0", "-eps_var_order default", "-cutnodes 0"):
+            assert part in line, part

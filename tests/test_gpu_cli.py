@@ -1,0 +1,44 @@
+"""GPU tests of the `turbo` executable: the reference's regression script (test_turbo.sh) restated."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import BENCH, ROOT, known_answers
+
+pytestmark = pytest.mark.gpu
+TURBO = os.path.join(ROOT, "turbo_amd", "bin", "turbo")
+
+
+@pytest.mark.parametrize("rel,expected", known_answers())
+def test_regression_script_contract(rel, expected):
+    # test_turbo.sh:34-44: -eps_var_order input_order -eps_value_order min -arch barebones -s -t 60000
+    r = subprocess.run([TURBO, "-eps_var_order", "input_order", "-eps_value_order", "min", "-arch", "barebones", "-s", "-t", "60000",
+                        os.path.join(BENCH, rel)], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"objective=(-?\d+)", r.stdout)            # test_turbo.sh:47
+    t = re.search(r"solveTime=([0-9.]+)", r.stdout)          # test_turbo.sh:48
+    assert m and t, r.stdout[-2000:]
+    assert int(m.group(1)) == expected
+    assert float(t.group(1)) < 60.0
+    assert "==========" in r.stdout and "----------" in r.stdout
+
+
+def test_output_format_and_gpu_arch_alias():
+    r = subprocess.run([TURBO, "-arch", "gpu", "-s", "-t", "30000", os.path.join(BENCH, "test_data", "sudoku_opt2.fzn")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "objective = -2;" in r.stdout and "x = array2d(1..2, 1..2, [" in r.stdout
+    for key in ("nodes", "failures", "variables", "propagators", "peakDepth", "initTime", "solveTime", "num_solutions",
+                "eps_num_subproblems", "eps_solved_subproblems", "eps_skipped_subproblems", "num_blocks_done",
+                "fixpoint_iterations", "num_deductions", "memory_configuration"):
+        assert f"%%%mzn-stat: {key}=" in r.stdout, key
+
+
+def test_timeout_is_honoured_and_reported():
+    r = subprocess.run([TURBO, "-s", "-t", "1500", os.path.join(BENCH, "example_wordpress7_500.fzn")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    t = float(re.search(r"solveTime=([0-9.]+)", r.stdout).group(1))
+    assert t < 10.0
+    assert "==========" not in r.stdout  # not exhaustive

@@ -21,7 +21,7 @@ MEM_KINDS = ["global", "store_shared", "tcn_shared"]
 TIMERS = ["OVERALL", "PREPROCESSING", "SEARCH", "FIXPOINT", "TRANSFER_CPU2GPU", "TRANSFER_GPU2CPU",
           "SELECT_FP_FUNCTIONS", "WAIT_CPU", "DIVE", "LATEST_BEST_OBJ_FOUND", "FIRST_BLOCK_IDLE"]
 
-EXPORTS = ["tb_version", "tb_last_error", "tb_device_count", "tb_get_device_info", "tb_propagate", "tb_solve",
+EXPORTS = ["tb_version", "tb_last_error", "tb_device_count", "tb_get_device_info", "tb_eps_slice", "tb_propagate", "tb_solve",
            "tb_session_create", "tb_session_start", "tb_session_poll", "tb_session_push_bound",
            "tb_session_stop", "tb_session_finish", "tb_session_destroy"]
 
@@ -86,6 +86,8 @@ def lib() -> C.CDLL:
         L.tb_device_count.restype = C.c_int
         L.tb_get_device_info.restype = C.c_int
         L.tb_get_device_info.argtypes = [C.c_int, C.POINTER(TbDeviceInfo)]
+        L.tb_eps_slice.restype = C.c_int
+        L.tb_eps_slice.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.tb_propagate.restype = C.c_int
         L.tb_propagate.argtypes = [C.POINTER(TbConfig), C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
@@ -134,6 +136,12 @@ def device_info(device: int = 0) -> dict:
     info = TbDeviceInfo()
     check(lib().tb_get_device_info(device, C.byref(info)))
     return {k: (getattr(info, k).decode() if k == "name" else getattr(info, k)) for k, _ in info._fields_}
+
+
+def eps_slice(subproblems_power: int, rank: int, world_size: int):
+    lo, hi = C.c_uint64(0), C.c_uint64(0)
+    check(lib().tb_eps_slice(subproblems_power, rank, world_size, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
 
 
 def _net_args(tcn):

@@ -245,6 +245,15 @@ int tb_get_device_info(int device, tb_device_info* out) {
   return TB_OK;
 }
 
+int tb_eps_slice(int32_t subproblems_power, int32_t rank, int32_t world_size, uint64_t* lo_out, uint64_t* hi_out) {
+  if (subproblems_power < 0 || subproblems_power > 62 || world_size < 1 || rank < 0 || rank >= world_size || !lo_out || !hi_out)
+    return fail(TB_ERR_INVALID, "bad slice arguments");
+  const unsigned long long nsub = 1ull << subproblems_power;
+  *lo_out = (uint64_t)(((unsigned __int128)nsub * (unsigned long long)rank) / (unsigned long long)world_size);
+  *hi_out = (uint64_t)(((unsigned __int128)nsub * ((unsigned long long)rank + 1)) / (unsigned long long)world_size);
+  return TB_OK;
+}
+
 int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const tb_prop* props,
                  int32_t n_stores, tb_itv* stores_inout, int32_t* failed_out, int32_t* all_entailed_out,
                  uint64_t* iterations_out, uint64_t* deductions_out, int64_t* kernel_ns_out) {
@@ -372,8 +381,10 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   const unsigned long long nsub = 1ull << plan.subproblems_power;
   const unsigned long long world = (unsigned long long)std::max(1, s->cfg.world_size), rank = (unsigned long long)std::max(0, s->cfg.rank);
   // contiguous slices keep the subtree skip `((idx >> r) + 1) << r` local to a GPU (clamped at the slice end)
-  P.sub_lo = (unsigned long long)(((unsigned __int128)nsub * rank) / world);
-  P.sub_hi = (unsigned long long)(((unsigned __int128)nsub * (rank + 1)) / world);
+  (void)nsub;
+  uint64_t lo = 0, hi = 0;
+  if ((rc = tb_eps_slice(plan.subproblems_power, (int32_t)rank, (int32_t)world, &lo, &hi)) != TB_OK) return rc;
+  P.sub_lo = lo; P.sub_hi = hi;
   P.cut_nodes = s->cfg.stop_after_n_nodes;
   P.stop_after_n_solutions = s->cfg.stop_after_n_solutions;
 

@@ -1,0 +1,268 @@
+// `turbo` executable: the reference's command line and output protocol in front of the MI355X engine.
+//
+// Mirrors  src/turbo.cpp:22-56 (main, arch dispatch, exception -> exit 1),
+//          include/barebones_dive_and_solve.hpp:464-518 (host side of the solve: preprocess, run, print),
+//          include/common_solving.hpp:829-896 (solution / statistics printing),
+//          include/statistics.hpp:338-412 (mzn-stat keys and separators).
+// The solving itself is libturbo_hip.so through its C-ABI; there is no CPU solving path in this binary.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cinttypes>
+#include <csignal>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/turbo_front.h"
+#include "../../../include/turbo_hip.h"
+#include "cli_options.hpp"
+
+using namespace turbo_host;
+using Clock = std::chrono::steady_clock;
+
+namespace {
+
+volatile int32_t g_stop_flag = 0;  // set by SIGINT / SIGTERM (common_solving.hpp:56-85)
+void on_signal(int) { g_stop_flag = 1; }
+
+struct Printer {
+  bool on;
+  void s(const char* k, const char* v) const { if (on) std::printf("%%%%%%mzn-stat: %s=\"%s\"\n", k, v); }
+  void u(const char* k, uint64_t v) const { if (on) std::printf("%%%%%%mzn-stat: %s=%" PRIu64 "\n", k, v); }
+  void i(const char* k, int v) const { if (on) std::printf("%%%%%%mzn-stat: %s=%d\n", k, v); }
+  void d(const char* k, double v) const { if (on) std::printf("%%%%%%mzn-stat: %s=%lf\n", k, v != v ? 0.0 : v); }
+  void end() const { if (on) std::printf("%%%%%%mzn-stat-end\n"); }
+};
+
+double to_sec(int64_t ns) { return (double)(ns / 1000 / 1000) / 1000.0; }  // statistics.hpp:321-323
+
+void final_separator(uint64_t solutions, bool exhaustive, bool optimization) {  // statistics.hpp:394-412
+  if (solutions > 0) { if (exhaustive) std::printf("==========\n"); }
+  else if (exhaustive) std::printf("=====UNSATISFIABLE=====\n");
+  else if (optimization) std::printf("=====UNBOUNDED=====\n");
+  else std::printf("=====UNKNOWN=====\n");
+}
+
+void print_solve_statistics(const Printer& p, const Options& o, const tb_stats& st, int n_vars, int n_props, int64_t preprocessing_ns, int64_t overall_ns) {
+  const int nb = std::max(1, st.num_blocks);
+  p.i("num_blocks", st.num_blocks);
+  p.u("nodes", st.nodes);
+  p.u("failures", st.fails);
+  p.u("variables", (uint64_t)n_vars);
+  p.u("propagators", (uint64_t)n_props);
+  p.i("peakDepth", st.depth_max);
+  p.d("initTime", to_sec(preprocessing_ns));
+  p.d("solveTime", to_sec(overall_ns));
+  p.u("num_solutions", st.solutions);
+  p.u("eps_num_subproblems", st.eps_num_subproblems);
+  p.u("eps_solved_subproblems", st.eps_solved_subproblems);
+  p.u("eps_skipped_subproblems", st.eps_skipped_subproblems);
+  p.u("num_blocks_done", st.num_blocks_done);
+  p.u("fixpoint_iterations", st.fixpoint_iterations);
+  p.u("num_deductions", st.num_deductions);
+  p.d("cumulative_time_block_sec", to_sec(st.cumulative_time_block_ns));
+  p.d("deductions_per_block_second", (double)(st.num_deductions / (uint64_t)nb) / to_sec(st.cumulative_time_block_ns));
+  p.d("solve_time", to_sec(st.timers_ns[TB_T_OVERALL] / nb));
+  p.d("search_time", to_sec(st.timers_ns[TB_T_SEARCH] / nb));
+  p.d("fixpoint_time", to_sec(st.timers_ns[TB_T_FIXPOINT] / nb));
+  p.d("transfer_cpu2gpu_time", to_sec(st.timers_ns[TB_T_TRANSFER_CPU2GPU] / nb));
+  p.d("transfer_gpu2cpu_time", to_sec(st.timers_ns[TB_T_TRANSFER_GPU2CPU] / nb));
+  p.d("select_fp_functions_time", to_sec(st.timers_ns[TB_T_SELECT_FP_FUNCTIONS] / nb));
+  p.d("wait_cpu_time", to_sec(st.timers_ns[TB_T_WAIT_CPU] / nb));
+  p.d("dive_time", to_sec(st.timers_ns[TB_T_DIVE] / nb));
+  p.d("best_obj_time", to_sec(st.timers_ns[TB_T_LATEST_BEST_OBJ_FOUND]));
+  p.d("first_block_idle_time", to_sec(st.timers_ns[TB_T_FIRST_BLOCK_IDLE]));
+  // engine-specific keys (additions, never replacing a reference key)
+  p.d("kernel_time", (double)st.kernel_ns * 1e-9);
+  p.d("propagations_per_second", st.kernel_ns > 0 ? (double)st.num_deductions / ((double)st.kernel_ns * 1e-9) : 0.0);
+  p.d("nodes_per_second", st.kernel_ns > 0 ? (double)st.nodes / ((double)st.kernel_ns * 1e-9) : 0.0);
+  (void)o;
+}
+
+void merge_stats(tb_stats& a, const tb_stats& b) {  // statistics.hpp:182-196 across GPUs
+  a.nodes += b.nodes; a.fails += b.fails; a.solutions += b.solutions;
+  a.fixpoint_iterations += b.fixpoint_iterations; a.num_deductions += b.num_deductions;
+  a.eps_solved_subproblems += b.eps_solved_subproblems; a.eps_skipped_subproblems += b.eps_skipped_subproblems;
+  a.num_blocks_done += b.num_blocks_done; a.store_writes += b.store_writes;
+  a.depth_max = std::max(a.depth_max, b.depth_max);
+  a.exhaustive = a.exhaustive && b.exhaustive;
+  a.interrupted = a.interrupted || b.interrupted;
+  a.num_blocks += b.num_blocks;
+  for (int t = 0; t < TB_NUM_TIMERS; ++t)
+    if (t != TB_T_FIRST_BLOCK_IDLE && t != TB_T_LATEST_BEST_OBJ_FOUND) a.timers_ns[t] += b.timers_ns[t];
+  a.timers_ns[TB_T_FIRST_BLOCK_IDLE] = std::min(a.timers_ns[TB_T_FIRST_BLOCK_IDLE], b.timers_ns[TB_T_FIRST_BLOCK_IDLE]);
+  a.cumulative_time_block_ns += b.cumulative_time_block_ns;
+  a.kernel_ns = std::max(a.kernel_ns, b.kernel_ns);
+}
+
+tb_config make_config(const Options& o, bool has_eps) {
+  tb_config c;
+  std::memset(&c, 0, sizeof(c));
+  c.timeout_ms = o.timeout_ms; c.or_nodes = o.or_nodes; c.subproblems_factor = o.subproblems_factor;
+  c.stop_after_n_nodes = o.stop_after_n_nodes == UINT64_MAX ? 0 : o.stop_after_n_nodes;
+  c.stop_after_n_solutions = o.stop_after_n_solutions; c.wac1_threshold = o.wac1_threshold;
+  c.subproblems_power = o.subproblems_power; c.fixpoint = o.fixpoint == Fixpoint::WAC1 ? 1 : 0;
+  c.only_global_memory = o.only_global_memory; c.verbose = o.verbose; c.has_eps_strategy = has_eps;
+  c.threads_per_block = o.threads_per_block; c.device = 0; c.rank = 0; c.world_size = 1;
+  c.deterministic = o.deterministic;
+  return c;
+}
+
+// N GPUs of the node: one session per device, this thread relays the incumbent bound and the stop flag.
+int solve_multi_gpu(const Options& o, const tb_config& base, const tf_model* m, std::vector<tb_itv>& best, int32_t* has, tb_stats* out) {
+  const int G = o.gpus;
+  std::vector<tb_session*> ss((size_t)G, nullptr);
+  int rc = TB_OK;
+  for (int g = 0; g < G && rc == TB_OK; ++g) {
+    tb_config c = base;
+    c.device = g; c.rank = g; c.world_size = G; c.deterministic = 0;
+    rc = tb_session_create(&c, tf_num_vars(m), tf_store(m), tf_num_props(m), tf_props(m), tf_num_strategies(m), tf_strat_var_order(m),
+                           tf_strat_val_order(m), tf_strat_off(m), tf_strat_vars(m), tf_obj_var(m), &ss[(size_t)g]);
+  }
+  for (int g = 0; g < G && rc == TB_OK; ++g) rc = tb_session_start(ss[(size_t)g]);
+  const auto t0 = Clock::now();
+  while (rc == TB_OK) {
+    int32_t gbest = TB_PINF, all_done = 1;
+    for (int g = 0; g < G; ++g) {
+      int32_t b = TB_PINF, d = 0;
+      rc = tb_session_poll(ss[(size_t)g], &b, &d);
+      if (rc != TB_OK) break;
+      gbest = std::min(gbest, b);
+      all_done &= d;
+    }
+    if (rc != TB_OK || all_done) break;
+    if (gbest != TB_PINF) for (int g = 0; g < G; ++g) tb_session_push_bound(ss[(size_t)g], gbest);
+    const uint64_t el = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(Clock::now() - t0).count();
+    if ((o.timeout_ms != 0 && el >= o.timeout_ms) || g_stop_flag) for (int g = 0; g < G; ++g) tb_session_stop(ss[(size_t)g]);
+    std::this_thread::sleep_for(std::chrono::microseconds(500));
+  }
+  bool first = true;
+  int32_t best_bound = TB_PINF;
+  std::vector<tb_itv> tmp(best.size());
+  for (int g = 0; g < G && rc == TB_OK; ++g) {
+    tb_stats st;
+    int32_t h = 0;
+    rc = tb_session_finish(ss[(size_t)g], tmp.data(), &h, &st);
+    if (rc != TB_OK) break;
+    if (h && (!*has || st.best_bound < best_bound)) { *has = 1; best_bound = st.best_bound; best = tmp; }  // ties: lowest rank = lowest subproblem slice
+    if (first) { *out = st; first = false; } else merge_stats(*out, st);
+  }
+  out->best_bound = best_bound;
+  for (tb_session* s : ss) tb_session_destroy(s);
+  return rc;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Options o = parse_options(argc, argv);
+  Printer p{o.print_statistics};
+  if (o.print_statistics) std::printf("%%%%%%mzn-stat: command_line=\"%s\"\n", command_line_echo(o, argv[0]).c_str());
+  if (o.arch == Arch::CPU || o.arch == Arch::HYBRID) {
+    std::cerr << "-arch " << name_of(o.arch) << " is not provided by this build: it contains only the MI355X dive-and-solve engine (use -arch gpu or -arch barebones)." << std::endl;
+    return EXIT_FAILURE;
+  }
+  if (o.print_intermediate_solutions) std::printf("%% WARNING: -arch %s is incompatible with -i and -a (it cannot print intermediate solutions).\n", name_of(o.arch));
+  const auto start = Clock::now();
+
+  // preprocess (common_solving.hpp:605-637, -disable_simplify pipeline)
+  const bool is_fzn = o.problem_path.size() >= 4 && o.problem_path.compare(o.problem_path.size() - 4, 4, ".fzn") == 0;
+  if (!is_fzn) {
+    std::printf("ERROR: Unknown input format for the file %s [supported extension: .fzn].\n", o.problem_path.c_str());
+    return EXIT_FAILURE;
+  }
+  char err[1024] = {0};
+  tf_model* m = tf_load_fzn(o.problem_path.c_str(), err, sizeof(err));
+  if (!m) {
+    std::cerr << "Could not parse input file." << std::endl;
+    if (o.verbose) std::cerr << err << std::endl;
+    return EXIT_FAILURE;
+  }
+  bool has_eps = false;
+  if (o.eps_var_order != "default") {
+    static const char* vo[] = {"input_order", "first_fail", "anti_first_fail", "smallest", "largest"};
+    static const char* vl[] = {"min", "max", "split", "reverse_split"};
+    int vi = -1, li = -1;
+    for (int k = 0; k < 5; ++k) if (o.eps_var_order == vo[k]) vi = k;
+    if (o.eps_var_order == "random") vi = 0;
+    for (int k = 0; k < 4; ++k) if (o.eps_value_order == vl[k]) li = k;
+    if (vi < 0) { std::printf("Unrecognized option `-eps_var_order %s`\n", o.eps_var_order.c_str()); return EXIT_FAILURE; }
+    if (li < 0) { std::printf("Unrecognized option `-eps_value_order %s`\n", o.eps_value_order.c_str()); return EXIT_FAILURE; }
+    tf_push_eps_strategy(m, vi, li);
+    has_eps = true;
+  }
+  const int n_vars = tf_num_vars(m), n_props = tf_num_props(m);
+  const int64_t preprocessing_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - start).count();
+  p.u("parsed_variables", (uint64_t)tf_parsed_variables(m));
+  p.u("parsed_constraints", (uint64_t)tf_parsed_constraints(m));
+  p.s("abstract_domain", "pir_itv32_z");
+  p.s("entailed_prop_removal", "deactivated");
+  p.u("tcn_variables", (uint64_t)n_vars);
+  p.u("tcn_constraints", (uint64_t)n_props);
+  p.d("preprocessing_time", to_sec(preprocessing_ns));
+  p.end();
+
+  const bool optimization = tf_goal(m) != 0;
+  tb_stats st;
+  std::memset(&st, 0, sizeof(st));
+  st.exhaustive = 1; st.num_blocks = 1;
+  if (tf_trivially_unsat(m)) {  // cp.iprop->is_bot() after preprocessing (barebones:474-478)
+    final_separator(0, true, optimization);
+    if (o.print_statistics) {
+      print_config_statistics(o);
+      print_solve_statistics(p, o, st, n_vars, n_props, preprocessing_ns, std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - start).count());
+      p.end();
+    }
+    tf_free(m);
+    return 0;
+  }
+
+  std::signal(SIGINT, on_signal);
+  std::signal(SIGTERM, on_signal);
+  tb_config cfg = make_config(o, has_eps);
+  std::vector<tb_itv> best((size_t)std::max(1, n_vars));
+  int32_t has = 0;
+  int rc;
+  if (o.gpus <= 1) {
+    rc = tb_solve(&cfg, n_vars, tf_store(m), n_props, tf_props(m), tf_num_strategies(m), tf_strat_var_order(m), tf_strat_val_order(m),
+                  tf_strat_off(m), tf_strat_vars(m), tf_obj_var(m), &g_stop_flag, best.data(), &has, &st);
+  } else {
+    rc = solve_multi_gpu(o, cfg, m, best, &has, &st);
+  }
+  if (rc != TB_OK) {
+    std::cout.flush();
+    std::cerr << "\n\tUnexpected exception:\n\t" << tb_last_error() << std::endl;
+    tf_free(m);
+    return EXIT_FAILURE;
+  }
+  const int64_t overall_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - start).count();
+
+  if (has) {  // barebones prints only the final best solution (barebones:499-506)
+    const int32_t need = tf_format_solution(m, best.data(), nullptr, 0);
+    std::string text((size_t)need + 1, '\0');
+    tf_format_solution(m, best.data(), text.data(), need + 1);
+    std::fputs(text.c_str(), stdout);
+    std::printf("----------\n");
+  }
+  final_separator(st.solutions, st.exhaustive != 0, optimization);
+  if (o.print_statistics) {
+    static const char* mem[] = {"global", "store_shared", "tcn_shared"};
+    p.s("memory_configuration", mem[std::min(2, std::max(0, st.mem_kind))]);
+    p.u("shared_mem", (uint64_t)st.shared_bytes);
+    p.u("store_mem", (uint64_t)n_vars * 8);
+    p.u("propagator_mem", (uint64_t)n_props * 16);
+    p.i("subproblems_power", st.subproblems_power);
+    p.end();
+    print_config_statistics(o);
+    p.i("threads_per_block", st.threads_per_block);
+    print_solve_statistics(p, o, st, n_vars, n_props, preprocessing_ns, overall_ns);
+    if (optimization && has) std::printf("%%%%%%mzn-stat: objective=%" PRId64 "\n", tf_objective_of(m, best.data()));
+    p.end();
+  }
+  tf_free(m);
+  return 0;
+}
