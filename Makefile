@@ -17,7 +17,7 @@ HOST_SRC := $(wildcard turbo_amd/csrc/host/*.cpp)
 HOST_HDR := $(wildcard turbo_amd/csrc/host/*.hpp)
 
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter -Wno-bitwise-instead-of-logical $(EXTRA_HIPFLAGS)
 
 all: front hip cli oracle
 

@@ -59,7 +59,7 @@ typedef struct {
   uint64_t stop_after_n_solutions;  /* -n, satisfaction problems only; 0 = all */
   uint64_t wac1_threshold;          /* -wac1_threshold (barebones:939) */
   int32_t subproblems_power;        /* -sub; -1 = auto */
-  int32_t fixpoint;                 /* 0 = AC1, 1 = WAC1 (config.hpp:22-25) */
+  int32_t fixpoint;                 /* 0 = AC1, 1 = WAC1 (config.hpp:22-25), 2 = event-driven WAC1 (this engine) */
   int32_t only_global_memory;       /* -globalmem */
   int32_t verbose;
   int32_t has_eps_strategy;         /* strategy 0 is the EPS strategy (barebones:434,747-750) */

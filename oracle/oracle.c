@@ -37,18 +37,22 @@ static inline int32_t clamp64(int64_t v) {
 
 static inline int32_t neg_ext(int32_t a) { return a == NINF ? PINF : (a == PINF ? NINF : -a); }
 
-/* lower bound of a sum given the two lower bounds */
-static inline int32_t add_lo(int32_t a, int32_t b) {
-  if (a == NINF || b == NINF) return NINF;
-  if (a == PINF || b == PINF) return PINF;
-  return clamp64((int64_t)a + (int64_t)b);
+/* Bounds of sums / differences.  An infinite bound on the side that matters absorbs, everything else
+ * saturates (a bound on the "wrong" side -- lb = +inf, ub = -inf -- only occurs for empty domains). */
+static inline int32_t add_lo(int32_t a, int32_t b) { /* lb(A+B) from lb(A), lb(B) */
+  return (a == NINF || b == NINF) ? NINF : clamp64((int64_t)a + (int64_t)b);
 }
-/* upper bound of a sum given the two upper bounds */
-static inline int32_t add_hi(int32_t a, int32_t b) {
-  if (a == PINF || b == PINF) return PINF;
-  if (a == NINF || b == NINF) return NINF;
-  return clamp64((int64_t)a + (int64_t)b);
+static inline int32_t add_hi(int32_t a, int32_t b) { /* ub(A+B) from ub(A), ub(B) */
+  return (a == PINF || b == PINF) ? PINF : clamp64((int64_t)a + (int64_t)b);
 }
+static inline int32_t sub_lo(int32_t a, int32_t b) { /* lb(A-B) from lb(A), ub(B) */
+  return (a == NINF || b == PINF) ? NINF : clamp64((int64_t)a - (int64_t)b);
+}
+static inline int32_t sub_hi(int32_t a, int32_t b) { /* ub(A-B) from ub(A), lb(B) */
+  return (a == PINF || b == NINF) ? PINF : clamp64((int64_t)a - (int64_t)b);
+}
+static inline int32_t sat_inc(int32_t a) { return clamp64((int64_t)a + 1); }
+static inline int32_t sat_dec(int32_t a) { return clamp64((int64_t)a - 1); }
 
 static inline int32_t mul_ext(int32_t a, int32_t b) {
   if (a == 0 || b == 0) return 0;
@@ -86,8 +90,8 @@ int orc_deduce(const orc_prop* p, orc_itv* store, int* failed) {
   switch (p->op) {
     case ORC_ADD: {
       embed(store, p->x, add_lo(Y.lb, Z.lb), add_hi(Y.ub, Z.ub), &changed, failed);
-      embed(store, p->y, add_lo(X.lb, neg_ext(Z.ub)), add_hi(X.ub, neg_ext(Z.lb)), &changed, failed);
-      embed(store, p->z, add_lo(X.lb, neg_ext(Y.ub)), add_hi(X.ub, neg_ext(Y.lb)), &changed, failed);
+      embed(store, p->y, sub_lo(X.lb, Z.ub), sub_hi(X.ub, Z.lb), &changed, failed);
+      embed(store, p->z, sub_lo(X.lb, Y.ub), sub_hi(X.ub, Y.lb), &changed, failed);
       break;
     }
     case ORC_MUL: {
@@ -170,12 +174,12 @@ int orc_deduce(const orc_prop* p, orc_itv* store, int* failed) {
         embed(store, p->z, Y.lb, Y.ub, &changed, failed);
       } else if (X.ub <= 0) {
         if (Y.lb == Y.ub) {
-          if (Z.lb == Y.lb) embed(store, p->z, add_lo(Y.lb, 1), PINF, &changed, failed);
-          if (Z.ub == Y.lb) embed(store, p->z, NINF, add_hi(Y.lb, -1), &changed, failed);
+          if (Z.lb == Y.lb) embed(store, p->z, sat_inc(Y.lb), PINF, &changed, failed);
+          if (Z.ub == Y.lb) embed(store, p->z, NINF, sat_dec(Y.lb), &changed, failed);
         }
         if (Z.lb == Z.ub) {
-          if (Y.lb == Z.lb) embed(store, p->y, add_lo(Z.lb, 1), PINF, &changed, failed);
-          if (Y.ub == Z.lb) embed(store, p->y, NINF, add_hi(Z.lb, -1), &changed, failed);
+          if (Y.lb == Z.lb) embed(store, p->y, sat_inc(Z.lb), PINF, &changed, failed);
+          if (Y.ub == Z.lb) embed(store, p->y, NINF, sat_dec(Z.lb), &changed, failed);
         }
       } else {
         if (Y.ub < Z.lb || Y.lb > Z.ub) embed(store, p->x, NINF, 0, &changed, failed);
@@ -211,8 +215,8 @@ int orc_ask(const orc_prop* p, const orc_itv* store) {
     default: break;
   }
   if (X.lb != X.ub || Y.lb != Y.ub || Z.lb != Z.ub) return 0;
-  if (is_inf(X.lb) || is_inf(Y.lb) || is_inf(Z.lb)) return 0;
   int64_t x = X.lb, y = Y.lb, z = Z.lb;
+  if ((p->op == ORC_MUL || p->op == ORC_TDIV || p->op == ORC_TMOD) && (is_inf(X.lb) || is_inf(Y.lb) || is_inf(Z.lb))) return 0;
   switch (p->op) {
     case ORC_ADD: return x == y + z;
     case ORC_MUL: return x == y * z;

@@ -14,7 +14,7 @@ for name in insts:
     for o in tcn.props["op"]:
         ops[int(o)] = ops.get(int(o), 0) + 1
     print("   ops:", {frontend.OP_NAMES[k]: v for k, v in sorted(ops.items())})
-    for label, kw in [("wac1", dict(fixpoint=1)), ("ac1", dict(fixpoint=0))]:
+    for label, kw in [("wac1", dict(fixpoint=1)), ("event", dict(fixpoint=2))]:
         has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=5000, **kw))
         secs = st["kernel_ns"] * 1e-9
         print(f"   GPU {label}: blocks={st['num_blocks']}x{st['threads_per_block']} mem={capi.MEM_KINDS[st['mem_kind']]} lds={st['shared_bytes']} d={st['subproblems_power']} "

@@ -67,11 +67,11 @@ def check_batch(tcn, stores, **cfg):
             assert bool(ent[i]) == eent, f"store {i}: entailment flag differs"
             np.testing.assert_array_equal(got[i]["lb"], exp["lb"], err_msg=f"store {i}: lower bounds differ")
             np.testing.assert_array_equal(got[i]["ub"], exp["ub"], err_msg=f"store {i}: upper bounds differ")
-        assert iters[i] >= 1 or efailed
+        assert iters[i] >= 1 or efailed or tcn.n_props == 0
 
 
 @pytest.mark.parametrize("rel", [r[0] for r in ROWS] + HEADLINE)
-@pytest.mark.parametrize("fixpoint", [0, 1], ids=["ac1", "wac1"])
+@pytest.mark.parametrize("fixpoint", [0, 1, 2], ids=["ac1", "wac1", "event"])
 def test_root_fixpoint_bit_exact(rel, fixpoint):
     tcn = load(rel)
     check_batch(tcn, tcn.store[None, :], fixpoint=fixpoint)
@@ -79,12 +79,13 @@ def test_root_fixpoint_bit_exact(rel, fixpoint):
 
 @pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pennies5.fzn",
                                  "test_data/triangular9.fzn", "test_data/bug4.fzn", "accap_a3.fzn"])
-@pytest.mark.parametrize("mode", ["wac1", "ac1", "globalmem", "t1024"])
+@pytest.mark.parametrize("mode", ["wac1", "ac1", "globalmem", "t1024", "event", "event_globalmem", "event_t1024"])
 def test_random_nodes_bit_exact(rel, mode):
     tcn = load(rel)
     stores = random_nodes(tcn, 48, seed=zlib.crc32(rel.encode()) % 1000)
     cfg = {"wac1": dict(fixpoint=1), "ac1": dict(fixpoint=0), "globalmem": dict(fixpoint=1, only_global_memory=1),
-           "t1024": dict(fixpoint=1, threads_per_block=1024)}[mode]
+           "t1024": dict(fixpoint=1, threads_per_block=1024), "event": dict(fixpoint=2),
+           "event_globalmem": dict(fixpoint=2, only_global_memory=1), "event_t1024": dict(fixpoint=2, threads_per_block=1024)}[mode]
     check_batch(tcn, stores, **cfg)
 
 
@@ -94,12 +95,13 @@ def test_wordpress_nodes_bit_exact():
     check_batch(tcn, stores, fixpoint=1)
 
 
+@pytest.mark.parametrize("fixpoint", [1, 2], ids=["wac1", "event"])
 @pytest.mark.parametrize("rel,expected", FAST)
-def test_sequential_tree_identical(rel, expected):
+def test_sequential_tree_identical(rel, expected, fixpoint):
     """One workgroup, one subproblem: the GPU explores exactly the oracle's DFS tree."""
     tcn = load(rel)
     has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=0, timeout_ms=120000)
-    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=0, timeout_ms=120000))
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=0, timeout_ms=120000, fixpoint=fixpoint))
     assert has_g == has_o and st_g["exhaustive"] == st_o["exhaustive"] == 1
     assert tcn.objective_of(best_g) == expected
     for k in ("nodes", "fails", "solutions", "depth_max"):
@@ -109,22 +111,25 @@ def test_sequential_tree_identical(rel, expected):
 
 @pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pat7.fzn", "test_data/sudoku_opt_p0.fzn"])
 @pytest.mark.parametrize("power", [3, 6])
-def test_sequential_eps_identical(rel, power):
-    """One workgroup walking 2^d subproblems in index order == the oracle's sequential dive-and-solve."""
+@pytest.mark.parametrize("fixpoint,levels", [(1, 0), (2, 0), (2, 1), (2, 3)], ids=["wac1", "event", "event_recompute", "event_3levels"])
+def test_sequential_eps_identical(rel, power, fixpoint, levels):
+    """One workgroup walking 2^d subproblems in index order == the oracle's sequential dive-and-solve
+    (snapshot_levels=1 is the reference's recompute-from-root backtracking)."""
     tcn = load(rel)
     has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power)
-    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=power, timeout_ms=120000))
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=power, timeout_ms=120000, fixpoint=fixpoint, snapshot_levels=levels))
     assert has_g == has_o
     for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
         assert st_g[k] == st_o[k], k
     np.testing.assert_array_equal(best_g, best_o)
 
 
+@pytest.mark.parametrize("fixpoint", [1, 2], ids=["wac1", "event"])
 @pytest.mark.parametrize("rel,expected", ROWS)
-def test_parallel_objective_matches_known_answer(rel, expected):
+def test_parallel_objective_matches_known_answer(rel, expected, fixpoint):
     """Reference regression contract (test_turbo.sh:34-67): the objective of every instance."""
     tcn = load(rel)
-    has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=60000))
+    has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=60000, fixpoint=fixpoint))
     assert has
     assert tcn.objective_of(best) == expected
     assert st["exhaustive"] == 1, "optimality must be proved within the reference's 60 s budget"

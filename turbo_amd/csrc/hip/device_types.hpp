@@ -47,13 +47,21 @@ struct DevProblem {
   const int* strat_val_order;
   const int* strat_off;
   const int* strat_vars;
+  // event-driven fixpoint: variable -> 64-propagator slices adjacency (CSR), built by the shim
+  const int* adj_off;   // [n_vars + 1]
+  const int* adj;       // slice ids
+  int n_slices;         // ceil(n_props / 64)
+  int dirty_words;      // ceil(n_slices / 32)
+  int vext;             // int2 elements of a store slab: n_vars + one "not entailed" byte per slice
+  int chg_cap;          // capacity of one change list (entries)
   // configuration
-  int fixpoint;            // 0 AC1, 1 WAC1
+  int fixpoint;            // 0 AC1, 1 WAC1, 2 event-driven WAC1
   int wac1_threshold;
   int subproblems_power;
   int has_eps_strategy;
   int use_fixed_bound, fixed_bound;
   int mem_kind;            // tb_mem_kind
+  int debug;               // ablation knobs for profiling (tb_config.reserved[0]); 0 in production
   int snapshot_levels;     // >= 1
   int max_depth;           // capacity of the decision stack
   unsigned long long sub_lo, sub_hi;  // this device's slice of the EPS index space

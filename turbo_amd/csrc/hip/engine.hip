@@ -75,6 +75,7 @@ struct LaunchPlan {
   int subproblems_power = 0;
   int snapshot_levels = 1;
   int max_depth = 16384;
+  int n_slices = 0, dirty_words = 0, vext = 0, chg_cap = 64;
 };
 
 inline size_t align16(size_t x) { return (x + 15) / 16 * 16; }
@@ -90,12 +91,19 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, int n_vars, int n_
   p.threads = T;
   p.tmax = T <= 256 ? 256 : 1024;
   const size_t lds = (size_t)caps.lds_per_cu;
-  const size_t store_b = align16((size_t)n_vars * 8), props_b = align16((size_t)n_props * 16);
+  const int n_slices = (n_props + 63) / 64, dirty_words = (n_slices + 31) / 32, vext = n_vars + (n_slices + 7) / 8;
+  p.n_slices = n_slices; p.dirty_words = dirty_words; p.vext = vext;
+  // store slab = domains + one entailment byte per 64-propagator slice; the three dirty bitmaps of the
+  // event-driven fixpoint always live in LDS
+  // one dirty bitmap + two change lists of (variable, slice) pairs; an overflowing list falls back to a full sweep
+  p.chg_cap = std::min(1024, std::max(64, n_vars / 4));
+  const size_t dirty_b = align16((size_t)dirty_words * 4) + (size_t)p.chg_cap * 16;
+  const size_t store_b = align16((size_t)vext * 8) + dirty_b, props_b = align16((size_t)n_props * 16);
   const size_t fixed = SH_BYTES;
   int bpc_max = std::min(8, 2048 / T);  // 32 waves per CU
   if (bpc_max < 1) bpc_max = 1;
   if (cfg.only_global_memory) {
-    p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)fixed;
+    p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
   } else if ((fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
     p.mem_kind = TB_MEM_TCN_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b + props_b);
   } else if ((fixed + store_b) * (size_t)bpc_max <= lds) {
@@ -103,7 +111,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, int n_vars, int n_
   } else if (fixed + store_b <= lds) {
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / (fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
   } else {
-    p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)fixed;
+    p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
   }
   long long blocks = (long long)p.blocks_per_cu * caps.cus;
   if (cfg.or_nodes != 0) blocks = std::min<long long>(blocks, (long long)cfg.or_nodes);
@@ -124,7 +132,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, int n_vars, int n_
   p.max_depth = 16384;
   int L = cfg.snapshot_levels;
   if (L <= 0) {
-    const size_t per_level = (size_t)p.num_blocks * (size_t)std::max(1, n_vars) * 8;
+    const size_t per_level = (size_t)p.num_blocks * (size_t)std::max(1, vext) * 8;
     size_t budget = caps.free_mem / 4;
     L = (int)std::min<size_t>(256, std::max<size_t>(1, budget / std::max<size_t>(1, per_level)));
   }
@@ -141,6 +149,63 @@ int validate_network(int32_t n_vars, const tb_itv* store, int32_t n_props, const
     if (p.x < 0 || p.x >= n_vars || p.y < 0 || p.y >= n_vars || p.z < 0 || p.z >= n_vars) return fail(TB_ERR_INVALID, "propagator " + std::to_string(i) + ": variable out of range");
   }
   return TB_OK;
+}
+
+// Rewrite the caller's bytecodes into the engine's packed records (propagators.hpp): pack-time class,
+// and an immediate in place of every operand that is a constant (a singleton variable) in `consts`.
+std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::vector<char>& is_const, const std::vector<int>& value) {
+  std::vector<int4> out((size_t)n_props);
+  for (int32_t base = 0; base < n_props; base += 64) {
+    const int32_t end = std::min(n_props, base + 64);
+    int present = 0;
+    for (int32_t i = base; i < end; ++i) {
+      const tb_prop& p = props[i];
+      const bool xc = is_const[(size_t)p.x] != 0;
+      const int cls = class_of(p.op, xc, xc ? value[(size_t)p.x] : 0);
+      present |= 1 << cls;
+      out[(size_t)i] = make_int4(cls | (p.op << 12), p.x, p.y, p.z);
+    }
+    for (int32_t i = base; i < end; ++i) out[(size_t)i].x |= present << 16;  // same mask in the 64 records of a slice
+  }
+  return out;
+}
+
+// Variable -> slices adjacency (CSR) of the event-driven fixpoint: slice s = propagators [64 s, 64 s + 64).
+// Constants never change, so they get an empty list.
+void build_adjacency(int32_t n_vars, int32_t n_props, const tb_prop* props, const std::vector<char>& is_const,
+                     std::vector<int>* off, std::vector<int>* adj) {
+  std::vector<std::vector<int>> lists((size_t)n_vars);
+  for (int32_t i = 0; i < n_props; ++i) {
+    const int s = i / 64;
+    const int vs[3] = {props[i].x, props[i].y, props[i].z};
+    for (int v : vs) {
+      if (is_const[(size_t)v]) continue;
+      std::vector<int>& l = lists[(size_t)v];
+      if (l.empty() || l.back() != s) l.push_back(s);
+    }
+  }
+  off->assign((size_t)n_vars + 1, 0);
+  adj->clear();
+  for (int32_t v = 0; v < n_vars; ++v) {
+    (*off)[(size_t)v] = (int)adj->size();
+    adj->insert(adj->end(), lists[(size_t)v].begin(), lists[(size_t)v].end());
+  }
+  (*off)[(size_t)n_vars] = (int)adj->size();
+}
+
+// Constants of a batch of stores: variables that are the same finite singleton in every store.
+void find_constants(int32_t n_vars, int32_t n_stores, const tb_itv* stores, std::vector<char>* is_const, std::vector<int>* value) {
+  is_const->assign((size_t)n_vars, 1);
+  value->assign((size_t)n_vars, 0);
+  for (int32_t v = 0; v < n_vars; ++v) {
+    const tb_itv d0 = stores[v];
+    if (d0.lb != d0.ub || d0.lb == TB_NINF || d0.lb == TB_PINF) { (*is_const)[(size_t)v] = 0; continue; }
+    (*value)[(size_t)v] = d0.lb;
+    for (int32_t s = 1; s < n_stores; ++s) {
+      const tb_itv d = stores[(size_t)s * (size_t)n_vars + (size_t)v];
+      if (d.lb != d0.lb || d.ub != d0.ub) { (*is_const)[(size_t)v] = 0; break; }
+    }
+  }
 }
 
 template <int MEM, int TMAX>
@@ -274,11 +339,26 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   if ((rc = bufs.alloc(&d_props, (size_t)n_props)) != TB_OK) return rc;
   if ((rc = bufs.alloc(&d_stores, (size_t)n_stores * (size_t)n_vars)) != TB_OK) return rc;
   if ((rc = bufs.alloc(&d_out, (size_t)n_stores)) != TB_OK) return rc;
-  if (n_props) HIP_TRY(hipMemcpy(d_props, props, (size_t)n_props * sizeof(tb_prop), hipMemcpyHostToDevice));
+  {
+    std::vector<char> is_const;
+    std::vector<int> value, off, adj;
+    find_constants(n_vars, n_stores, stores_inout, &is_const, &value);
+    const std::vector<int4> packed = pack_props(n_props, props, is_const, value);
+    if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), (size_t)n_props * sizeof(int4), hipMemcpyHostToDevice));
+    build_adjacency(n_vars, n_props, props, is_const, &off, &adj);
+    int *d_off = nullptr, *d_adj = nullptr;
+    if ((rc = bufs.alloc(&d_off, off.size())) != TB_OK) return rc;
+    if ((rc = bufs.alloc(&d_adj, adj.size())) != TB_OK) return rc;
+    HIP_TRY(hipMemcpy(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    if (!adj.empty()) HIP_TRY(hipMemcpy(d_adj, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
+    P.adj_off = d_off; P.adj = d_adj;
+    if (plan.mem_kind == TB_MEM_GLOBAL) { if ((rc = bufs.alloc(&P.g_store, (size_t)plan.num_blocks * (size_t)plan.vext)) != TB_OK) return rc; }
+  }
+  P.n_slices = plan.n_slices; P.dirty_words = plan.dirty_words; P.vext = plan.vext; P.chg_cap = plan.chg_cap;
   if (n_vars) HIP_TRY(hipMemcpy(d_stores, stores_inout, (size_t)n_stores * (size_t)n_vars * sizeof(tb_itv), hipMemcpyHostToDevice));
   P.n_vars = n_vars; P.n_props = n_props; P.props = d_props;
   P.fixpoint = cfg.fixpoint; P.wac1_threshold = (int)std::min<uint64_t>(cfg.wac1_threshold, 0x7fffffffu);
-  P.mem_kind = plan.mem_kind;
+  P.mem_kind = plan.mem_kind; P.debug = cfg.reserved[0];
   const uint64_t timeout_ms = cfg.timeout_ms ? cfg.timeout_ms : 60000;
   // watchdog deadline in device wall-clock ticks (read the counter through a tiny query below)
   if ((rc = set_lds_limit(false, plan.mem_kind, plan.tmax, plan.shared_bytes)) != TB_OK) return rc;
@@ -349,7 +429,21 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   if ((rc = s->bufs.alloc(&d_vl, (size_t)n_strats)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_off, (size_t)n_strats + 1)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_sv, (size_t)total_svars)) != TB_OK) return rc;
-  if (n_props) HIP_TRY(hipMemcpy(d_props, props, (size_t)n_props * sizeof(tb_prop), hipMemcpyHostToDevice));
+  {
+    std::vector<char> is_const;
+    std::vector<int> value, off, adj;
+    find_constants(n_vars, 1, root_store, &is_const, &value);  // constants = singleton variables of the root store
+    const std::vector<int4> packed = pack_props(n_props, props, is_const, value);
+    if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), (size_t)n_props * sizeof(int4), hipMemcpyHostToDevice));
+    build_adjacency(n_vars, n_props, props, is_const, &off, &adj);
+    int *d_aoff = nullptr, *d_adj = nullptr;
+    if ((rc = s->bufs.alloc(&d_aoff, off.size())) != TB_OK) return rc;
+    if ((rc = s->bufs.alloc(&d_adj, adj.size())) != TB_OK) return rc;
+    HIP_TRY(hipMemcpy(d_aoff, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    if (!adj.empty()) HIP_TRY(hipMemcpy(d_adj, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
+    s->P.adj_off = d_aoff; s->P.adj = d_adj;
+  }
+  s->P.n_slices = s->plan.n_slices; s->P.dirty_words = s->plan.dirty_words; s->P.vext = s->plan.vext; s->P.chg_cap = s->plan.chg_cap;
   if (n_vars) HIP_TRY(hipMemcpy(d_root, root_store, V * sizeof(tb_itv), hipMemcpyHostToDevice));
   if (n_strats) {
     HIP_TRY(hipMemcpy(d_vo, strat_var_order, (size_t)n_strats * 4, hipMemcpyHostToDevice));
@@ -361,8 +455,9 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   }
   if (total_svars) HIP_TRY(hipMemcpy(d_sv, strat_vars, (size_t)total_svars * 4, hipMemcpyHostToDevice));
 
-  if (plan.mem_kind == TB_MEM_GLOBAL) { if ((rc = s->bufs.alloc(&P.g_store, B * V)) != TB_OK) return rc; }
-  if ((rc = s->bufs.alloc(&P.g_snap, B * (size_t)plan.snapshot_levels * V)) != TB_OK) return rc;
+  const size_t VX = (size_t)plan.vext;
+  if (plan.mem_kind == TB_MEM_GLOBAL) { if ((rc = s->bufs.alloc(&P.g_store, B * VX)) != TB_OK) return rc; }
+  if ((rc = s->bufs.alloc(&P.g_snap, B * (size_t)plan.snapshot_levels * VX)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&P.g_best, B * V)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&P.g_dec, B * (size_t)plan.max_depth)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&P.g_stats, B)) != TB_OK) return rc;
@@ -377,7 +472,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   P.subproblems_power = plan.subproblems_power;
   P.has_eps_strategy = s->cfg.has_eps_strategy;
   P.use_fixed_bound = s->cfg.use_fixed_bound; P.fixed_bound = s->cfg.fixed_bound;
-  P.mem_kind = plan.mem_kind; P.snapshot_levels = plan.snapshot_levels; P.max_depth = plan.max_depth;
+  P.mem_kind = plan.mem_kind; P.snapshot_levels = plan.snapshot_levels; P.max_depth = plan.max_depth; P.debug = s->cfg.reserved[0];
   const unsigned long long nsub = 1ull << plan.subproblems_power;
   const unsigned long long world = (unsigned long long)std::max(1, s->cfg.world_size), rank = (unsigned long long)std::max(0, s->cfg.rank);
   // contiguous slices keep the subtree skip `((idx >> r) + 1) << r` local to a GPU (clamped at the slice end)

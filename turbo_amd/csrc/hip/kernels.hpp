@@ -43,7 +43,7 @@ struct alignas(16) BlockShared {
   int cur_strategy, next_unassigned, snap_strategy, snap_next_unassigned;
   int best_bound;  // best objective found by this workgroup (BlockData::best_bound, barebones:116)
   int found, sol, skip, abort;
-  int new_depth, pad0, pad1, pad2;
+  int new_depth, ev_all, chg_count[2];  // event mode: "run every slice" request, change-list fill levels
   unsigned long long sub_idx;
   unsigned long long red_key[MAX_WAVES];
   int red_first[MAX_WAVES];
@@ -71,21 +71,65 @@ struct ThreadCounters {
 
 // One propagator application: load 3 domains, evaluate, write the narrowed bounds.
 // `un` is only meaningful when the sweep it belongs to changed nothing.
-__device__ __forceinline__ void apply(const int4 pr, int2* store, int* bot, bool& changed, bool& un, ThreadCounters& tc) {
-  const Itv X = load_dom(store, pr.y), Y = load_dom(store, pr.z), Z = load_dom(store, pr.w);
-  if (X.lb > X.ub || Y.lb > Y.ub || Z.lb > Z.ub) { st(bot, 1); return; }
-  const Cand c = evaluate(pr.x, X, Y, Z);
-  int w = 0;
-  if (c.xl > X.lb) { raise_lb(store, pr.y, c.xl); ++w; }
-  if (c.xu < X.ub) { lower_ub(store, pr.y, c.xu); ++w; }
-  if (c.yl > Y.lb) { raise_lb(store, pr.z, c.yl); ++w; }
-  if (c.yu < Y.ub) { lower_ub(store, pr.z, c.yu); ++w; }
-  if (c.zl > Z.lb) { raise_lb(store, pr.w, c.zl); ++w; }
-  if (c.zu < Z.ub) { lower_ub(store, pr.w, c.zu); ++w; }
-  if (imax(c.xl, X.lb) > imin(c.xu, X.ub) || imax(c.yl, Y.lb) > imin(c.yu, Y.ub) || imax(c.zl, Z.lb) > imin(c.zu, Z.ub)) st(bot, 1);
-  tc.writes += (unsigned)w;
-  changed |= (w != 0);
-  un |= !c.ent;
+// `act` = the lane holds a propagator (the whole wave calls this: the class test and the write tail are
+// wave-uniform branches, so a sweep over propagators that change nothing -- the common case near the
+// fixpoint -- executes no predicated store at all).
+// Record of an idle lane (slice tail): the cheapest class, three immediates -> no memory access, entailed.
+__device__ __forceinline__ int4 idle_record() { return make_int4(K_LEQ_T, 0, 0, 0); }
+
+// Event mode: a narrowed variable is appended, with the slice that narrowed it, to a change list in LDS; the
+// list is expanded through the variable -> slices adjacency by the whole workgroup between two sweeps
+// (one wave per entry, lanes striding over the adjacency), so a high-degree variable costs one memory
+// latency instead of a serial walk by the lane that happened to narrow it.
+struct EventArgs {        // only read when EVENT
+  int2* list;             // change list being filled: (variable, slice that narrowed it)
+  int* count;
+  int cap;
+  int self;               // slice being evaluated (-1: decision / bound from outside the sweep)
+};
+__device__ __forceinline__ void append_change(const EventArgs& ev, int v) {
+  const int pos = __hip_atomic_fetch_add(ev.count, 1, TB_RLX, TB_WG);
+  if (pos < ev.cap) ev.list[pos] = make_int2(v, ev.self);  // an overflowing list degrades to "run every slice"
+}
+
+template <bool EVENT>
+__device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store, int* bot, bool& changed, bool& un, ThreadCounters& tc, const int dbg = 0,
+                                      const EventArgs ev = EventArgs{nullptr, nullptr, 0, -1}) {
+  const int w0 = pr.x;
+  // three gathers issued back to back, one s_waitcnt (the LDS is ~1 % busy: gathers are cheap, VALU is not)
+  Itv X{0, 1}, Y{0, 1}, Z{0, 1};
+  if (!(dbg & 2)) { X = load_dom(store, pr.y); Y = load_dom(store, pr.z); Z = load_dom(store, pr.w); }
+  Cand c;
+  if (!(dbg & 1)) c = evaluate_packed(w0, X, Y, Z); else c.ent = (pr.y != 0x7fffffff);
+  if (dbg & 4) { un |= act & !c.ent; return; }
+  const bool empty_in = (X.lb > X.ub) | (Y.lb > Y.ub) | (Z.lb > Z.ub);
+  const bool cx = (c.xl > X.lb) | (c.xu < X.ub), cy = (c.yl > Y.lb) | (c.yu < Y.ub), cz = (c.zl > Z.lb) | (c.zu < Z.ub);
+  const bool touched = act & (cx | cy | cz | empty_in);
+  if (__any(touched)) {  // wave-uniform: rare once the sweep is close to the fixpoint
+    if (touched) {
+      const int nxl = imax(c.xl, X.lb), nxu = imin(c.xu, X.ub);
+      const int nyl = imax(c.yl, Y.lb), nyu = imin(c.yu, Y.ub);
+      const int nzl = imax(c.zl, Z.lb), nzu = imin(c.zu, Z.ub);
+      if (empty_in | (nxl > nxu) | (nyl > nyu) | (nzl > nzu)) st(bot, 1);
+      if (!empty_in) {
+        int k = 0;
+        if (nxl != X.lb) { raise_lb(store, pr.y, nxl); ++k; }
+        if (nxu != X.ub) { lower_ub(store, pr.y, nxu); ++k; }
+        if (nyl != Y.lb) { raise_lb(store, pr.z, nyl); ++k; }
+        if (nyu != Y.ub) { lower_ub(store, pr.z, nyu); ++k; }
+        if (nzl != Z.lb) { raise_lb(store, pr.w, nzl); ++k; }
+        if (nzu != Z.ub) { lower_ub(store, pr.w, nzu); ++k; }
+        tc.writes += (unsigned)k;
+        changed |= (k != 0);
+        if (EVENT) {
+          if ((nxl != X.lb) | (nxu != X.ub)) append_change(ev, pr.y);
+          if ((nyl != Y.lb) | (nyu != Y.ub)) append_change(ev, pr.z);
+          if ((nzl != Z.lb) | (nzu != Z.ub)) append_change(ev, pr.w);
+        }
+      }
+    }
+  }
+  un |= act & !c.ent;
 }
 
 // Block-parallel fixpoint of all propagators + entailment test, fused.
@@ -99,28 +143,40 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
   const int n = P.n_props;
   const bool wac1 = P.fixpoint == 1 && n > P.wac1_threshold;
+  const int dbg = P.debug & 0xff, force_sweeps = (P.debug >> 8) & 0xff;  // profiling knobs, 0 in production
   if (tid == 0) { st(&sh.flag[0], 0); st(&sh.unent[0], 0); }
   __syncthreads();
   int it = 0, k = 0;
   for (;;) {
     k = it % 3;
     bool changed = false, un = false;
+    // The bytecode of the next 64-propagator slice is fetched while the current one is evaluated
+    // (software prefetch: the 16-B records come from L2 unless they were staged in LDS).
+    int4 pr_next = idle_record();
+    if (tid < n) pr_next = (dbg & 8) ? make_int4(K_EQ_R | (1 << (16 + K_EQ_R)), tid % P.n_vars, (tid * 7) % P.n_vars, (tid * 13) % P.n_vars) : props[tid];
     if (!wac1) {
-      for (int i = tid; i < n; i += T) apply(props[i], store, &sh.bot, changed, un, tc);
+      for (int base = tid - lane; base < n; base += T) {
+        const int i = base + lane;
+        const bool act = i < n;
+        const int4 pr = pr_next;
+        pr_next = idle_record();
+        if (i + T < n) pr_next = (dbg & 8) ? make_int4(K_EQ_R | (1 << (16 + K_EQ_R)), (i + T) % P.n_vars, (i * 7) % P.n_vars, (i * 13) % P.n_vars) : props[i + T];
+        apply<false>(pr, act, store, &sh.bot, changed, un, tc, dbg);
+      }
     } else {
       // WAC1: a wave iterates its 64 propagators to a local fixpoint before moving on (config.cpp:26,
       // warp_fixpoint at barebones:955; the wave is 64 wide on CDNA).
       for (int base = tid - lane; base < n; base += T) {
         const int i = base + lane;
         const bool act = i < n;
-        int4 pr = make_int4(0, 0, 0, 0);
-        if (act) pr = props[i];
+        const int4 pr = pr_next;
+        pr_next = idle_record();
+        if (i + T < n) pr_next = (dbg & 8) ? make_int4(K_EQ_R | (1 << (16 + K_EQ_R)), (i + T) % P.n_vars, (i * 7) % P.n_vars, (i * 13) % P.n_vars) : props[i + T];
         for (;;) {
           bool ch = false, un_i = false;
-          if (act) apply(pr, store, &sh.bot, ch, un_i, tc);
+          apply<false>(pr, act, store, &sh.bot, ch, un_i, tc, dbg);
           if (lane == 0) tc.deductions += 64;  // barebones:958-960 counts warp iterations x warp width
-          const bool any = __any(ch);
-          if (!any) { un |= un_i; break; }
+          if (!__any(ch)) { un |= un_i; break; }
           changed = true;
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
           if (ld(&sh.bot)) break;
@@ -140,10 +196,137 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     }
     __syncthreads();
     ++it;
+    if (force_sweeps) { if (it >= force_sweeps) break; else continue; }
     if (!ld(&sh.flag[k]) || ld(&sh.bot) || ld(&sh.abort)) break;
   }
   if (!wac1 && tid == 0) tc.deductions += (unsigned long long)it * (unsigned long long)n;  // barebones:934
   all_entailed = !ld(&sh.unent[k]);
+  return it;
+}
+
+// Event-driven WAC1 (tb_config.fixpoint = 2).  Same fixpoint, same wave-local iteration, but a sweep only
+// evaluates the 64-propagator slices that read a variable narrowed in the previous sweep (three rotating
+// dirty bitmaps in LDS, filled through the variable -> slices adjacency on every narrowing).  The first
+// sweep of a node starts from the slices of the decision variable, because backtracking restores the
+// parent's PROPAGATED store from the HBM snapshot stack.  Entailment is kept as one byte per slice, stored
+// right behind the store so that snapshots carry it: a slice that did not run has not changed status.
+// This is the role of FixpointSubsetGPU / entailed-propagator removal in the reference (gpu_dive_and_solve.hpp:334,
+// barebones:984, off by default there), re-thought for wave64 slices instead of a compacted index array.
+struct EventState {
+  unsigned* dirty;        // LDS: one bitmap of `words` words (slices to run in the current sweep)
+  int2* list;             // LDS: 2 x cap change-list entries (double buffered by sweep parity)
+  unsigned char* unent;   // one byte per slice, behind the store (LDS or HBM slab)
+  int words, cap;
+};
+
+// Callers outside a sweep (decisions, objective bound, replay): the change goes to list 0, which the
+// next fixpoint expands before its first sweep.
+__device__ __forceinline__ void note_change(BlockShared& sh, const EventState& es, int v) {
+  const EventArgs ev{es.list, &sh.chg_count[0], es.cap, -1};
+  append_change(ev, v);
+}
+
+__device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
+                                              const EventState& es, ThreadCounters& tc, bool& all_entailed) {
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+  const int n = P.n_props, W = es.words, S = P.n_slices;
+  const bool prof = (P.debug & 0x10000) != 0;
+  if (tid == 0) { st(&sh.flag[0], 0); st(&sh.unent[0], 0); }
+  __syncthreads();
+  int it = 0, k = 0;
+  for (;;) {
+    k = it % 3;
+    const int p = it & 1;
+    long long tp0 = 0;
+    if (tid == 0 && prof) tp0 = wall_clock64();
+    // ---- expansion: change list p -> dirty bitmap (the bitmap is empty here)
+    {
+      const int cnt = ld(&sh.chg_count[p]);
+      const bool all = ld(&sh.ev_all) != 0 || cnt > es.cap;
+      if (all) {
+        for (int i = tid; i < W; i += T) {
+          const int left = S - i * 32;
+          es.dirty[i] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+        }
+        if (tid == 0 && S > 0) st(&sh.flag[k], 1);
+      } else {
+        const int2* list = es.list + p * es.cap;
+        bool marked = false;
+        for (int e = wave; e < cnt; e += nw) {
+          const int2 ent = list[e];  // uniform address: LDS broadcast
+          const int v = __builtin_amdgcn_readfirstlane(ent.x), self = __builtin_amdgcn_readfirstlane(ent.y);
+          const int o0 = P.adj_off[v], o1 = P.adj_off[v + 1];
+          for (int j = o0 + lane; j < o1; j += 64) {
+            const int t = P.adj[j];
+            if (t != self) { (void)__hip_atomic_fetch_or(&es.dirty[t >> 5], 1u << (t & 31), TB_RLX, TB_WG); marked = true; }
+          }
+        }
+        if (__any(marked) && lane == 0) st(&sh.flag[k], 1);
+      }
+      if (tid == 0) {
+        st(&sh.flag[(k + 1) % 3], 0);
+        st(&sh.chg_count[p ^ 1], 0);  // filled by the sweep below, last read two barriers ago
+        if ((it & 255) == 255 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) st(&sh.ev_all, 0);
+    if (!ld(&sh.flag[k]) || ld(&sh.abort)) break;  // nothing left to run: fixpoint
+    long long tp1 = 0;
+    if (tid == 0 && prof) { tp1 = wall_clock64(); sh.bs.timers[TB_T_WAIT_CPU] += tp1 - tp0; }  // profiling: expansion
+    // ---- sweep over the dirty slices; narrowed variables go to list p^1
+    const EventArgs evb{es.list + (p ^ 1) * es.cap, &sh.chg_count[p ^ 1], es.cap, -1};
+    // Dirty slices are CLAIMED dynamically (atomic and on the bitmap word), so a cluster of dirty slices is
+    // spread over all waves instead of serialising on its static owners.  Each wave starts at its own word
+    // and prefers its own bit position to keep claim collisions rare.
+    int wi = (wave * W) / nw;
+    const int rot = (wave * 32) / nw;
+    for (int q = 0; q < W; ++q, wi = (wi + 1 == W) ? 0 : wi + 1) {
+      for (;;) {
+        const unsigned bits = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&es.dirty[wi], TB_RLX, TB_WG));
+        if (bits == 0) break;
+        const unsigned rotd = rot ? ((bits >> rot) | (bits << (32 - rot))) : bits;
+        const int bpos = (__builtin_ctz(rotd) + rot) & 31;
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_and(&es.dirty[wi], ~(1u << bpos), TB_RLX, TB_WG);
+        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+        if (!((old >> bpos) & 1u)) continue;  // another wave claimed it first
+        const int s = wi * 32 + bpos;
+        const int i = s * 64 + lane;
+        const bool act = i < n;
+        int4 pr = idle_record();
+        if (act) pr = props[i];
+        EventArgs ev = evb;
+        ev.self = s;
+        for (;;) {
+          bool ch = false, un_i = false;
+          apply<true>(pr, act, store, &sh.bot, ch, un_i, tc, 0, ev);
+          if (lane == 0) tc.deductions += 64;
+          if (!__any(ch)) {
+            const bool any_un = __any(un_i);
+            if (lane == 0) es.unent[s] = any_un ? 1 : 0;
+            break;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          if (ld(&sh.bot)) break;
+        }
+      }
+    }
+    long long tp2 = 0;
+    if (tid == 0 && prof) { tp2 = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += tp2 - tp1; }  // profiling: own slice work
+    __syncthreads();
+    if (tid == 0 && prof) sh.bs.timers[TB_T_TRANSFER_GPU2CPU] += wall_clock64() - tp2;  // profiling: waiting for the slowest wave
+    ++it;
+    if (ld(&sh.bot)) break;
+  }
+  // leave the bitmap and both lists empty for the next node, and reduce the per-slice entailment bytes
+  for (int i = tid; i < W; i += T) es.dirty[i] = 0;
+  if (tid == 0) { st(&sh.chg_count[0], 0); st(&sh.chg_count[1], 0); st(&sh.ev_all, 0); }
+  bool un = false;
+  for (int s = tid; s < S; s += T) un |= es.unent[s] != 0;
+  if (__any(un) && lane == 0) st(&sh.unent[0], 1);
+  __syncthreads();
+  all_entailed = !ld(&sh.unent[0]);
   return it;
 }
 
@@ -169,11 +352,18 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 }
 
 // Thread 0 only: VStore::embed of one interval (decisions, objective bound).
-__device__ __forceinline__ void embed0(int2* store, int* bot, int v, int lb, int ub) {
+__device__ __forceinline__ bool embed0(int2* store, int* bot, int v, int lb, int ub) {
   Itv d = load_dom(store, v);
-  if (lb > d.lb) { raise_lb(store, v, lb); d.lb = lb; }
-  if (ub < d.ub) { lower_ub(store, v, ub); d.ub = ub; }
+  bool changed = false;
+  if (lb > d.lb) { raise_lb(store, v, lb); d.lb = lb; changed = true; }
+  if (ub < d.ub) { lower_ub(store, v, ub); d.ub = ub; changed = true; }
   if (d.lb > d.ub) st(bot, 1);
+  return changed;
+}
+// embed0 + event bookkeeping: the slices reading v must run in the first sweep of the next fixpoint
+__device__ __forceinline__ void embed0_mark(const DevProblem& P, BlockShared& sh, const EventState& es, int2* store, int* bot, int v, int lb, int ub) {
+  const bool changed = embed0(store, bot, v, lb, ub);
+  if (P.fixpoint == 2 && changed) note_change(sh, es, v);
 }
 
 // Key to MINIMISE for each variable order (barebones:193-221); ties resolve to the lowest index
@@ -266,7 +456,7 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
 
 struct NodeTimers { long long t_last; };
 
-__device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
+__device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
                                                int2* best_store, Mailbox* mbox, ThreadCounters& tc,
                                                long long& t_mark, long long t_start) {
   const int tid = threadIdx.x;
@@ -274,7 +464,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
   long long t0 = 0;
   if (tid == 0) { t0 = wall_clock64(); bs.timers[TB_T_SEARCH] += t0 - t_mark; }
   bool all_entailed = false;
-  const int iters = fixpoint(P, sh, store, props, tc, all_entailed);
+  const int iters = P.fixpoint == 2 ? fixpoint_event(P, sh, store, props, es, tc, all_entailed) : fixpoint(P, sh, store, props, tc, all_entailed);
   const bool aborted = ld(&sh.abort) != 0;
   const bool failed = !aborted && ld(&sh.bot) != 0;
   if (aborted) all_entailed = false;
@@ -351,14 +541,24 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, b = blockIdx.x, V = P.n_vars;
-  int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : P.g_store + (size_t)b * V;
+  // LDS: [control block][store: vext x int2 (STORE/TCN_SHARED)][dirty bitmaps: 3 x words][bytecodes (TCN_SHARED)]
+  const int VX = P.vext;
+  const size_t store_bytes = MEM >= TB_MEM_STORE_SHARED ? (((size_t)VX * 8 + 15) / 16) * 16 : 0;
+  const size_t dirty_bytes = (((size_t)P.dirty_words * 4 + 15) / 16) * 16 + (size_t)P.chg_cap * 16;
+  int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : P.g_store + (size_t)b * VX;
+  EventState es;
+  es.dirty = reinterpret_cast<unsigned*>(smem + SH_BYTES + store_bytes);
+  es.list = reinterpret_cast<int2*>(smem + SH_BYTES + store_bytes + (((size_t)P.dirty_words * 4 + 15) / 16) * 16);
+  es.unent = reinterpret_cast<unsigned char*>(store + V);
+  es.words = P.dirty_words; es.cap = P.chg_cap;
   const int4* props = P.props;
   if (MEM == TB_MEM_TCN_SHARED) {
-    int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + (((size_t)V * 8 + 15) / 16) * 16);
+    int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + store_bytes + dirty_bytes);
     for (int i = tid; i < P.n_props; i += blockDim.x) lprops[i] = P.props[i];
     props = lprops;
   }
-  int2* snap = P.g_snap + (size_t)b * P.snapshot_levels * V;
+  for (int i = tid; i < P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
+  int2* snap = P.g_snap + (size_t)b * P.snapshot_levels * VX;
   int2* best_store = P.g_best + (size_t)b * V;
   Decision* dec = P.g_dec + (size_t)b * P.max_depth;
   BlockStats& bs = sh.bs;
@@ -370,7 +570,7 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
     bs.eps_solved = bs.eps_skipped = bs.store_writes = 0;
     bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
     sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0;
-    sh.abort = 0; sh.new_depth = 0;
+    sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0;
     sh.sub_idx = __hip_atomic_fetch_add(&P.ctrl->next_subproblem, 1ull, TB_RLX, TB_AGENT);
     t_start = t_mark = wall_clock64();
   }
@@ -380,6 +580,7 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
   while (sh.sub_idx < P.sub_hi && !sh.stop) {
     // C. restore the root
     copy_store(store, P.root_store, V);
+    if (P.fixpoint == 2 && tid == 0) sh.ev_all = 1;  // the root store is not a fixpoint: every slice runs once
     long long t_dive = 0;
     if (tid == 0) {
       sh.cur_strategy = 0; sh.next_unassigned = 0; sh.depth = 0; sh.bot = 0;
@@ -390,7 +591,7 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
     __syncthreads();
     // D. dive: no objective bound while diving (gpu_dive_and_solve.hpp:370-372)
     while (sh.remaining > 0 && !sh.leaf && !sh.stop) {
-      propagate_node(P, sh, store, props, best_store, mbox, tc, t_mark, t_start);
+      propagate_node(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
       if (!sh.leaf && !sh.stop) {
         split(P, sh, dec, store);
         if (tid == 0) {
@@ -399,7 +600,7 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
             --sh.remaining;
             --sh.depth;  // decisions are not recorded while diving
             const int bit = (int)((sh.sub_idx >> sh.remaining) & 1ull);
-            embed0(store, &sh.bot, dec[0].var, dec[0].child[bit].x, dec[0].child[bit].y);
+            embed0_mark(P, sh, es, store, &sh.bot, dec[0].var, dec[0].child[bit].x, dec[0].child[bit].y);
           }
         }
       }
@@ -421,7 +622,7 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
       while (!sh.stop) {
         // I. tighten the objective with the incumbent (barebones:756-771)
         if (tid == 0 && P.obj_var >= 0) {
-          if (P.use_fixed_bound) embed0(store, &sh.bot, P.obj_var, NINF, P.fixed_bound);
+          if (P.use_fixed_bound) embed0_mark(P, sh, es, store, &sh.bot, P.obj_var, NINF, P.fixed_bound);
           else {
             int g = __hip_atomic_load(&P.ctrl->best_bound, TB_RLX, TB_AGENT);
             const int f = __hip_atomic_load(&P.ctrl->foreign_bound, TB_RLX, TB_AGENT);
@@ -429,19 +630,19 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
             g = sh.best_bound < g ? sh.best_bound : g;
             if (g != PINF) {
               if (g == NINF) { sh.stop = 1; __hip_atomic_store(&P.ctrl->gpu_stop, 1, TB_RLX, TB_AGENT); }  // unbounded objective
-              else embed0(store, &sh.bot, P.obj_var, NINF, g - 1);
+              else embed0_mark(P, sh, es, store, &sh.bot, P.obj_var, NINF, g - 1);
             }
           }
         }
         __syncthreads();
         if (sh.stop) break;
         // II. propagate
-        propagate_node(P, sh, store, props, best_store, mbox, tc, t_mark, t_start);
+        propagate_node(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
         if (sh.stop) break;
         // III. branch
         if (!sh.leaf) {
           const int d0 = sh.depth;
-          if (d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * V, store, V);  // d0 == 0: barebones:785-791
+          if (d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * VX, store, VX);  // d0 == 0: barebones:785-791
           if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
           __syncthreads();
           split(P, sh, dec, store);
@@ -451,7 +652,7 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
             else {
               Decision& dd = dec[sh.depth - 1];
               const int c = ++dd.cur;
-              embed0(store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+              embed0_mark(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
             }
           }
           __syncthreads();
@@ -465,7 +666,7 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
           const int depth = sh.new_depth;
           if (depth == -1) break;
           const int lvl = (depth - 1) < (P.snapshot_levels - 1) ? (depth - 1) : (P.snapshot_levels - 1);
-          copy_store(store, snap + (size_t)lvl * V, V);
+          copy_store(store, snap + (size_t)lvl * VX, VX);
           if (tid == 0) { sh.bot = 0; sh.depth = depth; }
           __syncthreads();
           // re-apply decisions[lvl .. depth-2].current(): distinct decisions may hit the same variable, the
@@ -475,12 +676,13 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
             const int2 ch = di.child[di.cur];
             raise_lb(store, di.var, ch.x);
             lower_ub(store, di.var, ch.y);
+            if (P.fixpoint == 2) note_change(sh, es, di.var);
           }
           __syncthreads();
           if (tid == 0) {
             Decision& dd = dec[depth - 1];
             const int c = ++dd.cur;
-            embed0(store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+            embed0_mark(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
             sh.cur_strategy = sh.snap_strategy;
             sh.next_unassigned = sh.snap_next_unassigned;
           }
@@ -536,15 +738,25 @@ __global__ void __launch_bounds__(TMAX) propagate_kernel(DevProblem P, int2* sto
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, V = P.n_vars;
+  const int VX = P.vext;
+  const size_t store_bytes = MEM >= TB_MEM_STORE_SHARED ? (((size_t)VX * 8 + 15) / 16) * 16 : 0;
+  const size_t dirty_bytes = (((size_t)P.dirty_words * 4 + 15) / 16) * 16 + (size_t)P.chg_cap * 16;
+  EventState es;
+  es.dirty = reinterpret_cast<unsigned*>(smem + SH_BYTES + store_bytes);
+  es.list = reinterpret_cast<int2*>(smem + SH_BYTES + store_bytes + (((size_t)P.dirty_words * 4 + 15) / 16) * 16);
+  es.words = P.dirty_words; es.cap = P.chg_cap;
+  for (int i = tid; i < P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
   const int4* props = P.props;
   if (MEM == TB_MEM_TCN_SHARED) {
-    int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + (((size_t)V * 8 + 15) / 16) * 16);
+    int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + store_bytes + dirty_bytes);
     for (int i = tid; i < P.n_props; i += blockDim.x) lprops[i] = P.props[i];
     props = lprops;
   }
   for (int s = blockIdx.x; s < n_stores; s += gridDim.x) {
     int2* gstore = stores + (size_t)s * V;
+    // GLOBAL mode works in place on the caller's store; its entailment bytes go to a per-workgroup scratch slab
     int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : gstore;
+    es.unent = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<unsigned char*>(store + V) : reinterpret_cast<unsigned char*>(P.g_store + (size_t)blockIdx.x * VX + V);
     ThreadCounters tc;
     if (tid == 0) { sh.bot = 0; sh.abort = 0; sh.red_key[0] = 0; sh.red_key[1] = 0; }
     __syncthreads();
@@ -553,7 +765,8 @@ __global__ void __launch_bounds__(TMAX) propagate_kernel(DevProblem P, int2* sto
     __syncthreads();
     bool all_entailed = false;
     int iters = 0;
-    if (!ld(&sh.bot)) iters = fixpoint(P, sh, store, props, tc, all_entailed);
+    if (P.fixpoint == 2) { if (tid == 0) { sh.ev_all = 1; sh.chg_count[0] = 0; sh.chg_count[1] = 0; } __syncthreads(); }
+    if (!ld(&sh.bot)) iters = P.fixpoint == 2 ? fixpoint_event(P, sh, store, props, es, tc, all_entailed) : fixpoint(P, sh, store, props, tc, all_entailed);
     if (MEM >= TB_MEM_STORE_SHARED) copy_store(gstore, store, V);
     unsigned long long w = tc.writes, d = tc.deductions;
     for (int off = 32; off > 0; off >>= 1) { w += __shfl_xor(w, off, 64); d += __shfl_xor(d, off, 64); }

@@ -7,9 +7,15 @@
 // oracle/oracle.c -- the parity tests compare fixpoints, which are order independent because every
 // rule below is monotone and contracting.
 //
-// CDNA4 notes: integer VALU only (no MFMA: nothing here is a contraction).  A propagator is evaluated
-// in two phases so that a wave executing mixed operators diverges only in the cheap "compute the
-// candidate bounds" switch and reconverges for the memory phase (LDS atomics / change detection).
+// CDNA4 notes: integer VALU only (no MFMA: nothing here is a contraction).  The sweep is VALU-issue
+// bound (first profile: 134 VALU + 95 SALU per wave-propagation, LDS 1 % busy), so the rules are written
+// to minimise VALU instructions:
+//   * the shim rewrites each bytecode into a packed record whose word0 carries a pack-time CLASS and the
+//     set of classes present in its 64-record slice; the slice set is read into an SGPR, so every class
+//     body sits behind a SCALAR branch -- a wave pays only for the classes it contains and there is no
+//     exec-mask manipulation; inside a body all lanes compute and the lanes of that class keep the result;
+//   * predicates are combined with logical operators on already computed values (they become s_and/s_or on
+//     lane masks, not VALU), values with v_cndmask, sums with v_add_i32/v_sub_i32 clamp (saturating).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -33,21 +39,18 @@ struct Cand {
 __device__ __forceinline__ bool is_inf(int a) { return a == NINF || a == PINF; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int sel(bool c, int a, int b) { return c ? a : b; }
 __device__ __forceinline__ int sat_add(int a, int b) { return __builtin_elementwise_add_sat(a, b); }  // v_add_i32 clamp
+__device__ __forceinline__ int sat_sub(int a, int b) { return __builtin_elementwise_sub_sat(a, b); }  // v_sub_i32 clamp
 __device__ __forceinline__ int neg_ext(int a) { return a == NINF ? PINF : (a == PINF ? NINF : -a); }
 __device__ __forceinline__ int clamp64(long long v) { return v >= (long long)PINF ? PINF : (v <= (long long)NINF ? NINF : (int)v); }
 
-// lower / upper bound of a sum from the two lower / upper bounds (+-inf absorbing, saturating)
-__device__ __forceinline__ int add_lo(int a, int b) {
-  int r = sat_add(a, b);
-  r = (a == PINF || b == PINF) ? PINF : r;
-  return (a == NINF || b == NINF) ? NINF : r;
-}
-__device__ __forceinline__ int add_hi(int a, int b) {
-  int r = sat_add(a, b);
-  r = (a == NINF || b == NINF) ? NINF : r;
-  return (a == PINF || b == PINF) ? PINF : r;
-}
+// Bounds of sums / differences: an infinite bound on the side that matters absorbs, the rest saturates.
+__device__ __forceinline__ int add_lo(int a, int b) { return sel(a == NINF || b == NINF, NINF, sat_add(a, b)); }  // lb(A+B)
+__device__ __forceinline__ int add_hi(int a, int b) { return sel(a == PINF || b == PINF, PINF, sat_add(a, b)); }  // ub(A+B)
+__device__ __forceinline__ int sub_lo(int a, int b) { return sel(a == NINF || b == PINF, NINF, sat_sub(a, b)); }  // lb(A-B) from lb(A), ub(B)
+__device__ __forceinline__ int sub_hi(int a, int b) { return sel(a == PINF || b == NINF, PINF, sat_sub(a, b)); }  // ub(A-B) from ub(A), lb(B)
+
 __device__ __forceinline__ int mul_ext(int a, int b) {
   if (a == 0 || b == 0) return 0;
   if (is_inf(a) || is_inf(b)) return ((a < 0) != (b < 0)) ? NINF : PINF;
@@ -65,47 +68,36 @@ __device__ __forceinline__ int div_ceil(int a, int b) {
 __device__ __forceinline__ long long lmin(long long a, long long b) { return a < b ? a : b; }
 __device__ __forceinline__ long long lmax(long long a, long long b) { return a > b ? a : b; }
 __device__ __forceinline__ long long labs64(long long a) { return a < 0 ? -a : a; }
-
 __device__ __forceinline__ void meet(int& l, int& u, int nl, int nu) { l = imax(l, nl); u = imin(u, nu); }
 
-// Phase 1: candidate bounds + entailment, from the loaded domains only (no memory access).
-__device__ __forceinline__ Cand evaluate(int op, const Itv X, const Itv Y, const Itv Z) {
+// The three operators with divisions (rare; divergent code is acceptable here).
+__device__ __forceinline__ Cand evaluate_heavy(int op, const Itv X, const Itv Y, const Itv Z) {
   Cand c;
-  switch (op) {
-    case OP_ADD: {
-      c.xl = add_lo(Y.lb, Z.lb); c.xu = add_hi(Y.ub, Z.ub);
-      c.yl = add_lo(X.lb, neg_ext(Z.ub)); c.yu = add_hi(X.ub, neg_ext(Z.lb));
-      c.zl = add_lo(X.lb, neg_ext(Y.ub)); c.zu = add_hi(X.ub, neg_ext(Y.lb));
-      break;
+  if (op == OP_MUL) {
+    int c0 = mul_ext(Y.lb, Z.lb), c1 = mul_ext(Y.lb, Z.ub), c2 = mul_ext(Y.ub, Z.lb), c3 = mul_ext(Y.ub, Z.ub);
+    c.xl = imin(imin(c0, c1), imin(c2, c3)); c.xu = imax(imax(c0, c1), imax(c2, c3));
+    if (X.lb > 0 || X.ub < 0) {  // a non-zero product has non-zero factors
+      if (Y.lb == 0) c.yl = 1;
+      if (Y.ub == 0) c.yu = -1;
+      if (Z.lb == 0) c.zl = 1;
+      if (Z.ub == 0) c.zu = -1;
     }
-    case OP_MUL: {
-      int c0 = mul_ext(Y.lb, Z.lb), c1 = mul_ext(Y.lb, Z.ub), c2 = mul_ext(Y.ub, Z.lb), c3 = mul_ext(Y.ub, Z.ub);
-      c.xl = imin(imin(c0, c1), imin(c2, c3)); c.xu = imax(imax(c0, c1), imax(c2, c3));
-      if (X.lb > 0 || X.ub < 0) {  // a non-zero product has non-zero factors
-        if (Y.lb == 0) c.yl = 1;
-        if (Y.ub == 0) c.yu = -1;
-        if (Z.lb == 0) c.zl = 1;
-        if (Z.ub == 0) c.zu = -1;
-      }
-      bool x_fin = !is_inf(X.lb) && !is_inf(X.ub);
-      if (x_fin && (Z.lb > 0 || Z.ub < 0) && !is_inf(Z.lb) && !is_inf(Z.ub)) {
-        int lo = imin(imin(div_ceil(X.lb, Z.lb), div_ceil(X.lb, Z.ub)), imin(div_ceil(X.ub, Z.lb), div_ceil(X.ub, Z.ub)));
-        int hi = imax(imax(div_floor(X.lb, Z.lb), div_floor(X.lb, Z.ub)), imax(div_floor(X.ub, Z.lb), div_floor(X.ub, Z.ub)));
-        meet(c.yl, c.yu, lo, hi);
-      }
-      if (x_fin && (Y.lb > 0 || Y.ub < 0) && !is_inf(Y.lb) && !is_inf(Y.ub)) {
-        int lo = imin(imin(div_ceil(X.lb, Y.lb), div_ceil(X.lb, Y.ub)), imin(div_ceil(X.ub, Y.lb), div_ceil(X.ub, Y.ub)));
-        int hi = imax(imax(div_floor(X.lb, Y.lb), div_floor(X.lb, Y.ub)), imax(div_floor(X.ub, Y.lb), div_floor(X.ub, Y.ub)));
-        meet(c.zl, c.zu, lo, hi);
-      }
-      break;
+    bool x_fin = !is_inf(X.lb) && !is_inf(X.ub);
+    if (x_fin && (Z.lb > 0 || Z.ub < 0) && !is_inf(Z.lb) && !is_inf(Z.ub)) {
+      int lo = imin(imin(div_ceil(X.lb, Z.lb), div_ceil(X.lb, Z.ub)), imin(div_ceil(X.ub, Z.lb), div_ceil(X.ub, Z.ub)));
+      int hi = imax(imax(div_floor(X.lb, Z.lb), div_floor(X.lb, Z.ub)), imax(div_floor(X.ub, Z.lb), div_floor(X.ub, Z.ub)));
+      meet(c.yl, c.yu, lo, hi);
     }
-    case OP_TDIV:
-    case OP_TMOD: {
-      int zl = Z.lb, zu = Z.ub;  // the divisor is never 0
-      if (zl == 0) { zl = 1; c.zl = 1; }
-      if (zu == 0) { zu = -1; c.zu = -1; }
-      if (zl > zu) break;
+    if (x_fin && (Y.lb > 0 || Y.ub < 0) && !is_inf(Y.lb) && !is_inf(Y.ub)) {
+      int lo = imin(imin(div_ceil(X.lb, Y.lb), div_ceil(X.lb, Y.ub)), imin(div_ceil(X.ub, Y.lb), div_ceil(X.ub, Y.ub)));
+      int hi = imax(imax(div_floor(X.lb, Y.lb), div_floor(X.lb, Y.ub)), imax(div_floor(X.ub, Y.lb), div_floor(X.ub, Y.ub)));
+      meet(c.zl, c.zu, lo, hi);
+    }
+  } else {  // OP_TDIV, OP_TMOD
+    int zl = Z.lb, zu = Z.ub;  // the divisor is never 0
+    if (zl == 0) { zl = 1; c.zl = 1; }
+    if (zu == 0) { zu = -1; c.zu = -1; }
+    if (zl <= zu) {
       bool z_fin = !is_inf(zl) && !is_inf(zu);
       bool y_fin = !is_inf(Y.lb) && !is_inf(Y.ub);
       bool z_nz = (zl > 0 || zu < 0);
@@ -129,72 +121,107 @@ __device__ __forceinline__ Cand evaluate(int op, const Itv X, const Itv Y, const
         else { c.xl = neg_ext(m); c.xu = m; }
         if (y_fin && Y.lb == Y.ub && z_fin && zl == zu) { int r = Y.lb % zl; meet(c.xl, c.xu, r, r); }
       }
-      break;
     }
-    case OP_MIN: {
-      c.xl = imin(Y.lb, Z.lb); c.xu = imin(Y.ub, Z.ub);
-      c.yl = X.lb; c.zl = X.lb;
-      if (Y.lb > X.ub) c.zu = X.ub;
-      if (Z.lb > X.ub) c.yu = X.ub;
-      break;
-    }
-    case OP_MAX: {
-      c.xl = imax(Y.lb, Z.lb); c.xu = imax(Y.ub, Z.ub);
-      c.yu = X.ub; c.zu = X.ub;
-      if (Y.ub < X.lb) c.zl = X.lb;
-      if (Z.ub < X.lb) c.yl = X.lb;
-      break;
-    }
-    case OP_EQ: {
-      bool disjoint = Y.ub < Z.lb || Y.lb > Z.ub;
-      bool same = Y.lb == Y.ub && Z.lb == Z.ub && Y.lb == Z.lb;
-      if (X.lb >= 1) {
-        c.yl = Z.lb; c.yu = Z.ub; c.zl = Y.lb; c.zu = Y.ub;
-        c.ent = same;
-      } else if (X.ub <= 0) {
-        if (Y.lb == Y.ub) {
-          if (Z.lb == Y.lb) c.zl = add_lo(Y.lb, 1);
-          if (Z.ub == Y.lb) c.zu = add_hi(Y.lb, -1);
-        }
-        if (Z.lb == Z.ub) {
-          if (Y.lb == Z.lb) c.yl = add_lo(Z.lb, 1);
-          if (Y.ub == Z.lb) c.yu = add_hi(Z.lb, -1);
-        }
-        c.ent = disjoint;
-      } else {
-        if (disjoint) c.xu = 0;
-        else if (same) c.xl = 1;
-      }
-      return c;
-    }
-    case OP_LEQ: {
-      if (X.lb >= 1) {
-        c.yu = Z.ub; c.zl = Y.lb;
-        c.ent = Y.ub <= Z.lb;
-      } else if (X.ub <= 0) {
-        c.yl = add_lo(Z.lb, 1); c.zu = add_hi(Y.ub, -1);
-        c.ent = Y.lb > Z.ub;
-      } else {
-        if (Y.ub <= Z.lb) c.xl = 1;
-        else if (Y.lb > Z.ub) c.xu = 0;
-      }
-      return c;
-    }
-    default: break;
   }
-  // arithmetic operators: entailed iff all three are assigned and the relation holds
+  // entailed iff all three are assigned (finite) and the relation holds
   if (X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub && !is_inf(X.lb) && !is_inf(Y.lb) && !is_inf(Z.lb)) {
     long long x = X.lb, y = Y.lb, z = Z.lb;
-    switch (op) {
-      case OP_ADD: c.ent = (x == y + z); break;
-      case OP_MUL: c.ent = (x == y * z); break;
-      case OP_TDIV: c.ent = (z != 0 && x == (long long)(Y.lb / (Z.lb == 0 ? 1 : Z.lb))); break;
-      case OP_TMOD: c.ent = (z != 0 && x == (long long)(Y.lb % (Z.lb == 0 ? 1 : Z.lb))); break;
-      case OP_MIN: c.ent = (x == (y < z ? y : z)); break;
-      case OP_MAX: c.ent = (x == (y > z ? y : z)); break;
-      default: break;
+    if (op == OP_MUL) c.ent = (x == y * z);
+    else if (op == OP_TDIV) c.ent = (z != 0 && x == (long long)(Y.lb / (Z.lb == 0 ? 1 : Z.lb)));
+    else c.ent = (z != 0 && x == (long long)(Y.lb % (Z.lb == 0 ? 1 : Z.lb)));
+  }
+  return c;
+}
+
+// ---- packed records -----------------------------------------------------------------------------------
+// word0 = class | original op << 12 | (set of classes present in the 64-record slice) << 16 ; words 1-3 = x,y,z.
+// A comparison whose truth variable is a constant of the root store (TCN has no constants, only singleton
+// variables: common_solving.hpp:743-771) gets its own class: `y <= z`, `y > z`, `y = z`, `y != z`.
+
+enum Class : int {
+  K_HEAVY = 0,  // MUL, TDIV, TMOD
+  K_ADD = 1, K_MIN = 2, K_MAX = 3,
+  K_EQ_R = 4, K_LEQ_R = 5,  // reified: x is a variable
+  K_EQ_T = 6, K_EQ_F = 7,   // x is the constant true / false: y = z, y != z
+  K_LEQ_T = 8, K_LEQ_F = 9  // y <= z, y > z
+};
+
+__host__ __device__ inline int class_of(int op, bool x_const, int x_value) {
+  switch (op) {
+    case OP_ADD: return K_ADD;
+    case OP_MIN: return K_MIN;
+    case OP_MAX: return K_MAX;
+    case OP_EQ: return x_const ? (x_value >= 1 ? K_EQ_T : K_EQ_F) : K_EQ_R;
+    case OP_LEQ: return x_const ? (x_value >= 1 ? K_LEQ_T : K_LEQ_F) : K_LEQ_R;
+    default: return K_HEAVY;
+  }
+}
+
+__device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y, const Itv Z) {
+  Cand c;
+  const int cls = w0 & 0xff;
+  const int present = __builtin_amdgcn_readfirstlane(w0) >> 16;
+  bool ent = false;
+  // predicates shared by the comparison classes
+  const bool xt = X.lb >= 1, xf = X.ub <= 0;
+  if (present & ((1 << K_LEQ_T) | (1 << K_LEQ_F) | (1 << K_LEQ_R))) {
+    // x = (y <= z); T/F: x is a constant of that value
+    const bool t = cls == K_LEQ_T || (cls == K_LEQ_R && xt);
+    const bool f = cls == K_LEQ_F || (cls == K_LEQ_R && xf);
+    const bool u = cls == K_LEQ_R && !xt && !xf;
+    const bool le = Y.ub <= Z.lb, gt = Y.lb > Z.ub;
+    c.xl = sel(u && le, 1, c.xl);
+    c.xu = sel(u && gt, 0, c.xu);
+    c.yu = sel(t, Z.ub, c.yu);
+    c.zl = sel(t, Y.lb, c.zl);
+    c.yl = sel(f, add_lo(Z.lb, 1), c.yl);
+    c.zu = sel(f, add_hi(Y.ub, -1), c.zu);
+    ent = (t && le) || (f && gt);
+  }
+  if (present & ((1 << K_EQ_T) | (1 << K_EQ_F) | (1 << K_EQ_R))) {
+    // x = (y = z)
+    const bool t = cls == K_EQ_T || (cls == K_EQ_R && xt);
+    const bool f = cls == K_EQ_F || (cls == K_EQ_R && xf);
+    const bool u = cls == K_EQ_R && !xt && !xf;
+    const bool ys = Y.lb == Y.ub, zs = Z.lb == Z.ub;
+    const bool disjoint = Y.ub < Z.lb || Y.lb > Z.ub;
+    const bool same = ys && zs && Y.lb == Z.lb;
+    const bool fy = f && ys, fz = f && zs;
+    c.xl = sel(u && same, 1, c.xl);
+    c.xu = sel(u && disjoint, 0, c.xu);
+    c.yl = sel(t, Z.lb, sel(fz && Y.lb == Z.lb, sat_add(Z.lb, 1), c.yl));
+    c.yu = sel(t, Z.ub, sel(fz && Y.ub == Z.lb, sat_sub(Z.lb, 1), c.yu));
+    c.zl = sel(t, Y.lb, sel(fy && Z.lb == Y.lb, sat_add(Y.lb, 1), c.zl));
+    c.zu = sel(t, Y.ub, sel(fy && Z.ub == Y.lb, sat_sub(Y.lb, 1), c.zu));
+    ent = ent || (t && same) || (f && disjoint);
+  }
+  if (present & ((1 << K_ADD) | (1 << K_MIN) | (1 << K_MAX))) {
+    const bool ka = cls == K_ADD, kmin = cls == K_MIN, kmax = cls == K_MAX;
+    const bool fixed = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub;
+    if (present & (1 << K_ADD)) {
+      c.xl = sel(ka, add_lo(Y.lb, Z.lb), c.xl); c.xu = sel(ka, add_hi(Y.ub, Z.ub), c.xu);
+      c.yl = sel(ka, sub_lo(X.lb, Z.ub), c.yl); c.yu = sel(ka, sub_hi(X.ub, Z.lb), c.yu);
+      c.zl = sel(ka, sub_lo(X.lb, Y.ub), c.zl); c.zu = sel(ka, sub_hi(X.ub, Y.lb), c.zu);
+      ent = ent || (ka && fixed && (long long)X.lb == (long long)Y.lb + (long long)Z.lb);
+    }
+    if (present & ((1 << K_MIN) | (1 << K_MAX))) {
+      const int mnl = imin(Y.lb, Z.lb), mnu = imin(Y.ub, Z.ub), mxl = imax(Y.lb, Z.lb), mxu = imax(Y.ub, Z.ub);
+      c.xl = sel(kmin, mnl, sel(kmax, mxl, c.xl));
+      c.xu = sel(kmin, mnu, sel(kmax, mxu, c.xu));
+      c.yl = sel(kmin || (kmax && Z.ub < X.lb), X.lb, c.yl);
+      c.zl = sel(kmin || (kmax && Y.ub < X.lb), X.lb, c.zl);
+      c.yu = sel(kmax || (kmin && Z.lb > X.ub), X.ub, c.yu);
+      c.zu = sel(kmax || (kmin && Y.lb > X.ub), X.ub, c.zu);
+      ent = ent || (fixed && ((kmin && X.lb == mnl) || (kmax && X.lb == mxl)));
     }
   }
+  if (present & (1 << K_HEAVY)) {
+    if (cls == K_HEAVY) {
+      c = evaluate_heavy((w0 >> 12) & 0xf, X, Y, Z);
+      ent = c.ent;
+    }
+  }
+  c.ent = ent;
   return c;
 }
 
