@@ -27,6 +27,7 @@ WORKLOADS = {
     "wordpress7_500": ("example_wordpress7_500.fzn", 3000),
     "accap_a3": ("accap_a3.fzn", 4000),
     "trains15": ("trains15.fzn", 2000),
+    "synthetic": ("synthetic 100k x 500k (seed 42)", 40),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_PROPAGATION = 40  # 16 B bytecode + 3 x 8 B domains; + 8 B per narrowed bound written
@@ -51,9 +52,12 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="wordpress7_500", choices=sorted(WORKLOADS))
     ap.add_argument("--cutnodes", type=int, default=0, help="node budget per workgroup and step (0 = workload default)")
-    ap.add_argument("--fixpoint", default="wac1", choices=["ac1", "wac1"])
+    ap.add_argument("--fixpoint", default="wac1", choices=["ac1", "wac1", "event"])
+    ap.add_argument("--event-steps", type=int, default=2, help="extra steps in the event-driven fixpoint mode, reported beside the headline (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="testing aid: gloo lets two ranks share one GPU")
+    ap.add_argument("--share-device", action="store_true", help="testing aid: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,26 +70,35 @@ def main() -> int:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible and the engine has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    tdev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL over xGMI
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)  # "nccl" is RCCL over xGMI
 
     fzn, default_cut = WORKLOADS[args.workload]
     cut = args.cutnodes or default_cut
-    tcn = frontend.load_fzn(os.path.join(ROOT, "benchmarks", fzn))
-    cfg = capi.make_config(fixpoint=1 if args.fixpoint == "wac1" else 0, stop_after_n_nodes=cut, timeout_ms=600000,
+    if args.workload == "synthetic":
+        from turbo_amd.synth import make_synthetic
+        tcn = make_synthetic(100_000, 500_000, seed=42)
+    else:
+        tcn = frontend.load_fzn(os.path.join(ROOT, "benchmarks", fzn))
+    fp_code = {"ac1": 0, "wac1": 1, "event": 2}
+    cfg = capi.make_config(fixpoint=fp_code[args.fixpoint], stop_after_n_nodes=cut, timeout_ms=600000,
                            device=local_rank, rank=rank, world_size=world)
     session = capi.Session(tcn, cfg)  # inputs uploaded to HBM here, outside the timed region
 
     from turbo_amd.distributed import exchange_until_done
 
-    def one_step() -> dict:
-        session.start()
+    def one_step(sess=None) -> dict:
+        sess = sess or session
+        sess.start()
         # incumbent exchange (all_reduce MIN of one int32 over RCCL) until every rank's kernel is done
-        exchange_until_done(session, dist if world > 1 else None, tensor_device="cuda")
-        _, _, st = session.finish()
+        exchange_until_done(sess, dist if world > 1 else None, tensor_device=tdev)
+        _, _, st = sess.finish()
         return st
 
     def sync():
@@ -106,14 +119,41 @@ def main() -> int:
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        agg = torch.tensor([tot["nodes"], tot["num_deductions"], tot["store_writes"]], dtype=torch.int64, device="cuda")
+        agg = torch.tensor([tot["nodes"], tot["num_deductions"], tot["store_writes"]], dtype=torch.int64, device=tdev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         g_nodes, g_props, g_writes = (int(x) for x in agg.tolist())
     else:
         g_nodes, g_props, g_writes = tot["nodes"], tot["num_deductions"], tot["store_writes"]
+
+    # the same workload in the engine's event-driven fixpoint (same tree, fewer propagator evaluations per node)
+    event = None
+    if args.event_steps > 0 and args.fixpoint != "event":
+        cfg_e = capi.make_config(fixpoint=2, stop_after_n_nodes=cut * 4, timeout_ms=600000, device=local_rank, rank=rank, world_size=world)
+        sess_e = capi.Session(tcn, cfg_e)
+        one_step(sess_e)
+        sync()
+        te = time.perf_counter()
+        acc = {"nodes": 0, "num_deductions": 0}
+        for _ in range(args.event_steps):
+            st_e = one_step(sess_e)
+            for k in acc:
+                acc[k] += st_e[k]
+        sync()
+        te = time.perf_counter() - te
+        if world > 1:
+            t = torch.tensor([te], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            te = float(t.item())
+            agg = torch.tensor([acc["nodes"], acc["num_deductions"]], dtype=torch.int64, device=tdev)
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+            acc["nodes"], acc["num_deductions"] = (int(x) for x in agg.tolist())
+        event = {"fixpoint": "event", "steps": args.event_steps, "cutnodes": cut * 4, "nodes_per_sec": acc["nodes"] / te,
+                 "propagations_per_sec": acc["num_deductions"] / te,
+                 "note": "same search tree, propagators re-evaluated only when one of their variables was narrowed"}
+        sess_e.close()
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -135,7 +175,8 @@ def main() -> int:
             "nodes_per_sec": g_nodes / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1000.0 / steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "reference instance file (no randomness)",
+            "vs_baseline": None, "dtype": "int32",
+            "data": "synthetic (seed 42)" if args.workload == "synthetic" else "reference instance file (no randomness)",
             "config": {"workload": f"{fzn}: {tcn.n_vars} interval variables x {tcn.n_props} ternary propagators, "
                                    f"{last['num_blocks']} workgroups x {last['threads_per_block']} threads per GPU, "
                                    f"{capi.MEM_KINDS[last['mem_kind']]} ({last['shared_bytes']} B LDS per workgroup), "
@@ -147,6 +188,8 @@ def main() -> int:
                          "note": "algorithmic bytes = 40 B x propagations + 8 B x narrowed bounds; the store is LDS-resident on this "
                                  "workload, so the figure prices LDS+L2 traffic against the HBM peak (see DESIGN.md)"},
         }
+        if event is not None:
+            out["event_mode"] = event
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tcn, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / max(out["cpu_baseline"]["value"], 1e-9)

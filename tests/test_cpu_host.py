@@ -188,3 +188,25 @@ class TestCli:
         for part in ("-t 0", "-n 1", "-arch barebones", "-or 0", "-sub -1", "-subfactor 300", "-fp wac1", "-wac1_threshold 0",
                      "-seed 0", "-eps_var_order default", "-cutnodes 0"):
             assert part in line, part
+
+
+# ---- synthetic workload (BASELINE.json configs[4]) ----------------------------------------------------
+
+def test_synthetic_network_is_satisfiable_by_construction():
+    from oracle import pyoracle
+    from turbo_amd.synth import make_synthetic
+    tcn = make_synthetic(2000, 10000, seed=42)
+    assert tcn.n_vars == 2003 and tcn.n_props == 10000
+    v = tcn.hidden_solution
+    p = tcn.props
+    x, y, z = v[p["x"]], v[p["y"]], v[p["z"]]
+    ok = np.select([p["op"] == 0, p["op"] == 1, p["op"] == 4, p["op"] == 5, p["op"] == 6, p["op"] == 7],
+                   [x == y + z, x == y * z, x == np.minimum(y, z), x == np.maximum(y, z), x == (y == z), x == (y <= z)])
+    assert ok.all()
+    assert ((tcn.store["lb"] <= v) & (v <= tcn.store["ub"])).all()
+    # deterministic
+    again = make_synthetic(2000, 10000, seed=42)
+    assert np.array_equal(again.props, tcn.props) and np.array_equal(again.store, tcn.store)
+    # the root node propagates without failure and keeps the hidden solution
+    out, failed, _, _, _ = pyoracle.propagate(tcn.store, tcn.props)
+    assert not failed and ((out["lb"] <= v) & (v <= out["ub"])).all()

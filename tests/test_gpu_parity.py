@@ -167,3 +167,41 @@ def test_satisfaction_first_solution():
     assert has
     a, b, c = (int(best["lb"][i]) for i in range(3, 6))
     assert a + b + c == 7 and a < b
+
+
+# ---- synthetic 100k x 500k network (BASELINE.json configs[4]): store in global memory ------------------
+
+@pytest.fixture(scope="module")
+def synthetic():
+    from turbo_amd.synth import make_synthetic
+    return make_synthetic(100_000, 500_000, seed=42)
+
+
+@pytest.mark.parametrize("fixpoint", [1, 2], ids=["wac1", "event"])
+def test_synthetic_full_size_root_fixpoint_bit_exact(synthetic, fixpoint):
+    tcn = synthetic
+    rng = np.random.default_rng(5)
+    stores = np.repeat(tcn.store[None, :], 3, axis=0)
+    base = tcn.strat_vars[: tcn.strat_off[1]]
+    for s in (1, 2):  # two stores with a handful of hidden-solution-consistent decisions
+        for v in rng.choice(base, size=40 * s, replace=False):
+            stores[s]["lb"][v] = stores[s]["ub"][v] = tcn.hidden_solution[v]
+    got, failed, ent, iters, ded, _ = capi.propagate(tcn.props, stores, capi.make_config(fixpoint=fixpoint))
+    for i in range(stores.shape[0]):
+        exp, efailed, eent, _, _ = pyoracle.propagate(stores[i], tcn.props)
+        assert bool(failed[i]) == efailed and not efailed
+        assert bool(ent[i]) == eent
+        assert np.array_equal(got[i], exp)
+        v = tcn.hidden_solution
+        assert ((got[i]["lb"] <= v) & (v <= got[i]["ub"])).all()  # size-independent property: the hidden solution survives
+
+
+@pytest.mark.parametrize("fixpoint", [1, 2], ids=["wac1", "event"])
+def test_synthetic_search_finds_a_solution(synthetic, fixpoint):
+    tcn = synthetic
+    has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=20000, stop_after_n_nodes=400, fixpoint=fixpoint))
+    assert st["mem_kind"] == 0  # GLOBAL: 800 KB of domains do not fit in LDS
+    assert st["nodes"] > 0
+    if has:  # any reported solution satisfies every propagator
+        _, failed, ent, _, _ = pyoracle.propagate(best, tcn.props)
+        assert not failed and ent

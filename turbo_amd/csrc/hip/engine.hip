@@ -86,7 +86,10 @@ inline size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 int plan_launch(const tb_config& cfg, const DeviceCaps& caps, int n_vars, int n_props, LaunchPlan* plan) {
   LaunchPlan p;
   int T = cfg.threads_per_block;
-  if (T == 0) T = n_props >= 16384 ? 1024 : (n_props >= 2048 ? 512 : 256);
+  // Full sweeps (AC1/WAC1) want a wide workgroup: the sweep is throughput bound.  The event-driven fixpoint
+  // runs a few slices per sweep and is latency bound: many small workgroups per CU hide it better.
+  const bool event = cfg.fixpoint == 2;
+  if (T == 0) T = event ? 256 : (n_props >= 16384 ? 1024 : (n_props >= 2048 ? 512 : 256));
   if (T != 64 && T != 128 && T != 256 && T != 512 && T != 1024) return fail(TB_ERR_INVALID, "threads_per_block must be 64, 128, 256, 512 or 1024");
   p.threads = T;
   p.tmax = T <= 256 ? 256 : 1024;
@@ -97,10 +100,11 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, int n_vars, int n_
   // event-driven fixpoint always live in LDS
   // one dirty bitmap + two change lists of (variable, slice) pairs; an overflowing list falls back to a full sweep
   p.chg_cap = std::min(1024, std::max(64, n_vars / 4));
+  if (cfg.reserved[1] > 0) p.chg_cap = cfg.reserved[1];  // tuning knob
   const size_t dirty_b = align16((size_t)dirty_words * 4) + (size_t)p.chg_cap * 16;
   const size_t store_b = align16((size_t)vext * 8) + dirty_b, props_b = align16((size_t)n_props * 16);
   const size_t fixed = SH_BYTES;
-  int bpc_max = std::min(8, 2048 / T);  // 32 waves per CU
+  int bpc_max = std::min(cfg.reserved[2] > 0 ? cfg.reserved[2] : 8, 2048 / T);  // 32 waves per CU (reserved[2]: tuning knob)
   if (bpc_max < 1) bpc_max = 1;
   if (cfg.only_global_memory) {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
@@ -108,7 +112,9 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, int n_vars, int n_
     p.mem_kind = TB_MEM_TCN_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b + props_b);
   } else if ((fixed + store_b) * (size_t)bpc_max <= lds) {
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b);
-  } else if (fixed + store_b <= lds) {
+  } else if (fixed + store_b <= lds && !(event && (int)(lds / (fixed + store_b)) < 4)) {
+    // (event mode: a store that leaves fewer than 4 workgroups per CU goes to global memory instead --
+    //  measured 1.2-1.5x more nodes/s on wordpress7_500 / trains15 with 8 x 256-thread workgroups per CU)
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / (fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
   } else {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);

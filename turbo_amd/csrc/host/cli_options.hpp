@@ -9,7 +9,7 @@
 namespace turbo_host {
 
 enum class Arch { CPU, GPU, BAREBONES, HYBRID };
-enum class Fixpoint { AC1, WAC1 };
+enum class Fixpoint { AC1, WAC1, EVENT };  // EVENT: this engine's event-driven WAC1 (not a reference flag)
 
 struct Options {
   bool print_intermediate_solutions = false;  // -i / -a

@@ -105,7 +105,7 @@ tb_config make_config(const Options& o, bool has_eps) {
   c.timeout_ms = o.timeout_ms; c.or_nodes = o.or_nodes; c.subproblems_factor = o.subproblems_factor;
   c.stop_after_n_nodes = o.stop_after_n_nodes == UINT64_MAX ? 0 : o.stop_after_n_nodes;
   c.stop_after_n_solutions = o.stop_after_n_solutions; c.wac1_threshold = o.wac1_threshold;
-  c.subproblems_power = o.subproblems_power; c.fixpoint = o.fixpoint == Fixpoint::WAC1 ? 1 : 0;
+  c.subproblems_power = o.subproblems_power; c.fixpoint = o.fixpoint == Fixpoint::AC1 ? 0 : (o.fixpoint == Fixpoint::WAC1 ? 1 : 2);
   c.only_global_memory = o.only_global_memory; c.verbose = o.verbose; c.has_eps_strategy = has_eps;
   c.threads_per_block = o.threads_per_block; c.device = 0; c.rank = 0; c.world_size = 1;
   c.deterministic = o.deterministic;
