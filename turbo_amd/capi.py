@@ -53,6 +53,7 @@ class TbStats(C.Structure):
         d = {}
         for k, _ in self._fields_:
             if k == "reserved":
+                d["why_not_exhaustive"] = int(self.reserved[0])
                 continue
             v = getattr(self, k)
             d[k] = list(v) if hasattr(v, "__len__") else v

@@ -37,6 +37,7 @@ struct BlockStats {
   long long best_time;              // tick at which the best solution was found
   int depth_max, exhaustive, num_blocks_done, best_bound;
   long long best_sub;               // subproblem index that produced best_store (-1: none)
+  int why, pad_why;                 // debugging: reasons that cleared `exhaustive` (bit mask)
 };
 
 struct DevProblem {
@@ -48,8 +49,8 @@ struct DevProblem {
   const int* strat_off;
   const int* strat_vars;
   // event-driven fixpoint: variable -> 64-propagator slices adjacency (CSR), built by the shim
-  const int* adj_off;   // [n_vars + 1]
-  const int* adj;       // slice ids
+  const int4* adj_head; // [n_vars] {degree, first slice, second slice, offset of the remaining slices in adj}
+  const int* adj;       // remaining slice ids of the variables read by more than two slices
   int n_slices;         // ceil(n_props / 64)
   int dirty_words;      // ceil(n_slices / 32)
   int vext;             // int2 elements of a store slab: n_vars + one "not entailed" byte per slice

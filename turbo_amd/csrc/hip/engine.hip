@@ -101,7 +101,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, int n_vars, int n_
   // one dirty bitmap + two change lists of (variable, slice) pairs; an overflowing list falls back to a full sweep
   p.chg_cap = std::min(1024, std::max(64, n_vars / 4));
   if (cfg.reserved[1] > 0) p.chg_cap = cfg.reserved[1];  // tuning knob
-  const size_t dirty_b = align16((size_t)dirty_words * 4) + (size_t)p.chg_cap * 16;
+  const size_t dirty_b = align16((size_t)dirty_words * 4) + align16((size_t)p.chg_cap * 4);
   const size_t store_b = align16((size_t)vext * 8) + dirty_b, props_b = align16((size_t)n_props * 16);
   const size_t fixed = SH_BYTES;
   int bpc_max = std::min(cfg.reserved[2] > 0 ? cfg.reserved[2] : 8, 2048 / T);  // 32 waves per CU (reserved[2]: tuning knob)
@@ -157,46 +157,62 @@ int validate_network(int32_t n_vars, const tb_itv* store, int32_t n_props, const
   return TB_OK;
 }
 
-// Rewrite the caller's bytecodes into the engine's packed records (propagators.hpp): pack-time class,
-// and an immediate in place of every operand that is a constant (a singleton variable) in `consts`.
-std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::vector<char>& is_const, const std::vector<int>& value) {
+struct Adjacency {
+  std::vector<std::vector<int>> lists;  // per variable: the slices reading it (ascending, no duplicates); empty for constants
+  std::vector<int4> heads;              // {degree, first, second, offset of the rest}
+  std::vector<int> rest;
+};
+
+// Variable -> slices adjacency of the event-driven fixpoint: slice s = propagators [64 s, 64 s + 64).
+// Constants never change, so they get an empty list.
+Adjacency build_adjacency(int32_t n_vars, int32_t n_props, const tb_prop* props, const std::vector<char>& is_const) {
+  Adjacency a;
+  a.lists.resize((size_t)n_vars);
+  for (int32_t i = 0; i < n_props; ++i) {
+    const int s = i / 64;
+    const int vs[3] = {props[i].x, props[i].y, props[i].z};
+    for (int v : vs) {
+      if (is_const[(size_t)v]) continue;
+      std::vector<int>& l = a.lists[(size_t)v];
+      if (l.empty() || l.back() != s) l.push_back(s);
+    }
+  }
+  a.heads.resize((size_t)std::max(1, n_vars));
+  for (int32_t v = 0; v < n_vars; ++v) {
+    const std::vector<int>& l = a.lists[(size_t)v];
+    int4 h = make_int4((int)l.size(), l.size() > 0 ? l[0] : -1, l.size() > 1 ? l[1] : -1, (int)a.rest.size());
+    for (size_t k = 2; k < l.size(); ++k) a.rest.push_back(l[k]);
+    a.heads[(size_t)v] = h;
+  }
+  if (a.rest.empty()) a.rest.push_back(0);
+  return a;
+}
+
+// Rewrite the caller's bytecodes into the engine's packed records (propagators.hpp): word0 = pack-time class |
+// "operand is read by no other slice" bits 8-10 | original op << 12 | classes present in the 64-record slice << 16.
+std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::vector<char>& is_const, const std::vector<int>& value,
+                             const Adjacency& adj) {
   std::vector<int4> out((size_t)n_props);
   for (int32_t base = 0; base < n_props; base += 64) {
     const int32_t end = std::min(n_props, base + 64);
+    const int s = base / 64;
     int present = 0;
     for (int32_t i = base; i < end; ++i) {
       const tb_prop& p = props[i];
       const bool xc = is_const[(size_t)p.x] != 0;
       const int cls = class_of(p.op, xc, xc ? value[(size_t)p.x] : 0);
       present |= 1 << cls;
-      out[(size_t)i] = make_int4(cls | (p.op << 12), p.x, p.y, p.z);
+      int priv = 0;
+      const int vs[3] = {p.x, p.y, p.z};
+      for (int k = 0; k < 3; ++k) {
+        const std::vector<int>& l = adj.lists[(size_t)vs[k]];
+        if (l.empty() || (l.size() == 1 && l[0] == s)) priv |= 1 << k;
+      }
+      out[(size_t)i] = make_int4(cls | (priv << 8) | (p.op << 12), p.x, p.y, p.z);
     }
     for (int32_t i = base; i < end; ++i) out[(size_t)i].x |= present << 16;  // same mask in the 64 records of a slice
   }
   return out;
-}
-
-// Variable -> slices adjacency (CSR) of the event-driven fixpoint: slice s = propagators [64 s, 64 s + 64).
-// Constants never change, so they get an empty list.
-void build_adjacency(int32_t n_vars, int32_t n_props, const tb_prop* props, const std::vector<char>& is_const,
-                     std::vector<int>* off, std::vector<int>* adj) {
-  std::vector<std::vector<int>> lists((size_t)n_vars);
-  for (int32_t i = 0; i < n_props; ++i) {
-    const int s = i / 64;
-    const int vs[3] = {props[i].x, props[i].y, props[i].z};
-    for (int v : vs) {
-      if (is_const[(size_t)v]) continue;
-      std::vector<int>& l = lists[(size_t)v];
-      if (l.empty() || l.back() != s) l.push_back(s);
-    }
-  }
-  off->assign((size_t)n_vars + 1, 0);
-  adj->clear();
-  for (int32_t v = 0; v < n_vars; ++v) {
-    (*off)[(size_t)v] = (int)adj->size();
-    adj->insert(adj->end(), lists[(size_t)v].begin(), lists[(size_t)v].end());
-  }
-  (*off)[(size_t)n_vars] = (int)adj->size();
 }
 
 // Constants of a batch of stores: variables that are the same finite singleton in every store.
@@ -214,34 +230,48 @@ void find_constants(int32_t n_vars, int32_t n_stores, const tb_itv* stores, std:
   }
 }
 
-template <int MEM, int TMAX>
-int set_lds_limit_solve(int bytes) {
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<MEM, TMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+template <int MEM, int TMAX, bool EVENT>
+int prepare_solve(int bytes, int threads, int* max_blocks_per_cu) {
+  const void* k = reinterpret_cast<const void*>(&solve_kernel<MEM, TMAX, EVENT>);
+  HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  int nb = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, threads, (size_t)bytes));
+  *max_blocks_per_cu = nb;
   return TB_OK;
 }
-template <int MEM, int TMAX>
-int set_lds_limit_prop(int bytes) {
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<MEM, TMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+template <int MEM, int TMAX, bool EVENT>
+int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
+  const void* k = reinterpret_cast<const void*>(&propagate_kernel<MEM, TMAX, EVENT>);
+  HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  int nb = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, threads, (size_t)bytes));
+  *max_blocks_per_cu = nb;
   return TB_OK;
 }
 
-#define DISPATCH_KERNEL(FN, mem, tmax, ...)                                                          \
-  do {                                                                                               \
-    if (tmax == 256) {                                                                               \
-      if (mem == TB_MEM_GLOBAL) FN<TB_MEM_GLOBAL, 256> __VA_ARGS__;                                  \
-      else if (mem == TB_MEM_STORE_SHARED) FN<TB_MEM_STORE_SHARED, 256> __VA_ARGS__;                 \
-      else FN<TB_MEM_TCN_SHARED, 256> __VA_ARGS__;                                                   \
-    } else {                                                                                         \
-      if (mem == TB_MEM_GLOBAL) FN<TB_MEM_GLOBAL, 1024> __VA_ARGS__;                                 \
-      else if (mem == TB_MEM_STORE_SHARED) FN<TB_MEM_STORE_SHARED, 1024> __VA_ARGS__;                \
-      else FN<TB_MEM_TCN_SHARED, 1024> __VA_ARGS__;                                                  \
-    }                                                                                                \
+#define DISPATCH_MEM(FN, TM, EV, mem, ...)                                          \
+  do {                                                                              \
+    if (mem == TB_MEM_GLOBAL) FN<TB_MEM_GLOBAL, TM, EV> __VA_ARGS__;                \
+    else if (mem == TB_MEM_STORE_SHARED) FN<TB_MEM_STORE_SHARED, TM, EV> __VA_ARGS__; \
+    else FN<TB_MEM_TCN_SHARED, TM, EV> __VA_ARGS__;                                 \
+  } while (0)
+#define DISPATCH_KERNEL(FN, mem, tmax, event, ...)                                  \
+  do {                                                                              \
+    if (tmax == 256) {                                                              \
+      if (event) DISPATCH_MEM(FN, 256, true, mem, __VA_ARGS__);                     \
+      else DISPATCH_MEM(FN, 256, false, mem, __VA_ARGS__);                          \
+    } else {                                                                        \
+      if (event) DISPATCH_MEM(FN, 1024, true, mem, __VA_ARGS__);                    \
+      else DISPATCH_MEM(FN, 1024, false, mem, __VA_ARGS__);                         \
+    }                                                                               \
   } while (0)
 
-int set_lds_limit(bool solve, int mem, int tmax, int bytes) {
+// Sets the dynamic-LDS limit of the kernel that will run and returns how many of its workgroups a CU holds
+// (register / LDS limited).  A persistent kernel gains nothing from queued workgroups, so the grid is capped.
+int prepare_kernel(bool solve, int mem, int tmax, bool event, int bytes, int threads, int* max_blocks_per_cu) {
   int rc = TB_OK;
-  if (solve) DISPATCH_KERNEL(rc = set_lds_limit_solve, mem, tmax, (bytes));
-  else DISPATCH_KERNEL(rc = set_lds_limit_prop, mem, tmax, (bytes));
+  if (solve) DISPATCH_KERNEL(rc = prepare_solve, mem, tmax, event, (bytes, threads, max_blocks_per_cu));
+  else DISPATCH_KERNEL(rc = prepare_prop, mem, tmax, event, (bytes, threads, max_blocks_per_cu));
   return rc;
 }
 
@@ -347,17 +377,17 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   if ((rc = bufs.alloc(&d_out, (size_t)n_stores)) != TB_OK) return rc;
   {
     std::vector<char> is_const;
-    std::vector<int> value, off, adj;
+    std::vector<int> value;
     find_constants(n_vars, n_stores, stores_inout, &is_const, &value);
-    const std::vector<int4> packed = pack_props(n_props, props, is_const, value);
+    const Adjacency adj = build_adjacency(n_vars, n_props, props, is_const);
+    const std::vector<int4> packed = pack_props(n_props, props, is_const, value, adj);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), (size_t)n_props * sizeof(int4), hipMemcpyHostToDevice));
-    build_adjacency(n_vars, n_props, props, is_const, &off, &adj);
-    int *d_off = nullptr, *d_adj = nullptr;
-    if ((rc = bufs.alloc(&d_off, off.size())) != TB_OK) return rc;
-    if ((rc = bufs.alloc(&d_adj, adj.size())) != TB_OK) return rc;
-    HIP_TRY(hipMemcpy(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
-    if (!adj.empty()) HIP_TRY(hipMemcpy(d_adj, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
-    P.adj_off = d_off; P.adj = d_adj;
+    int4* d_head = nullptr; int* d_adj = nullptr;
+    if ((rc = bufs.alloc(&d_head, adj.heads.size())) != TB_OK) return rc;
+    if ((rc = bufs.alloc(&d_adj, adj.rest.size())) != TB_OK) return rc;
+    HIP_TRY(hipMemcpy(d_head, adj.heads.data(), adj.heads.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_adj, adj.rest.data(), adj.rest.size() * 4, hipMemcpyHostToDevice));
+    P.adj_head = d_head; P.adj = d_adj;
     if (plan.mem_kind == TB_MEM_GLOBAL) { if ((rc = bufs.alloc(&P.g_store, (size_t)plan.num_blocks * (size_t)plan.vext)) != TB_OK) return rc; }
   }
   P.n_slices = plan.n_slices; P.dirty_words = plan.dirty_words; P.vext = plan.vext; P.chg_cap = plan.chg_cap;
@@ -367,7 +397,12 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   P.mem_kind = plan.mem_kind; P.debug = cfg.reserved[0];
   const uint64_t timeout_ms = cfg.timeout_ms ? cfg.timeout_ms : 60000;
   // watchdog deadline in device wall-clock ticks (read the counter through a tiny query below)
-  if ((rc = set_lds_limit(false, plan.mem_kind, plan.tmax, plan.shared_bytes)) != TB_OK) return rc;
+  const bool event = cfg.fixpoint == 2;
+  {
+    int occ = 0;
+    if ((rc = prepare_kernel(false, plan.mem_kind, plan.tmax, event, plan.shared_bytes, plan.threads, &occ)) != TB_OK) return rc;
+    if (occ > 0) plan.num_blocks = std::min(plan.num_blocks, occ * caps.cus);
+  }
   hipStream_t stream;
   HIP_TRY(hipStreamCreate(&stream));
   hipEvent_t e0, e1;
@@ -377,7 +412,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   P.deadline_ticks = 0;
   const int grid = std::min(n_stores, plan.num_blocks);
   HIP_TRY(hipEventRecord(e0, stream));
-  DISPATCH_KERNEL(propagate_kernel, plan.mem_kind, plan.tmax, <<<dim3(grid), dim3(plan.threads), plan.shared_bytes, stream>>>(P, d_stores, d_out, n_stores));
+  DISPATCH_KERNEL(propagate_kernel, plan.mem_kind, plan.tmax, event, <<<dim3(grid), dim3(plan.threads), plan.shared_bytes, stream>>>(P, d_stores, d_out, n_stores));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e1, stream));
   HIP_TRY(hipStreamSynchronize(stream));
@@ -424,6 +459,18 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   s->n_vars = n_vars; s->obj_var = obj_var;
   if ((rc = query_caps(s->cfg.device, &s->caps)) != TB_OK) return rc;
   if ((rc = plan_launch(s->cfg, s->caps, n_vars, n_props, &s->plan)) != TB_OK) return rc;
+  {
+    // cap the grid by what is actually resident (registers, LDS): queued workgroups of a persistent kernel only
+    // add tail latency; re-plan so that the subproblem count follows the real workgroup count
+    int occ = 0;
+    if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->cfg.fixpoint == 2, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
+    if (occ > 0 && (long long)occ * s->caps.cus < (long long)s->plan.num_blocks) {
+      tb_config capped = s->cfg;
+      capped.or_nodes = (uint64_t)occ * (uint64_t)s->caps.cus;
+      if ((rc = plan_launch(capped, s->caps, n_vars, n_props, &s->plan)) != TB_OK) return rc;
+      if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->cfg.fixpoint == 2, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
+    }
+  }
   const LaunchPlan& plan = s->plan;
   DevProblem& P = s->P;
   const size_t V = (size_t)n_vars, B = (size_t)plan.num_blocks;
@@ -437,17 +484,17 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   if ((rc = s->bufs.alloc(&d_sv, (size_t)total_svars)) != TB_OK) return rc;
   {
     std::vector<char> is_const;
-    std::vector<int> value, off, adj;
+    std::vector<int> value;
     find_constants(n_vars, 1, root_store, &is_const, &value);  // constants = singleton variables of the root store
-    const std::vector<int4> packed = pack_props(n_props, props, is_const, value);
+    const Adjacency adj = build_adjacency(n_vars, n_props, props, is_const);
+    const std::vector<int4> packed = pack_props(n_props, props, is_const, value, adj);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), (size_t)n_props * sizeof(int4), hipMemcpyHostToDevice));
-    build_adjacency(n_vars, n_props, props, is_const, &off, &adj);
-    int *d_aoff = nullptr, *d_adj = nullptr;
-    if ((rc = s->bufs.alloc(&d_aoff, off.size())) != TB_OK) return rc;
-    if ((rc = s->bufs.alloc(&d_adj, adj.size())) != TB_OK) return rc;
-    HIP_TRY(hipMemcpy(d_aoff, off.data(), off.size() * 4, hipMemcpyHostToDevice));
-    if (!adj.empty()) HIP_TRY(hipMemcpy(d_adj, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
-    s->P.adj_off = d_aoff; s->P.adj = d_adj;
+    int4* d_head = nullptr; int* d_adj = nullptr;
+    if ((rc = s->bufs.alloc(&d_head, adj.heads.size())) != TB_OK) return rc;
+    if ((rc = s->bufs.alloc(&d_adj, adj.rest.size())) != TB_OK) return rc;
+    HIP_TRY(hipMemcpy(d_head, adj.heads.data(), adj.heads.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_adj, adj.rest.data(), adj.rest.size() * 4, hipMemcpyHostToDevice));
+    s->P.adj_head = d_head; s->P.adj = d_adj;
   }
   s->P.n_slices = s->plan.n_slices; s->P.dirty_words = s->plan.dirty_words; s->P.vext = s->plan.vext; s->P.chg_cap = s->plan.chg_cap;
   if (n_vars) HIP_TRY(hipMemcpy(d_root, root_store, V * sizeof(tb_itv), hipMemcpyHostToDevice));
@@ -495,7 +542,6 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&s->ev_start));
   HIP_TRY(hipEventCreate(&s->ev_stop));
-  if ((rc = set_lds_limit(true, plan.mem_kind, plan.tmax, plan.shared_bytes)) != TB_OK) return rc;
   *out = s.release();
   return TB_OK;
 }
@@ -528,7 +574,7 @@ int tb_session_start(tb_session* s) {
   s->t_start = std::chrono::steady_clock::now();
   HIP_TRY(hipEventRecord(s->ev_start, s->stream));
   const LaunchPlan& plan = s->plan;
-  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->mbox_dev));
+  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, s->cfg.fixpoint == 2, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->mbox_dev));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev_stop, s->stream));
   s->started = true;
@@ -592,6 +638,7 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
     st.store_writes += x.store_writes;
     st.depth_max = std::max(st.depth_max, x.depth_max);
     st.exhaustive = st.exhaustive && x.exhaustive;
+    st.reserved[0] |= x.why;
     for (int t = 0; t < TB_NUM_TIMERS; ++t)
       if (t != TB_T_FIRST_BLOCK_IDLE && t != TB_T_LATEST_BEST_OBJ_FOUND) st.timers_ns[t] += (int64_t)((double)x.timers[t] * ns_per_tick);
     st.cumulative_time_block_ns += (int64_t)((double)x.timers[TB_T_FIRST_BLOCK_IDLE] * ns_per_tick);

@@ -43,7 +43,7 @@ struct alignas(16) BlockShared {
   int cur_strategy, next_unassigned, snap_strategy, snap_next_unassigned;
   int best_bound;  // best objective found by this workgroup (BlockData::best_bound, barebones:116)
   int found, sol, skip, abort;
-  int new_depth, ev_all, chg_count[2];  // event mode: "run every slice" request, change-list fill levels
+  int new_depth, ev_all, chg_count[2], ev_busy;  // event mode: "run every slice" request, change-list fill, waves running a slice
   unsigned long long sub_idx;
   unsigned long long red_key[MAX_WAVES];
   int red_first[MAX_WAVES];
@@ -77,24 +77,21 @@ struct ThreadCounters {
 // Record of an idle lane (slice tail): the cheapest class, three immediates -> no memory access, entailed.
 __device__ __forceinline__ int4 idle_record() { return make_int4(K_LEQ_T, 0, 0, 0); }
 
-// Event mode: a narrowed variable is appended, with the slice that narrowed it, to a change list in LDS; the
-// list is expanded through the variable -> slices adjacency by the whole workgroup between two sweeps
-// (one wave per entry, lanes striding over the adjacency), so a high-degree variable costs one memory
-// latency instead of a serial walk by the lane that happened to narrow it.
-struct EventArgs {        // only read when EVENT
-  int2* list;             // change list being filled: (variable, slice that narrowed it)
+// Event mode bookkeeping of callers outside a fixpoint (decisions, objective bound, replay): the changed
+// variable goes to a small list in LDS that the next fixpoint expands into the dirty bitmap.
+struct ChangeList {
+  int* list;
   int* count;
   int cap;
-  int self;               // slice being evaluated (-1: decision / bound from outside the sweep)
 };
-__device__ __forceinline__ void append_change(const EventArgs& ev, int v) {
-  const int pos = __hip_atomic_fetch_add(ev.count, 1, TB_RLX, TB_WG);
-  if (pos < ev.cap) ev.list[pos] = make_int2(v, ev.self);  // an overflowing list degrades to "run every slice"
+__device__ __forceinline__ void append_change(const ChangeList& cl, int v) {
+  const int pos = __hip_atomic_fetch_add(cl.count, 1, TB_RLX, TB_WG);
+  if (pos < cl.cap) cl.list[pos] = v;  // an overflowing list degrades to "run every slice"
 }
 
 template <bool EVENT>
 __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store, int* bot, bool& changed, bool& un, ThreadCounters& tc, const int dbg = 0,
-                                      const EventArgs ev = EventArgs{nullptr, nullptr, 0, -1}) {
+                                      int* narrowed = nullptr) {
   const int w0 = pr.x;
   // three gathers issued back to back, one s_waitcnt (the LDS is ~1 % busy: gathers are cheap, VALU is not)
   Itv X{0, 1}, Y{0, 1}, Z{0, 1};
@@ -121,11 +118,7 @@ __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store
         if (nzu != Z.ub) { lower_ub(store, pr.w, nzu); ++k; }
         tc.writes += (unsigned)k;
         changed |= (k != 0);
-        if (EVENT) {
-          if ((nxl != X.lb) | (nxu != X.ub)) append_change(ev, pr.y);
-          if ((nyl != Y.lb) | (nyu != Y.ub)) append_change(ev, pr.z);
-          if ((nzl != Z.lb) | (nzu != Z.ub)) append_change(ev, pr.w);
-        }
+        if (EVENT) *narrowed = (int)((nxl != X.lb) | (nxu != X.ub)) | ((int)((nyl != Y.lb) | (nyu != Y.ub)) << 1) | ((int)((nzl != Z.lb) | (nzu != Z.ub)) << 2);
       }
     }
   }
@@ -213,121 +206,165 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
 // This is the role of FixpointSubsetGPU / entailed-propagator removal in the reference (gpu_dive_and_solve.hpp:334,
 // barebones:984, off by default there), re-thought for wave64 slices instead of a compacted index array.
 struct EventState {
-  unsigned* dirty;        // LDS: one bitmap of `words` words (slices to run in the current sweep)
-  int2* list;             // LDS: 2 x cap change-list entries (double buffered by sweep parity)
+  unsigned* dirty;        // LDS: bitmap of the slices that must (re)run
+  int* list;              // LDS: variables changed outside the fixpoint (decision, bound, replay)
   unsigned char* unent;   // one byte per slice, behind the store (LDS or HBM slab)
   int words, cap;
 };
 
-// Callers outside a sweep (decisions, objective bound, replay): the change goes to list 0, which the
-// next fixpoint expands before its first sweep.
 __device__ __forceinline__ void note_change(BlockShared& sh, const EventState& es, int v) {
-  const EventArgs ev{es.list, &sh.chg_count[0], es.cap, -1};
-  append_change(ev, v);
+  const ChangeList cl{es.list, &sh.chg_count[0], es.cap};
+  append_change(cl, v);
 }
 
+__device__ __forceinline__ void mark_slice(unsigned* dirty, int t) {
+  (void)__hip_atomic_fetch_or(&dirty[t >> 5], 1u << (t & 31), TB_RLX, TB_WG);
+}
+
+// Adjacency head of a variable: {degree, first slice, second slice, offset of the rest in P.adj}.  Most
+// variables of a lowered model are read by one or two slices, so one 16-byte load usually settles it.
+// Low-degree part: done by the lane itself.  Returns true when the rest must be walked cooperatively.
+__device__ __forceinline__ bool mark_head(unsigned* dirty, const int4 h, int self) {
+  if (h.x >= 1 && h.y != self) mark_slice(dirty, h.y);
+  if (h.x >= 2 && h.z != self) mark_slice(dirty, h.z);
+  return h.x > 2;
+}
+// Cooperative walk of the long adjacency lists of the lanes in `mask` (wave-uniform): one lane at a time is
+// broadcast, the 64 lanes stride over its list -- a high-degree variable costs one memory latency.
+__device__ __forceinline__ void mark_rest(const DevProblem& P, unsigned* dirty, unsigned long long mask, const int4 h, int self) {
+  const int lane = threadIdx.x & 63;
+  while (mask) {
+    const int l = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    const int deg = __builtin_amdgcn_readlane(h.x, l), off = __builtin_amdgcn_readlane(h.w, l);
+    for (int j = lane; j < deg - 2; j += 64) {
+      const int t = P.adj[off + j];
+      if (t != self) mark_slice(dirty, t);
+    }
+  }
+}
+
+// Claim one dirty slice (all lanes return the same id, -1 if the bitmap is empty).  The 64 lanes read 64
+// bitmap words at once; `rot` spreads the waves over the words so that claims rarely collide.
+__device__ __forceinline__ int claim_slice(const EventState& es, int rot) {
+  const int lane = threadIdx.x & 63;
+  for (int base = 0; base < es.words; base += 64) {
+    const int wi = base + lane;
+    unsigned w = wi < es.words ? __hip_atomic_load(&es.dirty[wi], TB_RLX, TB_WG) : 0u;
+    unsigned long long nz = __ballot(w != 0);
+    while (nz) {
+      const unsigned long long r = rot ? ((nz >> rot) | (nz << (64 - rot))) : nz;
+      const int l = (__builtin_ctzll(r) + rot) & 63;
+      const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)w, l);
+      const int b = __builtin_ctz(word);
+      unsigned old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_and(&es.dirty[base + l], ~(1u << b), TB_RLX, TB_WG);
+      old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+      if ((old >> b) & 1u) return (base + l) * 32 + b;
+      if (lane == l) w = old & ~(1u << b);  // somebody else was faster: refresh our copy of that word
+      nz = __ballot(w != 0);
+    }
+  }
+  return -1;
+}
+
+// Event-driven WAC1 (tb_config.fixpoint = 2), asynchronous: waves claim dirty slices, iterate each to its
+// local fixpoint, and mark the slices that read a narrowed variable IMMEDIATELY; there is no barrier between
+// "sweeps" -- a propagation chain advances at the latency of one slice run, not of one workgroup barrier.
+// A wave leaves when the bitmap is empty and no wave is running a slice (`busy`): a wave that marks slices
+// re-scans the bitmap itself, so no work is lost when others have already left.
 __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
                                               const EventState& es, ThreadCounters& tc, bool& all_entailed) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
   const int n = P.n_props, W = es.words, S = P.n_slices;
   const bool prof = (P.debug & 0x10000) != 0;
-  if (tid == 0) { st(&sh.flag[0], 0); st(&sh.unent[0], 0); }
-  __syncthreads();
-  int it = 0, k = 0;
-  for (;;) {
-    k = it % 3;
-    const int p = it & 1;
-    long long tp0 = 0;
-    if (tid == 0 && prof) tp0 = wall_clock64();
-    // ---- expansion: change list p -> dirty bitmap (the bitmap is empty here)
-    {
-      const int cnt = ld(&sh.chg_count[p]);
-      const bool all = ld(&sh.ev_all) != 0 || cnt > es.cap;
-      if (all) {
-        for (int i = tid; i < W; i += T) {
-          const int left = S - i * 32;
-          es.dirty[i] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
-        }
-        if (tid == 0 && S > 0) st(&sh.flag[k], 1);
-      } else {
-        const int2* list = es.list + p * es.cap;
-        bool marked = false;
-        for (int e = wave; e < cnt; e += nw) {
-          const int2 ent = list[e];  // uniform address: LDS broadcast
-          const int v = __builtin_amdgcn_readfirstlane(ent.x), self = __builtin_amdgcn_readfirstlane(ent.y);
-          const int o0 = P.adj_off[v], o1 = P.adj_off[v + 1];
-          for (int j = o0 + lane; j < o1; j += 64) {
-            const int t = P.adj[j];
-            if (t != self) { (void)__hip_atomic_fetch_or(&es.dirty[t >> 5], 1u << (t & 31), TB_RLX, TB_WG); marked = true; }
-          }
-        }
-        if (__any(marked) && lane == 0) st(&sh.flag[k], 1);
-      }
-      if (tid == 0) {
-        st(&sh.flag[(k + 1) % 3], 0);
-        st(&sh.chg_count[p ^ 1], 0);  // filled by the sweep below, last read two barriers ago
-        if ((it & 255) == 255 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
-      }
+  long long tp0 = 0;
+  if (tid == 0 && prof) tp0 = wall_clock64();
+  // ---- initial dirty set: everything, or the slices of the variables changed since the last fixpoint
+  const int cnt = ld(&sh.chg_count[0]);
+  const bool all = ld(&sh.ev_all) != 0 || cnt > es.cap;
+  if (all) {
+    for (int i = tid; i < W; i += T) {
+      const int left = S - i * 32;
+      es.dirty[i] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
     }
-    __syncthreads();
-    if (tid == 0) st(&sh.ev_all, 0);
-    if (!ld(&sh.flag[k]) || ld(&sh.abort)) break;  // nothing left to run: fixpoint
-    long long tp1 = 0;
-    if (tid == 0 && prof) { tp1 = wall_clock64(); sh.bs.timers[TB_T_WAIT_CPU] += tp1 - tp0; }  // profiling: expansion
-    // ---- sweep over the dirty slices; narrowed variables go to list p^1
-    const EventArgs evb{es.list + (p ^ 1) * es.cap, &sh.chg_count[p ^ 1], es.cap, -1};
-    // Dirty slices are CLAIMED dynamically (atomic and on the bitmap word), so a cluster of dirty slices is
-    // spread over all waves instead of serialising on its static owners.  Each wave starts at its own word
-    // and prefers its own bit position to keep claim collisions rare.
-    int wi = (wave * W) / nw;
-    const int rot = (wave * 32) / nw;
-    for (int q = 0; q < W; ++q, wi = (wi + 1 == W) ? 0 : wi + 1) {
-      for (;;) {
-        const unsigned bits = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&es.dirty[wi], TB_RLX, TB_WG));
-        if (bits == 0) break;
-        const unsigned rotd = rot ? ((bits >> rot) | (bits << (32 - rot))) : bits;
-        const int bpos = (__builtin_ctz(rotd) + rot) & 31;
-        unsigned old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_and(&es.dirty[wi], ~(1u << bpos), TB_RLX, TB_WG);
-        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-        if (!((old >> bpos) & 1u)) continue;  // another wave claimed it first
-        const int s = wi * 32 + bpos;
-        const int i = s * 64 + lane;
-        const bool act = i < n;
-        int4 pr = idle_record();
-        if (act) pr = props[i];
-        EventArgs ev = evb;
-        ev.self = s;
-        for (;;) {
-          bool ch = false, un_i = false;
-          apply<true>(pr, act, store, &sh.bot, ch, un_i, tc, 0, ev);
-          if (lane == 0) tc.deductions += 64;
-          if (!__any(ch)) {
-            const bool any_un = __any(un_i);
-            if (lane == 0) es.unent[s] = any_un ? 1 : 0;
-            break;
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-          if (ld(&sh.bot)) break;
-        }
-      }
+  } else {
+    for (int e = tid; e < cnt; e += T) {  // one lane per entry; long lists are finished cooperatively
+      const int4 h = P.adj_head[es.list[e]];
+      (void)mark_head(es.dirty, h, -1);
     }
-    long long tp2 = 0;
-    if (tid == 0 && prof) { tp2 = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += tp2 - tp1; }  // profiling: own slice work
-    __syncthreads();
-    if (tid == 0 && prof) sh.bs.timers[TB_T_TRANSFER_GPU2CPU] += wall_clock64() - tp2;  // profiling: waiting for the slowest wave
-    ++it;
-    if (ld(&sh.bot)) break;
+    for (int e0 = wave * 64; e0 < cnt; e0 += T) {
+      const int e = e0 + lane;
+      int4 h = make_int4(0, 0, 0, 0);
+      if (e < cnt) h = P.adj_head[es.list[e]];
+      mark_rest(P, es.dirty, __ballot(h.x > 2), h, -1);
+    }
   }
-  // leave the bitmap and both lists empty for the next node, and reduce the per-slice entailment bytes
+  if (tid == 0) { st(&sh.unent[0], 0); st(&sh.flag[0], (all ? S : cnt) > 0 ? 1 : 0); }
+  __syncthreads();
+  if (tid == 0) { st(&sh.ev_all, 0); st(&sh.chg_count[0], 0); }
+  const int ran = ld(&sh.flag[0]);
+  if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_WAIT_CPU] += t - tp0; tp0 = t; }  // profiling: seeding
+  // ---- asynchronous worklist
+  const int rot = (wave * 64) / nw;
+  int idle_spins = 0;
+  for (;;) {
+    if (ld(&sh.bot) || ld(&sh.abort)) break;
+    const int s = claim_slice(es, rot);
+    if (s < 0) {
+      if (ld(&sh.ev_busy) == 0) break;  // nothing to run and nobody can create work any more
+      __builtin_amdgcn_s_sleep(4);
+      if ((++idle_spins & 1023) == 0 && lane == 0 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
+      continue;
+    }
+    if (lane == 0) (void)__hip_atomic_fetch_add(&sh.ev_busy, 1, TB_RLX, TB_WG);
+    const int i = s * 64 + lane;
+    const bool act = i < n;
+    int4 pr = idle_record();
+    if (act) pr = props[i];
+    int4 hx = make_int4(0, 0, 0, 0), hy = hx, hz = hx;  // adjacency heads of my three operands, loaded on first use
+    int have = 0;
+    for (;;) {
+      bool ch = false, un_i = false;
+      int nar = 0;
+      apply<true>(pr, act, store, &sh.bot, ch, un_i, tc, 0, &nar);
+      if (lane == 0) tc.deductions += 64;
+      if (!__any(ch)) {
+        const bool any_un = __any(un_i);
+        if (lane == 0) es.unent[s] = any_un ? 1 : 0;
+        break;
+      }
+      // successors: every other slice reading a variable I narrowed (operands private to this slice are
+      // flagged at pack time in word0 and skipped)
+      nar &= ~(pr.x >> 8) & 7;
+      if ((nar & 1) && !(have & 1)) { hx = P.adj_head[pr.y]; have |= 1; }
+      if ((nar & 2) && !(have & 2)) { hy = P.adj_head[pr.z]; have |= 2; }
+      if ((nar & 4) && !(have & 4)) { hz = P.adj_head[pr.w]; have |= 4; }
+      const bool lx = (nar & 1) && mark_head(es.dirty, hx, s);
+      const bool ly = (nar & 2) && mark_head(es.dirty, hy, s);
+      const bool lz = (nar & 4) && mark_head(es.dirty, hz, s);
+      const unsigned long long mx = __ballot(lx), my = __ballot(ly), mz = __ballot(lz);
+      if (mx) mark_rest(P, es.dirty, mx, hx, s);
+      if (my) mark_rest(P, es.dirty, my, hy, s);
+      if (mz) mark_rest(P, es.dirty, mz, hz, s);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      if (ld(&sh.bot)) break;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my marks are visible before I stop being busy
+    if (lane == 0) (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG);
+  }
+  if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += t - tp0; tp0 = t; }  // profiling: own work
+  __syncthreads();
+  if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_GPU2CPU] += t - tp0; }  // profiling: waiting for the last wave
+  // leave the bitmap empty for the next node (it is not after a failure), reduce the entailment bytes
   for (int i = tid; i < W; i += T) es.dirty[i] = 0;
-  if (tid == 0) { st(&sh.chg_count[0], 0); st(&sh.chg_count[1], 0); st(&sh.ev_all, 0); }
+  if (tid == 0) st(&sh.ev_busy, 0);
   bool un = false;
   for (int s = tid; s < S; s += T) un |= es.unent[s] != 0;
   if (__any(un) && lane == 0) st(&sh.unent[0], 1);
   __syncthreads();
   all_entailed = !ld(&sh.unent[0]);
-  return it;
+  return ran;
 }
 
 // ---- small helpers -------------------------------------------------------------------------------
@@ -361,9 +398,10 @@ __device__ __forceinline__ bool embed0(int2* store, int* bot, int v, int lb, int
   return changed;
 }
 // embed0 + event bookkeeping: the slices reading v must run in the first sweep of the next fixpoint
+template <bool EVENT>
 __device__ __forceinline__ void embed0_mark(const DevProblem& P, BlockShared& sh, const EventState& es, int2* store, int* bot, int v, int lb, int ub) {
   const bool changed = embed0(store, bot, v, lb, ub);
-  if (P.fixpoint == 2 && changed) note_change(sh, es, v);
+  if (EVENT && changed) note_change(sh, es, v);
 }
 
 // Key to MINIMISE for each variable order (barebones:193-221); ties resolve to the lowest index
@@ -456,6 +494,7 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
 
 struct NodeTimers { long long t_last; };
 
+template <bool EVENT>
 __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
                                                int2* best_store, Mailbox* mbox, ThreadCounters& tc,
                                                long long& t_mark, long long t_start) {
@@ -464,7 +503,9 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
   long long t0 = 0;
   if (tid == 0) { t0 = wall_clock64(); bs.timers[TB_T_SEARCH] += t0 - t_mark; }
   bool all_entailed = false;
-  const int iters = P.fixpoint == 2 ? fixpoint_event(P, sh, store, props, es, tc, all_entailed) : fixpoint(P, sh, store, props, tc, all_entailed);
+  int iters;
+  if constexpr (EVENT) iters = fixpoint_event(P, sh, store, props, es, tc, all_entailed);
+  else iters = fixpoint(P, sh, store, props, tc, all_entailed);
   const bool aborted = ld(&sh.abort) != 0;
   const bool failed = !aborted && ld(&sh.bot) != 0;
   if (aborted) all_entailed = false;
@@ -523,7 +564,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
     if (__hip_atomic_load(&P.ctrl->stop, TB_RLX, TB_AGENT) != 0) must_stop = true;
     if (P.use_fixed_bound && __hip_atomic_load(&P.ctrl->first_sol_idx, TB_RLX, TB_AGENT) < sh.sub_idx) { sh.stop = 1; }
     if (aborted) { must_stop = true; __hip_atomic_store(&P.ctrl->stop, 1, TB_RLX, TB_AGENT); }
-    if (must_stop) { bs.exhaustive = 0; sh.stop = 1; }
+    if (must_stop) { bs.exhaustive = 0; sh.stop = 1; bs.why |= 4 | (aborted ? 8 : 0) | ((P.cut_nodes != 0 && bs.nodes >= P.cut_nodes) ? 16 : 0); }
   }
   __syncthreads();
   if (sh.sol) {  // uniform
@@ -536,19 +577,21 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
 
 constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 255) / 256 * 256);
 
-template <int MEM, int TMAX>
-__global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox) {
+// The event-driven variant is latency bound: its 256-thread form asks the register allocator for 6 waves per
+// SIMD (<= 80 VGPRs) so that 6 workgroups are resident per CU; the sweep variants are VALU bound and keep 4.
+template <int MEM, int TMAX, bool EVENT>
+__global__ void __launch_bounds__(TMAX, 4) solve_kernel(DevProblem P, Mailbox* mbox) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, b = blockIdx.x, V = P.n_vars;
   // LDS: [control block][store: vext x int2 (STORE/TCN_SHARED)][dirty bitmaps: 3 x words][bytecodes (TCN_SHARED)]
   const int VX = P.vext;
   const size_t store_bytes = MEM >= TB_MEM_STORE_SHARED ? (((size_t)VX * 8 + 15) / 16) * 16 : 0;
-  const size_t dirty_bytes = (((size_t)P.dirty_words * 4 + 15) / 16) * 16 + (size_t)P.chg_cap * 16;
+  const size_t dirty_bytes = (((size_t)P.dirty_words * 4 + 15) / 16) * 16 + (((size_t)P.chg_cap * 4 + 15) / 16) * 16;
   int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : P.g_store + (size_t)b * VX;
   EventState es;
   es.dirty = reinterpret_cast<unsigned*>(smem + SH_BYTES + store_bytes);
-  es.list = reinterpret_cast<int2*>(smem + SH_BYTES + store_bytes + (((size_t)P.dirty_words * 4 + 15) / 16) * 16);
+  es.list = reinterpret_cast<int*>(smem + SH_BYTES + store_bytes + (((size_t)P.dirty_words * 4 + 15) / 16) * 16);
   es.unent = reinterpret_cast<unsigned char*>(store + V);
   es.words = P.dirty_words; es.cap = P.chg_cap;
   const int4* props = P.props;
@@ -568,9 +611,10 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
     for (int i = 0; i < TB_NUM_TIMERS; ++i) bs.timers[i] = 0;
     bs.nodes = bs.fails = bs.solutions = bs.fixpoint_iterations = bs.num_deductions = 0;
     bs.eps_solved = bs.eps_skipped = bs.store_writes = 0;
+    bs.why = 0; bs.pad_why = 0;
     bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
     sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0;
-    sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0;
+    sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0;
     sh.sub_idx = __hip_atomic_fetch_add(&P.ctrl->next_subproblem, 1ull, TB_RLX, TB_AGENT);
     t_start = t_mark = wall_clock64();
   }
@@ -580,7 +624,7 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
   while (sh.sub_idx < P.sub_hi && !sh.stop) {
     // C. restore the root
     copy_store(store, P.root_store, V);
-    if (P.fixpoint == 2 && tid == 0) sh.ev_all = 1;  // the root store is not a fixpoint: every slice runs once
+    if (EVENT && tid == 0) sh.ev_all = 1;  // the root store is not a fixpoint: every slice runs once
     long long t_dive = 0;
     if (tid == 0) {
       sh.cur_strategy = 0; sh.next_unassigned = 0; sh.depth = 0; sh.bot = 0;
@@ -591,16 +635,16 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
     __syncthreads();
     // D. dive: no objective bound while diving (gpu_dive_and_solve.hpp:370-372)
     while (sh.remaining > 0 && !sh.leaf && !sh.stop) {
-      propagate_node(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
+      propagate_node<EVENT>(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
       if (!sh.leaf && !sh.stop) {
         split(P, sh, dec, store);
         if (tid == 0) {
-          if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; }  // unsplittable infinite domains (barebones:688-694)
+          if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; bs.why |= 1; }  // unsplittable infinite domains (barebones:688-694)
           else {
             --sh.remaining;
             --sh.depth;  // decisions are not recorded while diving
             const int bit = (int)((sh.sub_idx >> sh.remaining) & 1ull);
-            embed0_mark(P, sh, es, store, &sh.bot, dec[0].var, dec[0].child[bit].x, dec[0].child[bit].y);
+            embed0_mark<EVENT>(P, sh, es, store, &sh.bot, dec[0].var, dec[0].child[bit].x, dec[0].child[bit].y);
           }
         }
       }
@@ -622,7 +666,7 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
       while (!sh.stop) {
         // I. tighten the objective with the incumbent (barebones:756-771)
         if (tid == 0 && P.obj_var >= 0) {
-          if (P.use_fixed_bound) embed0_mark(P, sh, es, store, &sh.bot, P.obj_var, NINF, P.fixed_bound);
+          if (P.use_fixed_bound) embed0_mark<EVENT>(P, sh, es, store, &sh.bot, P.obj_var, NINF, P.fixed_bound);
           else {
             int g = __hip_atomic_load(&P.ctrl->best_bound, TB_RLX, TB_AGENT);
             const int f = __hip_atomic_load(&P.ctrl->foreign_bound, TB_RLX, TB_AGENT);
@@ -630,14 +674,14 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
             g = sh.best_bound < g ? sh.best_bound : g;
             if (g != PINF) {
               if (g == NINF) { sh.stop = 1; __hip_atomic_store(&P.ctrl->gpu_stop, 1, TB_RLX, TB_AGENT); }  // unbounded objective
-              else embed0_mark(P, sh, es, store, &sh.bot, P.obj_var, NINF, g - 1);
+              else embed0_mark<EVENT>(P, sh, es, store, &sh.bot, P.obj_var, NINF, g - 1);
             }
           }
         }
         __syncthreads();
         if (sh.stop) break;
         // II. propagate
-        propagate_node(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
+        propagate_node<EVENT>(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
         if (sh.stop) break;
         // III. branch
         if (!sh.leaf) {
@@ -648,11 +692,11 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
           split(P, sh, dec, store);
           if (sh.stop) break;
           if (tid == 0) {
-            if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; }
+            if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; bs.why |= 2; }
             else {
               Decision& dd = dec[sh.depth - 1];
               const int c = ++dd.cur;
-              embed0_mark(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+              embed0_mark<EVENT>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
             }
           }
           __syncthreads();
@@ -676,13 +720,13 @@ __global__ void __launch_bounds__(TMAX) solve_kernel(DevProblem P, Mailbox* mbox
             const int2 ch = di.child[di.cur];
             raise_lb(store, di.var, ch.x);
             lower_ub(store, di.var, ch.y);
-            if (P.fixpoint == 2) note_change(sh, es, di.var);
+            if (EVENT) note_change(sh, es, di.var);
           }
           __syncthreads();
           if (tid == 0) {
             Decision& dd = dec[depth - 1];
             const int c = ++dd.cur;
-            embed0_mark(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+            embed0_mark<EVENT>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
             sh.cur_strategy = sh.snap_strategy;
             sh.next_unassigned = sh.snap_next_unassigned;
           }
@@ -733,17 +777,17 @@ struct PropagateOut {
   unsigned long long iterations, deductions, writes;
 };
 
-template <int MEM, int TMAX>
-__global__ void __launch_bounds__(TMAX) propagate_kernel(DevProblem P, int2* stores, PropagateOut* out, int n_stores) {
+template <int MEM, int TMAX, bool EVENT>
+__global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* stores, PropagateOut* out, int n_stores) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, V = P.n_vars;
   const int VX = P.vext;
   const size_t store_bytes = MEM >= TB_MEM_STORE_SHARED ? (((size_t)VX * 8 + 15) / 16) * 16 : 0;
-  const size_t dirty_bytes = (((size_t)P.dirty_words * 4 + 15) / 16) * 16 + (size_t)P.chg_cap * 16;
+  const size_t dirty_bytes = (((size_t)P.dirty_words * 4 + 15) / 16) * 16 + (((size_t)P.chg_cap * 4 + 15) / 16) * 16;
   EventState es;
   es.dirty = reinterpret_cast<unsigned*>(smem + SH_BYTES + store_bytes);
-  es.list = reinterpret_cast<int2*>(smem + SH_BYTES + store_bytes + (((size_t)P.dirty_words * 4 + 15) / 16) * 16);
+  es.list = reinterpret_cast<int*>(smem + SH_BYTES + store_bytes + (((size_t)P.dirty_words * 4 + 15) / 16) * 16);
   es.words = P.dirty_words; es.cap = P.chg_cap;
   for (int i = tid; i < P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
   const int4* props = P.props;
@@ -765,8 +809,11 @@ __global__ void __launch_bounds__(TMAX) propagate_kernel(DevProblem P, int2* sto
     __syncthreads();
     bool all_entailed = false;
     int iters = 0;
-    if (P.fixpoint == 2) { if (tid == 0) { sh.ev_all = 1; sh.chg_count[0] = 0; sh.chg_count[1] = 0; } __syncthreads(); }
-    if (!ld(&sh.bot)) iters = P.fixpoint == 2 ? fixpoint_event(P, sh, store, props, es, tc, all_entailed) : fixpoint(P, sh, store, props, tc, all_entailed);
+    if (EVENT) { if (tid == 0) { sh.ev_all = 1; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; } __syncthreads(); }
+    if (!ld(&sh.bot)) {
+      if constexpr (EVENT) iters = fixpoint_event(P, sh, store, props, es, tc, all_entailed);
+      else iters = fixpoint(P, sh, store, props, tc, all_entailed);
+    }
     if (MEM >= TB_MEM_STORE_SHARED) copy_store(gstore, store, V);
     unsigned long long w = tc.writes, d = tc.deductions;
     for (int off = 32; off > 0; off >>= 1) { w += __shfl_xor(w, off, 64); d += __shfl_xor(d, off, 64); }
