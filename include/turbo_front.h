@@ -55,6 +55,24 @@ int64_t tf_objective_of(const tf_model* m, const tb_itv* store);
  * `----------` separator.  Returns the number of bytes needed (excluding NUL). */
 int32_t tf_format_solution(const tf_model* m, const tb_itv* store, char* buf, int32_t buf_len);
 
+/*
+ * TCN simplifier: the preprocessing loop of common_solving.hpp:537-585 (root fixpoint -> equivalence classes,
+ * algebraic simplification, entailed-constraint elimination, common subexpressions, useless variables), in place.
+ * `root_fixpoint` is the propagated root store of the CURRENT network (tf_num_vars entries) computed by the caller
+ * (the GPU engine: `tb_propagate`), or NULL.  May be called repeatedly (propagate, simplify, propagate, ...).
+ * stats_out (may be NULL) receives 9 int32: original vars/props, simplified vars/props, merged variables,
+ * common-subexpression merges, entailed propagators, duplicate propagators, eliminated variables.
+ * After the call tf_store/tf_props/... describe the simplified network; tf_format_solution / tf_objective_of /
+ * tf_expand_solution take solutions of the simplified network.
+ */
+int32_t tf_simplify(tf_model* m, const tb_itv* root_fixpoint, int32_t* stats_out);
+int32_t tf_original_num_vars(const tf_model* m);
+int32_t tf_original_num_props(const tf_model* m);
+const tb_itv* tf_original_store(const tf_model* m);
+const tb_prop* tf_original_props(const tf_model* m);
+/* solution of the current network -> store over the variables of the network as first lowered */
+int32_t tf_expand_solution(const tf_model* m, const tb_itv* store, tb_itv* original_out);
+
 /* name of a TCN variable ("" for temporaries), for debugging */
 const char* tf_var_name(const tf_model* m, int32_t var);
 

@@ -91,7 +91,37 @@ int64_t tf_objective_of(const tf_model* m, const tb_itv* store) {
   return m->tcn.goal == 2 ? d.ub : d.lb;
 }
 
-int32_t tf_format_solution(const tf_model* m, const tb_itv* store, char* buf, int32_t buf_len) {
+int32_t tf_simplify(tf_model* m, const tb_itv* root_fixpoint, int32_t* stats_out) {
+  SimplifyInfo info;
+  try {
+    simplify_tcn(m->tcn, root_fixpoint, &info);
+  } catch (const std::exception&) {
+    return -1;
+  }
+  if (stats_out) {
+    const int32_t v[9] = {info.original_vars, info.original_props, info.simplified_vars, info.simplified_props, info.merged_variables,
+                          info.cse_merges, info.entailed_props, info.duplicate_props, info.eliminated_variables};
+    std::memcpy(stats_out, v, sizeof(v));
+  }
+  return 0;
+}
+int32_t tf_original_num_vars(const tf_model* m) { return (int32_t)(m->tcn.simplified ? m->tcn.original_store.size() : m->tcn.store.size()); }
+int32_t tf_original_num_props(const tf_model* m) { return (int32_t)(m->tcn.simplified ? m->tcn.original_props.size() : m->tcn.props.size()); }
+const tb_itv* tf_original_store(const tf_model* m) { return m->tcn.simplified ? m->tcn.original_store.data() : m->tcn.store.data(); }
+const tb_prop* tf_original_props(const tf_model* m) { return m->tcn.simplified ? m->tcn.original_props.data() : m->tcn.props.data(); }
+int32_t tf_expand_solution(const tf_model* m, const tb_itv* store, tb_itv* original_out) {
+  expand_solution(m->tcn, store, original_out);
+  return 0;
+}
+
+int32_t tf_format_solution(const tf_model* m, const tb_itv* store_in, char* buf, int32_t buf_len) {
+  std::vector<tb_itv> expanded;
+  const tb_itv* store = store_in;
+  if (m->tcn.simplified) {  // output items name variables of the network as first lowered
+    expanded.resize(m->tcn.original_store.size());
+    expand_solution(m->tcn, store_in, expanded.data());
+    store = expanded.data();
+  }
   std::string out;
   for (const OutputItem& o : m->tcn.outputs) {
     if (!o.is_array) {

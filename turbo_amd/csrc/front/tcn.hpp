@@ -32,6 +32,7 @@ struct Strategy {
   int32_t var_order = TB_INPUT_ORDER;
   int32_t val_order = TB_VAL_MIN;
   std::vector<int32_t> vars;  // empty = whole store
+  bool emptied = false;       // simplifier: every variable of the strategy was eliminated
 };
 
 struct TCN {
@@ -46,6 +47,13 @@ struct TCN {
   bool trivially_unsat = false;
   int32_t parsed_variables = 0, parsed_constraints = 0;
 
+  // simplifier state: the network as first lowered, and how to expand a solution of the current network to it
+  bool simplified = false;
+  std::vector<tb_itv> original_store;
+  std::vector<tb_prop> original_props;
+  std::vector<int32_t> expand_var;    // original variable -> current variable, or -1
+  std::vector<int32_t> expand_const;  // value of an eliminated original variable
+
   // flattened strategy arrays (rebuilt by flatten_strategies)
   std::vector<int32_t> f_var_order, f_val_order, f_off, f_vars;
   void flatten_strategies();
@@ -56,5 +64,15 @@ struct LowerError : std::runtime_error {
 };
 
 TCN lower_to_tcn(const Model& m);
+
+struct SimplifyInfo {
+  int32_t original_vars = 0, original_props = 0, simplified_vars = 0, simplified_props = 0;
+  int32_t merged_variables = 0, cse_merges = 0, entailed_props = 0, duplicate_props = 0, eliminated_variables = 0;
+};
+// In-place simplification (simplify.cpp).  `root_fixpoint` (may be null) is the propagated root store of the
+// CURRENT network, computed by the caller.
+void simplify_tcn(TCN& t, const tb_itv* root_fixpoint, SimplifyInfo* info);
+// Solution of the current network -> store over the variables of the network as first lowered.
+void expand_solution(const TCN& t, const tb_itv* simplified, tb_itv* original_out);
 
 }  // namespace turbo_front

@@ -51,6 +51,16 @@ def lib() -> C.CDLL:
         L.tf_objective_of.argtypes = [C.c_void_p, C.c_void_p]
         L.tf_format_solution.restype = C.c_int32
         L.tf_format_solution.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32]
+        L.tf_simplify.restype = C.c_int32
+        L.tf_simplify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        for name in ("tf_original_num_vars", "tf_original_num_props"):
+            getattr(L, name).restype = C.c_int32
+            getattr(L, name).argtypes = [C.c_void_p]
+        for name in ("tf_original_store", "tf_original_props"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.tf_expand_solution.restype = C.c_int32
+        L.tf_expand_solution.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.tf_var_name.restype = C.c_char_p
         L.tf_var_name.argtypes = [C.c_void_p, C.c_int32]
         _lib = L
@@ -159,6 +169,33 @@ class Model:
             parsed_variables=L.tf_parsed_variables(h), parsed_constraints=L.tf_parsed_constraints(h),
             _model=self,
         )
+
+    def simplify(self, root_fixpoint: np.ndarray | None = None) -> dict:
+        """TCN simplifier (common_solving.hpp:537-585).  `root_fixpoint`: propagated root store of the CURRENT
+        network, computed by the caller (GPU engine in production).  Returns the statistics."""
+        stats = (C.c_int32 * 9)()
+        ptr = None
+        if root_fixpoint is not None:
+            root_fixpoint = np.ascontiguousarray(root_fixpoint, dtype=ITV_DTYPE)
+            assert root_fixpoint.shape[0] == lib().tf_num_vars(self._h)
+            ptr = root_fixpoint.ctypes.data
+        if lib().tf_simplify(self._h, ptr, stats) != 0:
+            raise RuntimeError("tf_simplify failed")
+        keys = ["original_vars", "original_props", "simplified_vars", "simplified_props", "merged_variables",
+                "cse_merges", "entailed_props", "duplicate_props", "eliminated_variables"]
+        return dict(zip(keys, (int(x) for x in stats)))
+
+    def original_network(self):
+        """(store, props) of the network as first lowered (what solutions are expanded back to)."""
+        L, h = lib(), self._h
+        return (_copy(L.tf_original_store(h), L.tf_original_num_vars(h), ITV_DTYPE),
+                _copy(L.tf_original_props(h), L.tf_original_num_props(h), PROP_DTYPE))
+
+    def expand_solution(self, store: np.ndarray) -> np.ndarray:
+        store = np.ascontiguousarray(store, dtype=ITV_DTYPE)
+        out = np.zeros(lib().tf_original_num_vars(self._h), dtype=ITV_DTYPE)
+        lib().tf_expand_solution(self._h, store.ctypes.data, out.ctypes.data)
+        return out
 
     def format_solution(self, store: np.ndarray) -> str:
         store = np.ascontiguousarray(store, dtype=ITV_DTYPE)
