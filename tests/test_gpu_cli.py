@@ -25,6 +25,26 @@ def test_regression_script_contract(rel, expected):
     assert "==========" in r.stdout and "----------" in r.stdout
 
 
+@pytest.mark.parametrize("rel,expected", [r for r in known_answers() if r[0].split("/")[-1] in
+                                          ("pennies5.fzn", "bug2.fzn", "pat8.fzn", "sudoku_opt_p0.fzn", "maximize_unconstrained.fzn")])
+def test_simplifier_can_be_disabled(rel, expected):
+    outs = {}
+    for extra in ([], ["-disable_simplify"]):
+        r = subprocess.run([TURBO, "-arch", "barebones", "-s", "-t", "60000", *extra, os.path.join(BENCH, rel)],
+                           capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, r.stderr
+        assert int(re.search(r"objective=(-?\d+)", r.stdout).group(1)) == expected
+        assert "==========" in r.stdout
+        outs[bool(extra)] = r.stdout
+    assert "preprocessed_tcn_variables=" in outs[False] and "preprocessing_eliminated_variables=" in outs[False]
+    assert "preprocessed_tcn_variables=" not in outs[True]
+    tcn_v = int(re.search(r"mzn-stat: tcn_variables=(\d+)", outs[False]).group(1))
+    pre_v = int(re.search(r"preprocessed_tcn_variables=(\d+)", outs[False]).group(1))
+    assert pre_v <= tcn_v
+    assert int(re.search(r"mzn-stat: variables=(\d+)", outs[False]).group(1)) == pre_v
+    assert int(re.search(r"mzn-stat: variables=(\d+)", outs[True]).group(1)) == tcn_v
+
+
 def test_output_format_and_gpu_arch_alias():
     r = subprocess.run([TURBO, "-arch", "gpu", "-s", "-t", "30000", os.path.join(BENCH, "test_data", "sudoku_opt2.fzn")],
                        capture_output=True, text=True, timeout=120)

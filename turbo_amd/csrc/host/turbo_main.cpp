@@ -112,6 +112,45 @@ tb_config make_config(const Options& o, bool has_eps) {
   return c;
 }
 
+std::string array_text(const std::vector<int32_t>& v) {  // statistics.hpp:31-43
+  std::string s = "[";
+  for (size_t i = 0; i < v.size(); ++i) s += (i ? ", " : "") + std::to_string(v[i]);
+  return s + "]";
+}
+
+// The preprocessing loop of common_solving.hpp:537-585: root fixpoint (on the GPU, `tb_propagate`), then the
+// network simplifier, until neither changes anything.  The propagators are not restated on the host.
+bool simplify_network(const Options& o, const Printer& p, tf_model* m, std::string& err) {
+  std::vector<int32_t> icse, algsimp, algsimp_eq, entailed, useless;
+  tb_config c;
+  std::memset(&c, 0, sizeof(c));
+  c.fixpoint = 1; c.only_global_memory = o.only_global_memory; c.verbose = 0; c.world_size = 1;
+  for (int round = 0; round < 16 && !tf_trivially_unsat(m); ++round) {
+    const int n_vars = tf_num_vars(m), n_props = tf_num_props(m);
+    std::vector<tb_itv> root(tf_store(m), tf_store(m) + n_vars);
+    if (n_props > 0) {
+      int32_t failed = 0;
+      const int rc = tb_propagate(&c, n_vars, n_props, tf_props(m), 1, root.data(), &failed, nullptr, nullptr, nullptr, nullptr);
+      if (rc != TB_OK) { err = tb_last_error(); return false; }
+    }
+    int32_t st[9];
+    if (tf_simplify(m, root.data(), st) != 0) { err = "the network simplifier failed"; return false; }
+    icse.push_back(st[5]); algsimp.push_back(st[7]); algsimp_eq.push_back(st[4]); entailed.push_back(st[6]); useless.push_back(st[8]);
+    if (st[4] == 0 && st[5] == 0 && st[6] == 0 && st[7] == 0 && st[8] == 0) break;
+  }
+  p.s("preprocessing_icse_eliminated_constraints", array_text(icse).c_str());
+  p.s("preprocessing_algsimp_eliminated_constraints", array_text(algsimp).c_str());
+  p.s("preprocessing_algsimp_eliminated_eq_constraints", array_text(algsimp_eq).c_str());
+  p.s("preprocessing_entailment_eliminated_constraints", array_text(entailed).c_str());
+  p.s("preprocessing_eliminated_variables", array_text(useless).c_str());
+  if (o.verbose) std::printf("%% Formula simplified.\n");
+  if (!tf_trivially_unsat(m)) {
+    p.u("preprocessed_tcn_variables", (uint64_t)tf_num_vars(m));
+    p.u("preprocessed_tcn_constraints", (uint64_t)tf_num_props(m));
+  }
+  return true;
+}
+
 // N GPUs of the node: one session per device, this thread relays the incumbent bound and the stop flag.
 int solve_multi_gpu(const Options& o, const tb_config& base, const tf_model* m, std::vector<tb_itv>& best, int32_t* has, tb_stats* out) {
   const int G = o.gpus;
@@ -169,7 +208,7 @@ int main(int argc, char** argv) {
   if (o.print_intermediate_solutions) std::printf("%% WARNING: -arch %s is incompatible with -i and -a (it cannot print intermediate solutions).\n", name_of(o.arch));
   const auto start = Clock::now();
 
-  // preprocess (common_solving.hpp:605-637, -disable_simplify pipeline)
+  // preprocess (common_solving.hpp:605-637)
   const bool is_fzn = o.problem_path.size() >= 4 && o.problem_path.compare(o.problem_path.size() - 4, 4, ".fzn") == 0;
   if (!is_fzn) {
     std::printf("ERROR: Unknown input format for the file %s [supported extension: .fzn].\n", o.problem_path.c_str());
@@ -181,6 +220,21 @@ int main(int argc, char** argv) {
     std::cerr << "Could not parse input file." << std::endl;
     if (o.verbose) std::cerr << err << std::endl;
     return EXIT_FAILURE;
+  }
+  p.u("parsed_variables", (uint64_t)tf_parsed_variables(m));
+  p.u("parsed_constraints", (uint64_t)tf_parsed_constraints(m));
+  p.s("abstract_domain", "pir_itv32_z");
+  p.s("entailed_prop_removal", "deactivated");
+  p.u("tcn_variables", (uint64_t)tf_num_vars(m));
+  p.u("tcn_constraints", (uint64_t)tf_num_props(m));
+  if (!o.disable_simplify && !tf_trivially_unsat(m)) {
+    std::string err_text;
+    if (!simplify_network(o, p, m, err_text)) {
+      std::cout.flush();
+      std::cerr << "\n\tUnexpected exception:\n\t" << err_text << std::endl;
+      tf_free(m);
+      return EXIT_FAILURE;
+    }
   }
   bool has_eps = false;
   if (o.eps_var_order != "default") {
@@ -197,12 +251,6 @@ int main(int argc, char** argv) {
   }
   const int n_vars = tf_num_vars(m), n_props = tf_num_props(m);
   const int64_t preprocessing_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - start).count();
-  p.u("parsed_variables", (uint64_t)tf_parsed_variables(m));
-  p.u("parsed_constraints", (uint64_t)tf_parsed_constraints(m));
-  p.s("abstract_domain", "pir_itv32_z");
-  p.s("entailed_prop_removal", "deactivated");
-  p.u("tcn_variables", (uint64_t)n_vars);
-  p.u("tcn_constraints", (uint64_t)n_props);
   p.d("preprocessing_time", to_sec(preprocessing_ns));
   p.end();
 

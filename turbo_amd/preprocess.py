@@ -9,7 +9,7 @@ from __future__ import annotations
 from . import capi, frontend
 
 
-def load_fzn_simplified(path: str, rounds: int = 3, eps_var_order: str = "default", eps_value_order: str = "default",
+def load_fzn_simplified(path: str, rounds: int = 16, eps_var_order: str = "default", eps_value_order: str = "default",
                         propagate=None):
     """Returns (model, tcn, stats).  `propagate(store, props) -> (store, failed)` defaults to the GPU engine."""
     m = frontend.Model.from_file(path)
@@ -30,7 +30,7 @@ def load_fzn_simplified(path: str, rounds: int = 3, eps_var_order: str = "defaul
             break
         st = m.simplify(root)
         stats.append(st)
-        if st["merged_variables"] == 0 and st["entailed_props"] == 0 and st["eliminated_variables"] == 0:
+        if not any(st[k] for k in ("merged_variables", "cse_merges", "entailed_props", "duplicate_props", "eliminated_variables")):
             break
     if eps_var_order != "default":
         m.push_eps_strategy(eps_var_order, eps_value_order)
