@@ -12,4 +12,4 @@ for fp in (2,):
     t = st["timers_ns"]
     n = st["nodes"]
     print(f"{name} fp={fp}: nodes={n} ({n/(st['kernel_ns']*1e-9):.3e}/s) sweeps/node={st['fixpoint_iterations']/n:.1f} props/node={st['num_deductions']/n:.0f} "
-          f"fix%={t[3]/tot:.2f} search%={t[2]/tot:.2f} own_work%={t[4]/tot:.2f} barrier_wait%={t[5]/tot:.2f} dive%={t[8]/tot:.2f}  us/node/block={tot/n*1e-3:.1f}")
+          f"fix%={t[3]/tot:.2f} search%={t[2]/tot:.2f} own_work%={t[4]/tot:.2f} barrier_wait%={t[5]/tot:.2f} dive%={t[8]/tot:.2f} snap_push%={t[1]/tot:.2f} split%={t[6]/tot:.2f} us/node/block={tot/n*1e-3:.1f}")

@@ -94,7 +94,9 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, int n_vars, int n_
   p.threads = T;
   p.tmax = T <= 256 ? 256 : 1024;
   const size_t lds = (size_t)caps.lds_per_cu;
-  const int n_slices = (n_props + 63) / 64, dirty_words = (n_slices + 31) / 32, vext = n_vars + (n_slices + 7) / 8;
+  // slab = domains + one entailment byte per slice, rounded to an even number of intervals so that every slab of a
+  // stack (stores, snapshots) starts 16-byte aligned and copies as 16-byte words
+  const int n_slices = (n_props + 63) / 64, dirty_words = (n_slices + 31) / 32, vext = (n_vars + (n_slices + 7) / 8 + 1) & ~1;
   p.n_slices = n_slices; p.dirty_words = dirty_words; p.vext = vext;
   // store slab = domains + one entailment byte per 64-propagator slice; the three dirty bitmaps of the
   // event-driven fixpoint always live in LDS
@@ -112,7 +114,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, int n_vars, int n_
     p.mem_kind = TB_MEM_TCN_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b + props_b);
   } else if ((fixed + store_b) * (size_t)bpc_max <= lds) {
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b);
-  } else if (fixed + store_b <= lds && !(event && (int)(lds / (fixed + store_b)) < 4)) {
+  } else if (fixed + store_b <= lds && !(event && (int)(lds / (fixed + store_b)) < 4 && !(cfg.reserved[0] & 0x40000))) {
     // (event mode: a store that leaves fewer than 4 workgroups per CU goes to global memory instead --
     //  measured 1.2-1.5x more nodes/s on wordpress7_500 / trains15 with 8 x 256-thread workgroups per CU)
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / (fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);

@@ -283,11 +283,16 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   // ---- initial dirty set: everything, or the slices of the variables changed since the last fixpoint
   const int cnt = ld(&sh.chg_count[0]);
   const bool all = ld(&sh.ev_all) != 0 || cnt > es.cap;
+  // Entailed-slice removal: a slice whose 64 propagators were all entailed when it last ran stays entailed in the
+  // whole subtree (domains only shrink), so it is dropped when claimed.  The bytes are undefined before the root pass.
+  const bool root_pass = ld(&sh.ev_all) != 0;
+  const bool drop_entailed = !root_pass && !(P.debug & 0x20000);
   if (all) {
     for (int i = tid; i < W; i += T) {
       const int left = S - i * 32;
       es.dirty[i] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
     }
+    if (root_pass) for (int s = tid; s < S; s += T) es.unent[s] = 1;  // nothing is known to be entailed yet
   } else {
     for (int e = tid; e < cnt; e += T) {  // one lane per entry; long lists are finished cooperatively
       const int4 h = P.adj_head[es.list[e]];
@@ -322,6 +327,10 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     const bool act = i < n;
     int4 pr = idle_record();
     if (act) pr = props[i];
+    if (drop_entailed && es.unent[s] == 0) {
+      if (lane == 0) (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG);
+      continue;
+    }
     int4 hx = make_int4(0, 0, 0, 0), hy = hx, hz = hx;  // adjacency heads of my three operands, loaded on first use
     int have = 0;
     for (;;) {
@@ -330,8 +339,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       apply<true>(pr, act, store, &sh.bot, ch, un_i, tc, 0, &nar);
       if (lane == 0) tc.deductions += 64;
       if (!__any(ch)) {
-        const bool any_un = __any(un_i);
-        if (lane == 0) es.unent[s] = any_un ? 1 : 0;
+        // The byte only ever goes 1 -> 0 below a node (entailment is monotone): two waves may run the same slice
+        // at once, and the one that read the older domains must not overwrite the verdict of the other.
+        if (!__any(un_i) && lane == 0) es.unent[s] = 0;
         break;
       }
       // successors: every other slice reading a variable I narrowed (operands private to this slice are
@@ -340,6 +350,8 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       if ((nar & 1) && !(have & 1)) { hx = P.adj_head[pr.y]; have |= 1; }
       if ((nar & 2) && !(have & 2)) { hy = P.adj_head[pr.z]; have |= 2; }
       if ((nar & 4) && !(have & 4)) { hz = P.adj_head[pr.w]; have |= 4; }
+      // my narrowings are performed (global-memory atomics included) before any slice I mark can be claimed
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       const bool lx = (nar & 1) && mark_head(es.dirty, hx, s);
       const bool ly = (nar & 2) && mark_head(es.dirty, hy, s);
       const bool lz = (nar & 4) && mark_head(es.dirty, hz, s);
@@ -347,7 +359,6 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       if (mx) mark_rest(P, es.dirty, mx, hx, s);
       if (my) mark_rest(P, es.dirty, my, hy, s);
       if (mz) mark_rest(P, es.dirty, mz, hz, s);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       if (ld(&sh.bot)) break;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my marks are visible before I stop being busy
@@ -369,8 +380,25 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
 
 // ---- small helpers -------------------------------------------------------------------------------
 
+// Block-wide copy of n intervals.  Both sides are 16-byte aligned (slabs are laid out in multiples of 2
+// intervals), so the body moves 16 B per lane with four independent loads in flight: a snapshot of a
+// 25k-variable store is ~12 memory round trips per thread instead of ~100.
 __device__ __forceinline__ void copy_store(int2* dst, const int2* src, int n) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+  const int T = blockDim.x, tid = threadIdx.x;
+  if ((reinterpret_cast<size_t>(dst) | reinterpret_cast<size_t>(src)) & 15) {  // odd-sized caller buffers (best store, tb_propagate batches)
+    for (int i = tid; i < n; i += T) dst[i] = src[i];
+    return;
+  }
+  const int n4 = n >> 1;
+  int4* d4 = reinterpret_cast<int4*>(dst);
+  const int4* s4 = reinterpret_cast<const int4*>(src);
+  int i = tid;
+  for (; i + 3 * T < n4; i += 4 * T) {
+    const int4 a = s4[i], b = s4[i + T], c = s4[i + 2 * T], d = s4[i + 3 * T];
+    d4[i] = a; d4[i + T] = b; d4[i + 2 * T] = c; d4[i + 3 * T] = d;
+  }
+  for (; i < n4; i += T) d4[i] = s4[i];
+  if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
@@ -454,13 +482,29 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
     const int vo = P.strat_var_order[s];
     unsigned long long best = ~0ull;
     int first = n;
-    for (int i = sh.next_unassigned + tid; i < n; i += T) {
-      const int v = in_store ? i : P.strat_vars[off + i];
-      const Itv d = load_dom(store, v);
-      if (d.lb != d.ub && !is_inf(d.lb) && !is_inf(d.ub)) {
-        const unsigned long long key = ((unsigned long long)order_key(vo, d) << 32) | (unsigned)i;
-        best = key < best ? key : best;
-        first = i < first ? i : first;
+    // four candidates per thread and round: the index gathers, then the domain gathers, are issued together
+    // (a store in global memory costs one L2 round trip per dependent load, not per variable)
+    for (int i0 = sh.next_unassigned + tid; i0 < n; i0 += 4 * T) {
+      int v[4];
+      Itv d[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * T;
+        v[k] = i < n ? (in_store ? i : P.strat_vars[off + i]) : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d[k] = Itv{0, 0};
+        if (v[k] >= 0) d[k] = load_dom(store, v[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * T;
+        if (d[k].lb != d[k].ub && !is_inf(d[k].lb) && !is_inf(d[k].ub)) {
+          const unsigned long long key = ((unsigned long long)order_key(vo, d[k]) << 32) | (unsigned)i;
+          best = key < best ? key : best;
+          first = i < first ? i : first;
+        }
       }
     }
     best = wave_min_u64(best);
@@ -686,10 +730,15 @@ __global__ void __launch_bounds__(TMAX, 4) solve_kernel(DevProblem P, Mailbox* m
         // III. branch
         if (!sh.leaf) {
           const int d0 = sh.depth;
+          const bool prof = (P.debug & 0x10000) != 0;
+          long long tp = 0;
+          if (prof && tid == 0) tp = wall_clock64();
           if (d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * VX, store, VX);  // d0 == 0: barebones:785-791
           if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
           __syncthreads();
+          if (prof && tid == 0) { const long long t = wall_clock64(); bs.timers[TB_T_PREPROCESSING] += t - tp; tp = t; }  // profiling: snapshot push
           split(P, sh, dec, store);
+          if (prof && tid == 0) bs.timers[TB_T_SELECT_FP_FUNCTIONS] += wall_clock64() - tp;  // profiling: variable selection
           if (sh.stop) break;
           if (tid == 0) {
             if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; bs.why |= 2; }
