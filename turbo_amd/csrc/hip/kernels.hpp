@@ -624,7 +624,10 @@ constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 255) / 256 * 256);
 // The event-driven variant is latency bound: its 256-thread form asks the register allocator for 6 waves per
 // SIMD (<= 80 VGPRs) so that 6 workgroups are resident per CU; the sweep variants are VALU bound and keep 4.
 template <int MEM, int TMAX, bool EVENT>
-__global__ void __launch_bounds__(TMAX, 4) solve_kernel(DevProblem P, Mailbox* mbox) {
+#ifndef TB_EVENT_WAVES
+#define TB_EVENT_WAVES 6
+#endif
+__global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES : 4) solve_kernel(DevProblem P, Mailbox* mbox) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, b = blockIdx.x, V = P.n_vars;
