@@ -71,7 +71,8 @@ typedef struct {
   int32_t deterministic;            /* tb_solve only: after B&B, run the canonical pass so the returned solution is the
                                        DFS-first optimal one (bit-identical to the sequential oracle) */
   int32_t snapshot_levels;          /* per-workgroup snapshot stack depth in HBM; 0 = auto, 1 = reference behaviour (recompute from subproblem root) */
-  int32_t reserved[3];
+  int32_t stream_solutions;         /* sessions only: hand solutions to the host while the kernel runs (tb_session_next_solution) */
+  int32_t reserved[4];
 } tb_config;
 
 /* Statistics<> (include/statistics.hpp:134-154) + TimingStatistics (statistics.hpp:13-29). */
@@ -157,6 +158,16 @@ int tb_session_start(tb_session* s);
 int tb_session_poll(tb_session* s, int32_t* local_best_out, int32_t* done_out);
 int tb_session_push_bound(tb_session* s, int32_t bound);
 int tb_session_stop(tb_session* s);
+/*
+ * Solution streaming (cfg.stream_solutions = 1), the producer/consumer protocol of the reference's `gpu` path
+ * (gpu_dive_and_solve.hpp:100-132,334-345: `-i`, `-a`, satisfaction `-n k`) over a ring of pinned host buffers:
+ * every solution of a satisfaction problem (at most stop_after_n_solutions of them), and every solution that improves
+ * the device-wide incumbent of an optimisation problem, is handed over while the kernel runs.  A workgroup waits for
+ * a free slot, so the caller drains the ring while polling, and once more after `done`.
+ * *has_out = 1: store_out (n_vars intervals) holds the next solution, *objective_out its objective (lb of obj_var).
+ * Solutions of concurrent workgroups may arrive out of objective order; a printer keeps the improving ones.
+ */
+int tb_session_next_solution(tb_session* s, tb_itv* store_out, int32_t* objective_out, int32_t* has_out);
 int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_solution_out, tb_stats* stats_out);
 void tb_session_destroy(tb_session* s);
 

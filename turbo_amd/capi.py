@@ -23,7 +23,7 @@ TIMERS = ["OVERALL", "PREPROCESSING", "SEARCH", "FIXPOINT", "TRANSFER_CPU2GPU", 
 
 EXPORTS = ["tb_version", "tb_last_error", "tb_device_count", "tb_get_device_info", "tb_eps_slice", "tb_propagate", "tb_solve",
            "tb_session_create", "tb_session_start", "tb_session_poll", "tb_session_push_bound",
-           "tb_session_stop", "tb_session_finish", "tb_session_destroy"]
+           "tb_session_stop", "tb_session_next_solution", "tb_session_finish", "tb_session_destroy"]
 
 
 class TbConfig(C.Structure):
@@ -34,7 +34,7 @@ class TbConfig(C.Structure):
                 ("verbose", C.c_int32), ("has_eps_strategy", C.c_int32), ("threads_per_block", C.c_int32),
                 ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
                 ("use_fixed_bound", C.c_int32), ("fixed_bound", C.c_int32), ("deterministic", C.c_int32),
-                ("snapshot_levels", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("snapshot_levels", C.c_int32), ("stream_solutions", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class TbStats(C.Structure):
@@ -105,6 +105,8 @@ def lib() -> C.CDLL:
         L.tb_session_poll.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.tb_session_push_bound.restype = C.c_int
         L.tb_session_push_bound.argtypes = [C.c_void_p, C.c_int32]
+        L.tb_session_next_solution.restype = C.c_int
+        L.tb_session_next_solution.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.tb_session_finish.restype = C.c_int
         L.tb_session_finish.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(TbStats)]
         L.tb_session_destroy.restype = None
@@ -214,6 +216,13 @@ class Session:
 
     def stop(self) -> None:
         check(lib().tb_session_stop(self._h))
+
+    def next_solution(self):
+        """Streaming (cfg.stream_solutions=1): (store, objective) of the next solution handed over, or None."""
+        out = np.zeros(max(self._n_vars, 1), dtype=ITV_DTYPE)
+        obj, has = C.c_int32(0), C.c_int32(0)
+        check(lib().tb_session_next_solution(self._h, out.ctypes.data, C.byref(obj), C.byref(has)))
+        return (out[:self._n_vars], obj.value) if has.value else None
 
     def finish(self):
         best = np.zeros(max(self._n_vars, 1), dtype=ITV_DTYPE)

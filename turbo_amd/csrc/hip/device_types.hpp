@@ -27,6 +27,17 @@ struct Ctrl {
   int blocks_done;                     // number of workgroups that left the kernel
   int error;                           // device-side error code (decision stack overflow ...)
   unsigned long long solutions;        // satisfaction: global solution counter for -n
+  unsigned long long sol_ticket;       // streaming: next sequence number of the solution ring
+};
+
+// Solution ring in pinned host memory (streaming, gpu_dive_and_solve.hpp:100-132 re-done without a print lock):
+// a producer takes a ticket, waits until `ticket - consumed < slots`, copies its store into slot ticket % slots and
+// publishes seq[slot] = ticket + 1; the host consumes in ticket order.
+struct SolutionRing {
+  unsigned long long* consumed;  // host -> device: number of solutions the host has taken
+  unsigned long long* seq;       // [slots] device -> host
+  int2* data;                    // [slots][n_vars]
+  int slots;                     // 0 = streaming off
 };
 
 // Per-workgroup statistics (Statistics<>, statistics.hpp:134-154), reduced on the host.
@@ -76,6 +87,7 @@ struct DevProblem {
   Decision* g_dec;   // [B][max_depth]
   BlockStats* g_stats;
   Ctrl* ctrl;
+  SolutionRing ring;
 };
 
 }  // namespace tb

@@ -303,6 +303,10 @@ struct tb_session {
   DevBuffers bufs;
   Mailbox* mbox_host = nullptr;
   Mailbox* mbox_dev = nullptr;
+  // solution ring (streaming): one pinned host block = [consumed | seq[slots] | data[slots][n_vars]]
+  unsigned char* ring_host = nullptr;
+  int ring_slots = 0;
+  unsigned long long ring_next = 0;  // next ticket the host expects
   hipStream_t stream = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int32_t n_vars = 0, obj_var = -1;
@@ -315,7 +319,11 @@ struct tb_session {
     if (ev_stop) (void)hipEventDestroy(ev_stop);
     if (stream) (void)hipStreamDestroy(stream);
     if (mbox_host) (void)hipHostFree(mbox_host);
+    if (ring_host) (void)hipHostFree(ring_host);
   }
+  unsigned long long* ring_consumed() const { return reinterpret_cast<unsigned long long*>(ring_host); }
+  unsigned long long* ring_seq() const { return reinterpret_cast<unsigned long long*>(ring_host + 64); }
+  tb_itv* ring_data() const { return reinterpret_cast<tb_itv*>(ring_host + 64 + align16((size_t)ring_slots * 8)); }
 };
 
 extern "C" {
@@ -541,6 +549,18 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->mbox_host), sizeof(Mailbox), hipHostMallocMapped));
   s->mbox_host->stop = 0; s->mbox_host->foreign_bound = TB_PINF; s->mbox_host->local_best = TB_PINF; s->mbox_host->pad = 0;
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->mbox_dev), s->mbox_host, 0));
+  if (s->cfg.stream_solutions && !s->cfg.use_fixed_bound) {
+    s->ring_slots = 8;
+    const size_t bytes = 64 + align16((size_t)s->ring_slots * 8) + (size_t)s->ring_slots * std::max<size_t>(1, V) * sizeof(tb_itv);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->ring_host), bytes, hipHostMallocMapped));
+    std::memset(s->ring_host, 0, bytes);
+    unsigned char* dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), s->ring_host, 0));
+    P.ring.consumed = reinterpret_cast<unsigned long long*>(dev);
+    P.ring.seq = reinterpret_cast<unsigned long long*>(dev + 64);
+    P.ring.data = reinterpret_cast<int2*>(dev + 64 + align16((size_t)s->ring_slots * 8));
+    P.ring.slots = s->ring_slots;
+  }
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&s->ev_start));
   HIP_TRY(hipEventCreate(&s->ev_stop));
@@ -556,6 +576,10 @@ int tb_session_start(tb_session* s) {
   s->finished = false;
   s->host_best = TB_PINF;
   s->mbox_host->stop = 0; s->mbox_host->foreign_bound = TB_PINF; s->mbox_host->local_best = TB_PINF;
+  if (s->ring_host) {
+    std::memset(s->ring_host, 0, 64 + align16((size_t)s->ring_slots * 8));
+    s->ring_next = 0;
+  }
   Ctrl c{};
   c.next_subproblem = s->P.sub_lo;
   c.first_sol_idx = ~0ull;
@@ -607,6 +631,23 @@ int tb_session_push_bound(tb_session* s, int32_t bound) {
 int tb_session_stop(tb_session* s) {
   if (!s) return fail(TB_ERR_INVALID, "null session");
   __atomic_store_n(&s->mbox_host->stop, 1, __ATOMIC_RELEASE);
+  return TB_OK;
+}
+
+int tb_session_next_solution(tb_session* s, tb_itv* store_out, int32_t* objective_out, int32_t* has_out) {
+  if (!s || !has_out) return fail(TB_ERR_INVALID, "null argument");
+  *has_out = 0;
+  if (!s->started) return fail(TB_ERR_STATE, "session not started");
+  if (!s->ring_host) return TB_OK;  // streaming is off: there is never anything to take
+  const int slot = (int)(s->ring_next % (unsigned long long)s->ring_slots);
+  const unsigned long long seq = __atomic_load_n(&s->ring_seq()[slot], __ATOMIC_ACQUIRE);
+  if (seq != s->ring_next + 1) return TB_OK;
+  const tb_itv* src = s->ring_data() + (size_t)slot * (size_t)s->n_vars;
+  if (store_out && s->n_vars) std::memcpy(store_out, src, (size_t)s->n_vars * sizeof(tb_itv));
+  if (objective_out) *objective_out = s->obj_var >= 0 ? src[s->obj_var].lb : 0;
+  s->ring_next += 1;
+  __atomic_store_n(s->ring_consumed(), s->ring_next, __ATOMIC_RELEASE);  // frees the slot for ticket ring_next + slots - 1
+  *has_out = 1;
   return TB_OK;
 }
 
@@ -718,6 +759,7 @@ int tb_solve(const tb_config* cfg_in, int32_t n_vars, const tb_itv* root_store,
     return rc;
   };
   tb_config cfg = *cfg_in;
+  cfg.stream_solutions = 0;  // nobody drains a ring in the blocking call: streaming belongs to the session API
   tb_stats st;
   int32_t has = 0;
   int rc = run(cfg, best_store_out, &has, &st);

@@ -45,6 +45,7 @@ struct alignas(16) BlockShared {
   int found, sol, skip, abort;
   int new_depth, ev_all, chg_count[2], ev_busy;  // event mode: "run every slice" request, change-list fill, waves running a slice
   unsigned long long sub_idx;
+  long long ticket;  // streaming: sequence number of the solution being handed to the host, -1 if none
   unsigned long long red_key[MAX_WAVES];
   int red_first[MAX_WAVES];
   BlockStats bs;  // written by thread 0 only
@@ -534,6 +535,32 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
   }
 }
 
+// Streaming: hand the solution in `store` to the host through the ring (GridData::produce_solution,
+// gpu_dive_and_solve.hpp:100-114, without the print lock: a ticket orders the producers, the host consumes in
+// ticket order).  Uniform call; sh.ticket was taken by thread 0.
+__device__ __forceinline__ void produce_solution(const DevProblem& P, BlockShared& sh, const int2* store, Mailbox* mbox) {
+  const int tid = threadIdx.x;
+  const unsigned long long ticket = (unsigned long long)sh.ticket;
+  const SolutionRing& r = P.ring;
+  if (tid == 0) {
+    // wait for a free slot; a stop request (host or device) drops the solution: nobody is listening any more
+    while (ticket - __hip_atomic_load(r.consumed, __ATOMIC_ACQUIRE, TB_SYS) >= (unsigned long long)r.slots) {
+      if (__hip_atomic_load(&mbox->stop, TB_RLX, TB_SYS) != 0 || __hip_atomic_load(&P.ctrl->stop, TB_RLX, TB_AGENT) != 0 ||
+          (P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks)) { sh.ticket = -1; break; }
+      __builtin_amdgcn_s_sleep(64);
+    }
+  }
+  __syncthreads();
+  if (sh.ticket >= 0) {
+    const int slot = (int)(ticket % (unsigned long long)r.slots);
+    copy_store(r.data + (size_t)slot * P.n_vars, store, P.n_vars);
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&r.seq[slot], ticket + 1ull, __ATOMIC_RELEASE, TB_SYS);
+  }
+  __syncthreads();
+}
+
 // ---- one search node (barebones:903-1031) ---------------------------------------------------------
 
 struct NodeTimers { long long t_last; };
@@ -558,6 +585,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
     bs.timers[TB_T_FIXPOINT] += t1 - t0;
     t_mark = t1;
     int leaf = failed ? 1 : 0, sol = 0;
+    bool stream = false;
     if (!failed && all_entailed) {
       leaf = 1;
       if (P.obj_var >= 0) {
@@ -567,11 +595,16 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
           sol = 1;
           if (!P.use_fixed_bound) {
             const int old = __hip_atomic_fetch_min(&P.ctrl->best_bound, obj, TB_RLX, TB_AGENT);  // appx_best_bound.meet
-            if (obj < old) __hip_atomic_store(&mbox->local_best, obj, TB_RLX, TB_SYS);
+            if (obj < old) {
+              __hip_atomic_store(&mbox->local_best, obj, TB_RLX, TB_SYS);
+              stream = P.ring.slots != 0;  // best_has_changed && is_printing_intermediate_sol (gpu_dive_and_solve.hpp:341-344)
+            }
           }
         }
       } else {
-        sol = 1;
+        // A leaf met while diving is reached by every workgroup whose subproblem lies below it (barebones:736-739):
+        // only the leftmost one reports the solution, so that `-a` / `-n k` enumerate each solution leaf once.
+        sol = (sh.remaining > 0 && (sh.sub_idx & ((1ull << sh.remaining) - 1ull)) != 0ull) ? 0 : 1;
       }
       if (sol) {
         bs.solutions++;
@@ -580,9 +613,10 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
         if (P.use_fixed_bound) {
           __hip_atomic_fetch_min(&P.ctrl->first_sol_idx, sh.sub_idx, TB_RLX, TB_AGENT);
           sh.stop = 1;
-        } else if (P.obj_var < 0 && P.stop_after_n_solutions != 0) {
+        } else if (P.obj_var < 0 && (P.stop_after_n_solutions != 0 || P.ring.slots != 0)) {
           const unsigned long long nsol = __hip_atomic_fetch_add(&P.ctrl->solutions, 1ull, TB_RLX, TB_AGENT) + 1;
-          if (nsol >= P.stop_after_n_solutions) {  // common_solving.hpp:858-867
+          stream = P.ring.slots != 0 && (P.stop_after_n_solutions == 0 || nsol <= P.stop_after_n_solutions);
+          if (P.stop_after_n_solutions != 0 && nsol >= P.stop_after_n_solutions) {  // common_solving.hpp:858-867
             bs.exhaustive = 0;
             sh.stop = 1;
             __hip_atomic_store(&P.ctrl->gpu_stop, 1, TB_RLX, TB_AGENT);
@@ -590,6 +624,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
         }
       }
     }
+    sh.ticket = stream ? (long long)__hip_atomic_fetch_add(&P.ctrl->sol_ticket, 1ull, TB_RLX, TB_AGENT) : -1ll;
     sh.leaf = leaf;
     sh.sol = sol;
     bs.fixpoint_iterations += (unsigned long long)iters;
@@ -614,6 +649,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
   if (sh.sol) {  // uniform
     copy_store(best_store, store, P.n_vars);
     __syncthreads();
+    if (sh.ticket >= 0) produce_solution(P, sh, store, mbox);
   }
 }
 

@@ -151,18 +151,55 @@ bool simplify_network(const Options& o, const Printer& p, tf_model* m, std::stri
   return true;
 }
 
-// N GPUs of the node: one session per device, this thread relays the incumbent bound and the stop flag.
-int solve_multi_gpu(const Options& o, const tb_config& base, const tf_model* m, std::vector<tb_itv>& best, int32_t* has, tb_stats* out) {
-  const int G = o.gpus;
+// Prints the solutions handed over while the kernels run (consume_solution, gpu_dive_and_solve.hpp:116-132).
+struct SolutionPrinter {
+  const tf_model* m;
+  bool optimization;
+  uint64_t limit;        // satisfaction: -n (0 = all)
+  uint64_t printed = 0;
+  int32_t last_obj = TB_PINF;
+  void print(const tb_itv* store) {
+    const int32_t need = tf_format_solution(m, store, nullptr, 0);
+    std::string text((size_t)need + 1, '\0');
+    tf_format_solution(m, store, text.data(), need + 1);
+    std::fputs(text.c_str(), stdout);
+    std::printf("----------\n");
+    std::fflush(stdout);
+    ++printed;
+  }
+  // Workgroups race: an optimisation solution is printed only if it improves on the last one printed.
+  void offer(const tb_itv* store, int32_t obj) {
+    if (optimization) { if (obj < last_obj) { last_obj = obj; print(store); } }
+    else if (limit == 0 || printed < limit) print(store);
+  }
+  bool satisfied() const { return !optimization && limit != 0 && printed >= limit; }
+};
+
+// N GPUs of the node (N >= 1): one session per device, this thread relays the incumbent bound and the stop flag and,
+// when streaming, prints the solutions as they arrive.
+int solve_sessions(const Options& o, const tb_config& base, const tf_model* m, std::vector<tb_itv>& best, int32_t* has, tb_stats* out, SolutionPrinter* printer) {
+  const int G = std::max(1, o.gpus);
   std::vector<tb_session*> ss((size_t)G, nullptr);
   int rc = TB_OK;
   for (int g = 0; g < G && rc == TB_OK; ++g) {
     tb_config c = base;
     c.device = g; c.rank = g; c.world_size = G; c.deterministic = 0;
+    c.stream_solutions = printer ? 1 : 0;
     rc = tb_session_create(&c, tf_num_vars(m), tf_store(m), tf_num_props(m), tf_props(m), tf_num_strategies(m), tf_strat_var_order(m),
                            tf_strat_val_order(m), tf_strat_off(m), tf_strat_vars(m), tf_obj_var(m), &ss[(size_t)g]);
   }
   for (int g = 0; g < G && rc == TB_OK; ++g) rc = tb_session_start(ss[(size_t)g]);
+  std::vector<tb_itv> tmp(best.size());
+  auto drain = [&]() {
+    if (!printer) return;
+    for (int g = 0; g < G && rc == TB_OK; ++g)
+      for (;;) {
+        int32_t got = 0, obj = 0;
+        rc = tb_session_next_solution(ss[(size_t)g], tmp.data(), &obj, &got);
+        if (rc != TB_OK || !got) break;
+        printer->offer(tmp.data(), obj);
+      }
+  };
   const auto t0 = Clock::now();
   while (rc == TB_OK) {
     int32_t gbest = TB_PINF, all_done = 1;
@@ -173,15 +210,16 @@ int solve_multi_gpu(const Options& o, const tb_config& base, const tf_model* m, 
       gbest = std::min(gbest, b);
       all_done &= d;
     }
+    if (rc != TB_OK) break;
+    drain();
     if (rc != TB_OK || all_done) break;
-    if (gbest != TB_PINF) for (int g = 0; g < G; ++g) tb_session_push_bound(ss[(size_t)g], gbest);
+    if (G > 1 && gbest != TB_PINF) for (int g = 0; g < G; ++g) tb_session_push_bound(ss[(size_t)g], gbest);
     const uint64_t el = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(Clock::now() - t0).count();
-    if ((o.timeout_ms != 0 && el >= o.timeout_ms) || g_stop_flag) for (int g = 0; g < G; ++g) tb_session_stop(ss[(size_t)g]);
-    std::this_thread::sleep_for(std::chrono::microseconds(500));
+    if ((o.timeout_ms != 0 && el >= o.timeout_ms) || g_stop_flag || (printer && printer->satisfied())) for (int g = 0; g < G; ++g) tb_session_stop(ss[(size_t)g]);
+    std::this_thread::sleep_for(std::chrono::microseconds(printer ? 200 : 500));
   }
   bool first = true;
   int32_t best_bound = TB_PINF;
-  std::vector<tb_itv> tmp(best.size());
   for (int g = 0; g < G && rc == TB_OK; ++g) {
     tb_stats st;
     int32_t h = 0;
@@ -205,7 +243,6 @@ int main(int argc, char** argv) {
     std::cerr << "-arch " << name_of(o.arch) << " is not provided by this build: it contains only the MI355X dive-and-solve engine (use -arch gpu or -arch barebones)." << std::endl;
     return EXIT_FAILURE;
   }
-  if (o.print_intermediate_solutions) std::printf("%% WARNING: -arch %s is incompatible with -i and -a (it cannot print intermediate solutions).\n", name_of(o.arch));
   const auto start = Clock::now();
 
   // preprocess (common_solving.hpp:605-637)
@@ -275,11 +312,16 @@ int main(int argc, char** argv) {
   std::vector<tb_itv> best((size_t)std::max(1, n_vars));
   int32_t has = 0;
   int rc;
-  if (o.gpus <= 1) {
+  // Streaming as in the reference's `gpu` path (is_printing_intermediate_sol, common_solving.hpp:838-840): `-i`/`-a`, and
+  // satisfaction problems asked for more than one solution.  Otherwise only the final best solution is printed
+  // (barebones:499-506), which keeps the answer of a satisfaction problem deterministic (lowest subproblem).
+  const bool streaming = o.print_intermediate_solutions || (!optimization && o.stop_after_n_solutions != 1);
+  SolutionPrinter printer{m, optimization, o.stop_after_n_solutions};
+  if (o.gpus <= 1 && !streaming) {
     rc = tb_solve(&cfg, n_vars, tf_store(m), n_props, tf_props(m), tf_num_strategies(m), tf_strat_var_order(m), tf_strat_val_order(m),
                   tf_strat_off(m), tf_strat_vars(m), tf_obj_var(m), &g_stop_flag, best.data(), &has, &st);
   } else {
-    rc = solve_multi_gpu(o, cfg, m, best, &has, &st);
+    rc = solve_sessions(o, cfg, m, best, &has, &st, streaming ? &printer : nullptr);
   }
   if (rc != TB_OK) {
     std::cout.flush();
@@ -289,12 +331,11 @@ int main(int argc, char** argv) {
   }
   const int64_t overall_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - start).count();
 
-  if (has) {  // barebones prints only the final best solution (barebones:499-506)
-    const int32_t need = tf_format_solution(m, best.data(), nullptr, 0);
-    std::string text((size_t)need + 1, '\0');
-    tf_format_solution(m, best.data(), text.data(), need + 1);
-    std::fputs(text.c_str(), stdout);
-    std::printf("----------\n");
+  if (has) {
+    // without streaming: the final best solution (barebones:499-506); with streaming it was printed when it arrived,
+    // unless its hand-over was cut short by a stop request
+    const bool pending = !streaming || (optimization ? best[(size_t)tf_obj_var(m)].lb < printer.last_obj : printer.printed == 0);
+    if (pending) printer.print(best.data());
   }
   final_separator(st.solutions, st.exhaustive != 0, optimization);
   if (o.print_statistics) {
