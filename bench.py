@@ -54,6 +54,7 @@ def main() -> int:
     ap.add_argument("--cutnodes", type=int, default=0, help="node budget per workgroup and step (0 = workload default)")
     ap.add_argument("--fixpoint", default="wac1", choices=["ac1", "wac1", "event"])
     ap.add_argument("--event-steps", type=int, default=2, help="extra steps in the event-driven fixpoint mode, reported beside the headline (0 = skip)")
+    ap.add_argument("--no-simplify", action="store_true", help="skip the network simplifier (the reference's -disable_simplify)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="testing aid: gloo lets two ranks share one GPU")
@@ -84,8 +85,12 @@ def main() -> int:
     if args.workload == "synthetic":
         from turbo_amd.synth import make_synthetic
         tcn = make_synthetic(100_000, 500_000, seed=42)
-    else:
+    elif args.no_simplify:
         tcn = frontend.load_fzn(os.path.join(ROOT, "benchmarks", fzn))
+    else:
+        # the reference's default pipeline: root fixpoint (tb_propagate on this GPU) + network simplifier, outside the timed region
+        from turbo_amd import preprocess
+        _model, tcn, _ = preprocess.load_fzn_simplified(os.path.join(ROOT, "benchmarks", fzn), device=local_rank)
     fp_code = {"ac1": 0, "wac1": 1, "event": 2}
     cfg = capi.make_config(fixpoint=fp_code[args.fixpoint], stop_after_n_nodes=cut, timeout_ms=600000,
                            device=local_rank, rank=rank, world_size=world)
@@ -131,7 +136,7 @@ def main() -> int:
     # the same workload in the engine's event-driven fixpoint (same tree, fewer propagator evaluations per node)
     event = None
     if args.event_steps > 0 and args.fixpoint != "event":
-        cfg_e = capi.make_config(fixpoint=2, stop_after_n_nodes=cut * 4, timeout_ms=600000, device=local_rank, rank=rank, world_size=world)
+        cfg_e = capi.make_config(fixpoint=2, stop_after_n_nodes=cut * 2, timeout_ms=600000, device=local_rank, rank=rank, world_size=world)
         sess_e = capi.Session(tcn, cfg_e)
         one_step(sess_e)
         sync()
@@ -150,7 +155,7 @@ def main() -> int:
             agg = torch.tensor([acc["nodes"], acc["num_deductions"]], dtype=torch.int64, device=tdev)
             dist.all_reduce(agg, op=dist.ReduceOp.SUM)
             acc["nodes"], acc["num_deductions"] = (int(x) for x in agg.tolist())
-        event = {"fixpoint": "event", "steps": args.event_steps, "cutnodes": cut * 4, "nodes_per_sec": acc["nodes"] / te,
+        event = {"fixpoint": "event", "steps": args.event_steps, "cutnodes": cut * 2, "nodes_per_sec": acc["nodes"] / te,
                  "propagations_per_sec": acc["num_deductions"] / te,
                  "note": "same search tree, propagators re-evaluated only when one of their variables was narrowed"}
         sess_e.close()
@@ -165,7 +170,8 @@ def main() -> int:
         if os.path.exists(tfile):
             try:
                 rec = json.load(open(tfile))
-                if rec.get("workload") == args.workload and rec.get("cutnodes") == cut and rec.get("fixpoint") == args.fixpoint:
+                if (rec.get("workload") == args.workload and rec.get("cutnodes") == cut and rec.get("fixpoint") == args.fixpoint
+                        and bool(rec.get("simplified", False)) == (not args.no_simplify and args.workload != "synthetic")):
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -177,7 +183,7 @@ def main() -> int:
             "ms_per_step": elapsed * 1000.0 / steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32",
             "data": "synthetic (seed 42)" if args.workload == "synthetic" else "reference instance file (no randomness)",
-            "config": {"workload": f"{fzn}: {tcn.n_vars} interval variables x {tcn.n_props} ternary propagators, "
+            "config": {"workload": f"{fzn}{'' if args.no_simplify or args.workload == 'synthetic' else ' (simplified network)'}: {tcn.n_vars} interval variables x {tcn.n_props} ternary propagators, "
                                    f"{last['num_blocks']} workgroups x {last['threads_per_block']} threads per GPU, "
                                    f"{capi.MEM_KINDS[last['mem_kind']]} ({last['shared_bytes']} B LDS per workgroup), "
                                    f"2^{last['subproblems_power']} subproblems, cutnodes={cut} per workgroup and step, fixpoint={args.fixpoint}",

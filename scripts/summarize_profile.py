@@ -11,7 +11,7 @@ import argparse, json, os, sqlite3, sys
 ap = argparse.ArgumentParser()
 ap.add_argument("tag"); ap.add_argument("trace_db"); ap.add_argument("fetch_db", nargs="?"); ap.add_argument("write_db", nargs="?")
 ap.add_argument("--workload", default="wordpress7_500"); ap.add_argument("--cutnodes", type=int, default=3000); ap.add_argument("--fixpoint", default="wac1")
-ap.add_argument("--kernel", default="solve_kernel")
+ap.add_argument("--kernel", default="solve_kernel"); ap.add_argument("--simplified", action="store_true")
 a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(root, "profiles"); os.makedirs(out_dir, exist_ok=True)
@@ -37,7 +37,7 @@ if a.fetch_db and a.write_db:
     fetch = per_launch(a.fetch_db, "FETCH_SIZE"); write = per_launch(a.write_db, "WRITE_SIZE")
     f_kib = sum(fetch) / max(1, len(fetch)); w_kib = sum(write) / max(1, len(write))
     hbm = (2.0 * f_kib + w_kib) * 1024.0
-    rec = {"tag": a.tag, "workload": a.workload, "cutnodes": a.cutnodes, "fixpoint": a.fixpoint, "kernel": a.kernel,
+    rec = {"tag": a.tag, "workload": a.workload, "cutnodes": a.cutnodes, "fixpoint": a.fixpoint, "simplified": a.simplified, "kernel": a.kernel,
            "launches_profiled": len(fetch), "FETCH_SIZE_KiB_per_launch": f_kib, "WRITE_SIZE_KiB_per_launch": w_kib,
            "correction": "hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x)",
            "hbm_bytes_per_launch": hbm}

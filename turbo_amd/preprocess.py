@@ -10,12 +10,12 @@ from . import capi, frontend
 
 
 def load_fzn_simplified(path: str, rounds: int = 16, eps_var_order: str = "default", eps_value_order: str = "default",
-                        propagate=None):
+                        propagate=None, device: int = 0):
     """Returns (model, tcn, stats).  `propagate(store, props) -> (store, failed)` defaults to the GPU engine."""
     m = frontend.Model.from_file(path)
     if propagate is None:
         def propagate(store, props):
-            out, failed, _, _, _, _ = capi.propagate(props, store[None, :], capi.make_config(fixpoint=1))
+            out, failed, _, _, _, _ = capi.propagate(props, store[None, :], capi.make_config(fixpoint=1, device=device))
             return out[0], bool(failed[0])
     stats = []
     for _ in range(rounds):
