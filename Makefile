@@ -9,7 +9,7 @@ ARCH ?= gfx950
 
 LIBDIR := turbo_amd/lib
 BINDIR := turbo_amd/bin
-FRONT_SRC := turbo_amd/csrc/front/fzn_parser.cpp turbo_amd/csrc/front/tcn_lower.cpp turbo_amd/csrc/front/simplify.cpp turbo_amd/csrc/front/front_capi.cpp
+FRONT_SRC := turbo_amd/csrc/front/fzn_parser.cpp turbo_amd/csrc/front/tcn_lower.cpp turbo_amd/csrc/front/simplify.cpp turbo_amd/csrc/front/xcsp3_reader.cpp turbo_amd/csrc/front/front_capi.cpp
 FRONT_HDR := turbo_amd/csrc/front/fzn_ast.hpp turbo_amd/csrc/front/tcn.hpp include/turbo_front.h include/turbo_hip.h
 HIP_SRC := turbo_amd/csrc/hip/engine.hip
 HIP_HDR := $(wildcard turbo_amd/csrc/hip/*.hpp) include/turbo_hip.h

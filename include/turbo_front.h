@@ -23,6 +23,11 @@ typedef struct tf_model tf_model;
 /* Parse + lower.  Returns NULL on error and writes a message into err (if non-NULL). */
 tf_model* tf_load_fzn(const char* path, char* err, int32_t err_len);
 tf_model* tf_load_fzn_string(const char* text, char* err, int32_t err_len);
+/* XCSP3-core input (common_solving.hpp:409-413, `parse_xcsp3` of lala-parsing): the instance is rewritten to FlatZinc
+ * (tf_xcsp3_to_fzn returns the text length, -1 on error) and then takes the same path as a .fzn file. */
+tf_model* tf_load_xcsp3(const char* path, char* err, int32_t err_len);
+tf_model* tf_load_xcsp3_string(const char* xml, char* err, int32_t err_len);
+int32_t tf_xcsp3_to_fzn(const char* xml, char* buf, int32_t buf_len, char* err, int32_t err_len);
 void tf_free(tf_model* m);
 
 int32_t tf_num_vars(const tf_model* m);
@@ -72,6 +77,14 @@ const tb_itv* tf_original_store(const tf_model* m);
 const tb_prop* tf_original_props(const tf_model* m);
 /* solution of the current network -> store over the variables of the network as first lowered */
 int32_t tf_expand_solution(const tf_model* m, const tb_itv* store, tb_itv* original_out);
+
+/* Statistics of the model before ternarisation (analyze_cn, common_solving.hpp:669-704): `key=value` lines
+ * (fcn_variables, fcn_constraints, fcn_var_occurrences, fcn_histogram_symbols, fcn_histogram_constraints_degree). */
+const char* tf_fcn_statistics(const tf_model* m);
+
+/* `-eps_var_order random`: strategy `strategy` becomes INPUT_ORDER over its variables shuffled with
+ * std::mt19937(seed) (split->shuffle_random_strategies, common_solving.hpp:632-633). */
+int32_t tf_shuffle_strategy(tf_model* m, int32_t strategy, uint64_t seed);
 
 /* name of a TCN variable ("" for temporaries), for debugging */
 const char* tf_var_name(const tf_model* m, int32_t var);

@@ -22,6 +22,12 @@
 #include <string.h>
 #include <time.h>
 
+/* Optional sink for every accepted solution leaf (tests enumerate solutions with it); not thread safe. */
+static orc_itv* g_sink = NULL;
+static int64_t g_sink_cap = 0, g_sink_count = 0;
+void orc_set_solution_sink(orc_itv* buf, int64_t capacity) { g_sink = buf; g_sink_cap = capacity; g_sink_count = 0; }
+int64_t orc_solution_sink_count(void) { return g_sink_count; }
+
 #define NINF ORC_NINF
 #define PINF ORC_PINF
 
@@ -373,6 +379,8 @@ static int propagate(engine_t* e, int is_dive) {
       if (accept) {
         if (e->obj_var >= 0) e->best_bound = e->store[e->obj_var].lb;
         memcpy(e->best_store, e->store, sizeof(orc_itv) * (size_t)e->n_vars);
+        if (g_sink && g_sink_count < g_sink_cap) memcpy(g_sink + (size_t)g_sink_count * (size_t)e->n_vars, e->store, sizeof(orc_itv) * (size_t)e->n_vars);
+        if (g_sink) g_sink_count++;
         e->st.solutions++;
         e->st.best_subproblem = (int32_t)e->cur_subproblem;
         if (e->cfg->use_fixed_bound) e->stop = 1;

@@ -94,6 +94,11 @@ int orc_solve(const orc_config* cfg, int32_t n_vars, const orc_itv* root_store,
               const int32_t* strat_off, const int32_t* strat_vars,
               int32_t obj_var, orc_itv* best_store_out, int32_t* has_solution_out, orc_stats* stats_out);
 
+/* Test aid: copy every accepted solution leaf of the next orc_solve calls into buf (capacity solutions of n_vars
+ * intervals); orc_solution_sink_count() = leaves seen (may exceed capacity).  NULL switches it off. */
+void orc_set_solution_sink(orc_itv* buf, int64_t capacity);
+int64_t orc_solution_sink_count(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,3 +99,21 @@ def solve(tcn, subproblems_power: int = 0, cutnodes: int = 0, timeout_ms: int = 
     if rc != 0:
         raise RuntimeError(f"orc_solve failed with {rc}")
     return bool(has.value), best, stats.as_dict()
+
+
+def enumerate_solutions(tcn, capacity: int = 100000):
+    """Every solution leaf (a box: unassigned variables are free) of a satisfaction problem, in DFS order."""
+    L = lib()
+    L.orc_set_solution_sink.argtypes = [C.c_void_p, C.c_int64]
+    L.orc_solution_sink_count.restype = C.c_int64
+    n = int(np.asarray(tcn.store).shape[0])
+    buf = np.zeros((capacity, max(n, 1)), dtype=ITV)
+    L.orc_set_solution_sink(buf.ctypes.data, capacity)
+    try:
+        _, _, st = solve(tcn, stop_after_n_solutions=0)
+        k = int(L.orc_solution_sink_count())
+    finally:
+        L.orc_set_solution_sink(None, 0)
+    if k > capacity:
+        raise RuntimeError(f"{k} solutions exceed the capacity {capacity}")
+    return buf[:k, :n], st

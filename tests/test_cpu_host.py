@@ -210,3 +210,23 @@ def test_synthetic_network_is_satisfiable_by_construction():
     # the root node propagates without failure and keeps the hidden solution
     out, failed, _, _, _ = pyoracle.propagate(tcn.store, tcn.props)
     assert not failed and ((out["lb"] <= v) & (v <= out["ub"])).all()
+
+
+def test_model_statistics_and_random_order():
+    from turbo_amd import frontend
+    m = frontend.Model.from_file(os.path.join(BENCH, "test_data", "pat2.fzn"))
+    st = m.fcn_statistics()
+    assert int(st["fcn_variables"]) > 0 and int(st["fcn_constraints"]) == m.tcn().parsed_constraints
+    assert "'int_lin_le'" in st["fcn_histogram_symbols"]
+    orders = {}
+    for seed in (0, 0, 5):
+        mm = frontend.Model.from_file(os.path.join(BENCH, "test_data", "pat2.fzn"))
+        before = mm.tcn()
+        mm.push_eps_strategy("input_order", "min")
+        mm.shuffle_strategy(0, seed)
+        t = mm.tcn()
+        vars0 = t.strat_vars[t.strat_off[0]:t.strat_off[1]].tolist()
+        assert sorted(vars0) == sorted(before.strat_vars[before.strat_off[0]:before.strat_off[1]].tolist())
+        assert t.strat_var_order[0] == frontend.VAR_ORDERS["input_order"]
+        orders.setdefault(seed, []).append(vars0)
+    assert orders[0][0] == orders[0][1] and orders[0][0] != orders[5][0]

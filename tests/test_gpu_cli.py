@@ -56,6 +56,34 @@ def test_output_format_and_gpu_arch_alias():
         assert f"%%%mzn-stat: {key}=" in r.stdout, key
 
 
+@pytest.mark.parametrize("seed", [0, 7])
+def test_random_eps_variable_order(seed):
+    # -eps_var_order random = input order over the strategy's variables shuffled with mt19937(seed) (common_solving.hpp:632)
+    rel, expected = "test_data/pat8.fzn", 11
+    r = subprocess.run([TURBO, "-eps_var_order", "random", "-eps_value_order", "min", "-seed", str(seed), "-s", "-t", "60000",
+                        os.path.join(BENCH, rel)], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    assert int(re.search(r"objective=(-?\d+)", r.stdout).group(1)) == expected and "==========" in r.stdout
+    assert f"%%%mzn-stat: seed={seed}" in r.stdout
+
+
+def test_network_analysis_statistics():
+    path = os.path.join(BENCH, "test_data", "pat2.fzn")
+    r = subprocess.run([TURBO, "-s", "-t", "60000", path], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    for key in ("fcn_variables", "fcn_constraints", "fcn_var_occurrences", "fcn_histogram_symbols",
+                "tcn_variables", "tcn_constraints", "tcn_assigned_variables", "tcn_unbounded_variables", "tcn_histogram_symbols",
+                "tcn_histogram_reified_predicates", "tcn_histogram_unassigned_vars_degree", "tcn_histogram_vars_dom_size",
+                "preprocessed_tcn_variables", "preprocessed_tcn_histogram_symbols"):
+        assert f"%%%mzn-stat: {key}=" in r.stdout, key
+    # the histogram of symbols accounts for every ternary constraint
+    hist = re.search(r'mzn-stat: tcn_histogram_symbols="\{([^}]*)\}"', r.stdout).group(1)
+    total = sum(int(x.split(":")[1]) for x in hist.split(","))
+    assert total == int(re.search(r"mzn-stat: tcn_constraints=(\d+)", r.stdout).group(1))
+    q = subprocess.run([TURBO, "-s", "-disable_network_analysis", "-t", "60000", path], capture_output=True, text=True, timeout=180)
+    assert q.returncode == 0 and "tcn_variables=" in q.stdout and "histogram" not in q.stdout and "fcn_variables" not in q.stdout
+
+
 def test_timeout_is_honoured_and_reported():
     r = subprocess.run([TURBO, "-s", "-t", "1500", os.path.join(BENCH, "example_wordpress7_500.fzn")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr

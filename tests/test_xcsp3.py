@@ -1,0 +1,171 @@
+"""XCSP3-core input (common_solving.hpp:409-413; lala-parsing's parser is absent from the reference tree).
+
+Pinned by the reference's own known answer for this format (benchmarks/test_list.csv: cumulative.xml -> 0) and by
+brute-force enumeration of small handwritten instances: the number of solutions of the lowered network (oracle,
+all solutions) must equal the number of assignments satisfying the XCSP3 semantics written directly in Python.
+"""
+import itertools
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import BENCH, ROOT
+from oracle import pyoracle
+from turbo_amd import capi, frontend
+
+TURBO = os.path.join(ROOT, "turbo_amd", "bin", "turbo")
+CUMULATIVE = os.path.join(BENCH, "test_data", "cumulative.xml")
+
+
+def inst(variables, constraints, objectives=""):
+    return (f'<instance format="XCSP3" type="{"COP" if objectives else "CSP"}">\n<variables>{variables}</variables>\n'
+            f"<constraints>{constraints}</constraints>\n{objectives}</instance>\n")
+
+
+def solutions(xml):
+    """All solutions of the lowered network projected on the output items (as text), through the oracle."""
+    m = frontend.Model.from_xcsp3_string(xml)
+    tcn = m.tcn()
+    boxes, st = pyoracle.enumerate_solutions(tcn)
+    assert st["exhaustive"]
+    # a solution leaf is a box (every propagator entailed, some variables possibly free): count the assignments of
+    # the instance's own variables it stands for
+    own = [v for v in range(tcn.n_vars) if (nm := m.var_name(v)) and not nm.startswith(("X_T", "X_B"))]
+    points = set()
+    for b in boxes:
+        ranges = [range(int(b[v]["lb"]), int(b[v]["ub"]) + 1) for v in own]
+        points.update(itertools.product(*ranges))
+    return len(points), m, tcn
+
+
+def optimum(xml):
+    m = frontend.Model.from_xcsp3_string(xml)
+    tcn = m.tcn()
+    has, best, st = pyoracle.solve(tcn)
+    assert st["exhaustive"]
+    return (tcn.objective_of(best) if has else None), (m.format_solution(best) if has else "")
+
+
+def test_reference_known_answer_cumulative():
+    m = frontend.Model.from_xcsp3_file(CUMULATIVE)
+    tcn = m.tcn()
+    has, best, st = pyoracle.solve(tcn)
+    assert has and st["exhaustive"] and tcn.objective_of(best) == 0
+    # check the schedule against the cumulative semantics directly
+    starts = [int(v) for v in re.search(r"x = array1d\(0\.\.4, \[([^\]]*)\]\)", m.format_solution(best)).group(1).split(",")]
+    lengths, heights = [3, 2, 2, 4, 2], [3, 2, 2, 2, 3]
+    for t in range(0, 10):
+        assert sum(h for s, l, h in zip(starts, lengths, heights) if s <= t < s + l) <= 5
+    assert starts[1] == 0
+
+
+def test_compact_forms_in_value_lists():
+    xml = open(CUMULATIVE).read()
+    fzn = frontend.xcsp3_to_fzn(xml)
+    assert "array [1..5] of var 0..4: x :: output_array([0..4]);" in fzn
+    assert "solve minimize" in fzn
+    # heights "3 2x3 3" = 3 2 2 2 3: at t = 0 every task may run
+    assert re.search(r"int_lin_le\(\[3, 2, 2, 2, 3\]", fzn)
+
+
+def count(pred, *domains):
+    return sum(1 for t in itertools.product(*domains) if pred(*t))
+
+
+R5 = range(0, 6)
+
+
+@pytest.mark.parametrize("name,xml,expected", [
+    ("intension_arith", inst('<var id="x"> 0..5 </var><var id="y"> 0..5 </var>',
+                             "<intension> eq(add(x,mul(2,y)),7) </intension><intension> lt(x,y) </intension>"),
+     count(lambda x, y: x + 2 * y == 7 and x < y, R5, R5)),
+    ("intension_logic", inst('<var id="x"> 0..5 </var><var id="y"> 0..5 </var><var id="z"> 0..5 </var>',
+                             "<intension> or(and(le(x,1),gt(y,3)),iff(eq(z,2),ne(x,y))) </intension>"
+                             "<intension> imp(ge(x,4),eq(dist(y,z),1)) </intension>"),
+     count(lambda x, y, z: ((x <= 1 and y > 3) or ((z == 2) == (x != y))) and ((not x >= 4) or abs(y - z) == 1), R5, R5, R5)),
+    ("intension_if_minmax", inst('<var id="x"> 0..5 </var><var id="y"> 0..5 </var><var id="z"> 0..5 </var>',
+                                 "<intension> eq(z,if(lt(x,y),min(x,3),max(y,2))) </intension><intension> ne(mod(add(x,y),3),neg(sub(0,1))) </intension>"),
+     count(lambda x, y, z: z == (min(x, 3) if x < y else max(y, 2)) and (x + y) % 3 != 1, R5, R5, R5)),
+    ("alldiff_ordered", inst('<array id="a" size="[4]"> 1..5 </array>',
+                             "<allDifferent> a[] </allDifferent><ordered><list> a[0..2] </list><operator> lt </operator></ordered>"),
+     count(lambda a, b, c, d: len({a, b, c, d}) == 4 and a < b < c, *[range(1, 6)] * 4)),
+    ("sum_coeffs", inst('<array id="a" size="[3]"> 0..4 </array><var id="k"> 3 5 9 </var>',
+                        "<sum><list> a[] </list><coeffs> 1 2 3 </coeffs><condition> (eq,k) </condition></sum>"
+                        "<sum><list> a[0] a[2] </list><condition> (gt,2) </condition></sum>"),
+     count(lambda a, b, c, k: a + 2 * b + 3 * c == k and a + c > 2, range(5), range(5), range(5), [3, 5, 9])),
+    ("extension", inst('<var id="x"> 1..3 </var><var id="y"> 0..3 </var><var id="z"> 0..2 </var>',
+                       "<extension><list> x y </list><supports> (1,2)(2,3)(*,0) </supports></extension>"
+                       "<extension><list> y z </list><conflicts> (0,0)(3,*) </conflicts></extension>"
+                       "<extension><list> z </list><supports> 0 2 </supports></extension>"),
+     count(lambda x, y, z: ((x, y) in {(1, 2), (2, 3)} or y == 0) and not ((y, z) == (0, 0) or y == 3) and z in (0, 2),
+           range(1, 4), range(4), range(3))),
+    ("element", inst('<var id="i"> 0..3 </var><var id="v"> 0..9 </var><array id="a" size="[3]"> 0..2 </array><var id="j"> 1..3 </var>',
+                     "<element><list> 4 7 1 9 </list><index> i </index><value> v </value></element>"
+                     '<element><list startIndex="1"> a[] </list><index> j </index><value> 2 </value></element>'),
+     count(lambda i, v, a, b, c, j: [4, 7, 1, 9][i] == v and [a, b, c][j - 1] == 2, range(4), range(10), range(3), range(3), range(3), range(1, 4))),
+    ("minmax_group", inst('<array id="m" size="[2][2]"> 0..3 </array>',
+                          "<minimum><list> m[][0] </list><condition> (ge,1) </condition></minimum>"
+                          "<maximum><list> m[1][] </list><condition> (eq,2) </condition></maximum>"
+                          "<group><intension> ne(%0,%1) </intension><args> m[0][0] m[0][1] </args><args> m[0][1] m[1][1] </args></group>"),
+     count(lambda a, b, c, d: min(a, c) >= 1 and max(c, d) == 2 and a != b and b != d, *[range(4)] * 4)),
+    ("instantiation_block", inst('<array id="a" size="[3]"> 0..3 </array>',
+                                 "<block><instantiation><list> a[0] </list><values> 2 </values></instantiation>"
+                                 "<intension> le(add(a[0],a[1],a[2]),4) </intension></block>"),
+     count(lambda a, b, c: a == 2 and a + b + c <= 4, *[range(4)] * 3)),
+])
+def test_solution_counts_match_brute_force(name, xml, expected):
+    n, m, tcn = solutions(xml)
+    assert n == expected
+
+
+def test_objectives():
+    v = '<array id="a" size="[3]"> 0..4 </array>'
+    c = "<allDifferent> a[] </allDifferent><sum><list> a[] </list><condition> (ge,7) </condition></sum>"
+    assert optimum(inst(v, c, "<objectives><minimize> add(a[0],mul(a[1],3)) </minimize></objectives>"))[0] == \
+        min(a + 3 * b for a, b, cc in itertools.permutations(range(5), 3) if a + b + cc >= 7)
+    assert optimum(inst(v, c, '<objectives><maximize type="sum"><list> a[] </list><coeffs> 1 -2 1 </coeffs></maximize></objectives>'))[0] == \
+        max(a - 2 * b + cc for a, b, cc in itertools.permutations(range(5), 3) if a + b + cc >= 7)
+    assert optimum(inst(v, c, '<objectives><minimize type="maximum"> a[] </minimize></objectives>'))[0] == \
+        min(max(t) for t in itertools.permutations(range(5), 3) if sum(t) >= 7)
+    assert optimum(inst(v, c, '<objectives><maximize type="minimum"> a[0] a[1] </maximize></objectives>'))[0] == \
+        max(min(t[0], t[1]) for t in itertools.permutations(range(5), 3) if sum(t) >= 7)
+
+
+def test_unsupported_and_malformed_inputs_are_reported():
+    for bad in ["<instance><variables><var id='x'> 0..2 </var></variables><constraints><circuit> x </circuit></constraints></instance>",
+                "<instance><variables><var id='x'> 0..2 </var></variables><constraints><intension> eq(y,1) </intension></constraints></instance>",
+                "<instance><variables><var id='x'> 0..2 </variables></instance>",
+                "<nothing/>"]:
+        with pytest.raises(ValueError, match="XCSP3"):
+            frontend.Model.from_xcsp3_string(bad)
+
+
+def test_cli_rejects_other_extensions(tmp_path):
+    p = tmp_path / "model.mzn"
+    p.write_text("solve satisfy;\n")
+    r = subprocess.run([TURBO, str(p)], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "supported extension: .xml and .fzn" in r.stdout  # config.hpp:268-278
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixpoint", ["wac1", "event"])
+def test_regression_script_row_on_the_gpu(fixpoint):
+    # test_turbo.sh:34-44 on the .xml row of test_list.csv
+    r = subprocess.run([TURBO, "-eps_var_order", "input_order", "-eps_value_order", "min", "-arch", "barebones", "-s", "-t", "60000",
+                        "-fp", fixpoint, CUMULATIVE], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    assert int(re.search(r"objective=(-?\d+)", r.stdout).group(1)) == 0
+    assert "==========" in r.stdout and "x = array1d(0..4, [" in r.stdout
+
+
+@pytest.mark.gpu
+def test_xcsp3_network_on_the_engine():
+    m = frontend.Model.from_xcsp3_file(CUMULATIVE)
+    tcn = m.tcn()
+    has, best, st = capi.solve(tcn, capi.make_config(deterministic=1))
+    ohas, obest, _ = pyoracle.solve(tcn)
+    assert has and ohas and st["exhaustive"]
+    np.testing.assert_array_equal(best, obest)  # canonical solution, bit for bit

@@ -2,7 +2,10 @@
 #include "../../../include/turbo_front.h"
 
 #include <cstring>
+#include <algorithm>
 #include <fstream>
+#include <map>
+#include <random>
 #include <sstream>
 
 #include "tcn.hpp"
@@ -11,6 +14,7 @@ using namespace turbo_front;
 
 struct tf_model {
   TCN tcn;
+  std::string fcn_stats;  // analyze_cn (common_solving.hpp:669-704) of the model as parsed, one `key=value` per line
 };
 
 namespace {
@@ -21,11 +25,54 @@ void set_err(char* err, int32_t err_len, const std::string& msg) {
   err[err_len - 1] = '\0';
 }
 
+// Statistics of the constraint network before ternarisation (analyze_cn, common_solving.hpp:669-704), on the
+// FlatZinc model: symbols are predicate names, a variable occurrence is a reference from a constraint argument.
+std::string analyze_model(const Model& m) {
+  std::map<std::string, int64_t> var_size;  // declared variables (arrays: number of cells)
+  for (const VarDecl& v : m.vars) var_size[v.name] = 1;
+  for (const ArrayDecl& a : m.arrays) if (a.is_var) var_size[a.name] = a.size;
+  int64_t n_vars = 0;
+  for (auto& kv : var_size) n_vars += kv.second;
+  int64_t occurrences = 0;
+  std::map<std::string, int64_t> symbols, degree_hist;
+  struct Walk {
+    const std::map<std::string, int64_t>& vs;
+    int64_t count(const Expr& e) const {
+      int64_t n = 0;
+      if (e.kind == Expr::ID) { auto it = vs.find(e.name); if (it != vs.end()) n += it->second; }
+      else if (e.kind == Expr::INDEX) { if (vs.count(e.name)) n += 1; }
+      for (const Expr& a : e.args) n += count(a);
+      return n;
+    }
+  } walk{var_size};
+  for (const Constraint& c : m.constraints) {
+    symbols[c.name]++;
+    int64_t deg = 0;
+    for (const Expr& a : c.args) deg += walk.count(a);
+    occurrences += deg;
+    degree_hist["('" + c.name + "', " + std::to_string(deg) + ")"]++;
+  }
+  auto dict = [](const std::map<std::string, int64_t>& d, bool quote) {
+    std::string s = "{";
+    bool first = true;
+    for (auto& kv : d) { s += (first ? "" : ", ") + (quote ? "'" + kv.first + "'" : kv.first) + ": " + std::to_string(kv.second); first = false; }
+    return s + "}";
+  };
+  std::string out;
+  out += "fcn_variables=" + std::to_string(n_vars) + "\n";
+  out += "fcn_constraints=" + std::to_string(m.constraints.size()) + "\n";
+  out += "fcn_var_occurrences=" + std::to_string(occurrences) + "\n";
+  out += "fcn_histogram_symbols=\"" + dict(symbols, true) + "\"\n";
+  out += "fcn_histogram_constraints_degree=\"" + dict(degree_hist, false) + "\"\n";
+  return out;
+}
+
 tf_model* build(const std::string& text, char* err, int32_t err_len) {
   try {
     Model m = parse_flatzinc(text);
     tf_model* out = new tf_model;
     out->tcn = lower_to_tcn(m);
+    out->fcn_stats = analyze_model(m);
     return out;
   } catch (const std::exception& e) {
     set_err(err, err_len, e.what());
@@ -54,6 +101,41 @@ tf_model* tf_load_fzn(const char* path, char* err, int32_t err_len) {
 }
 
 tf_model* tf_load_fzn_string(const char* text, char* err, int32_t err_len) { return build(text ? text : "", err, err_len); }
+
+tf_model* tf_load_xcsp3_string(const char* xml, char* err, int32_t err_len) {
+  std::string fzn;
+  try {
+    fzn = xcsp3_to_flatzinc(xml ? xml : "");
+  } catch (const std::exception& e) {
+    set_err(err, err_len, e.what());
+    return nullptr;
+  }
+  return build(fzn, err, err_len);
+}
+
+tf_model* tf_load_xcsp3(const char* path, char* err, int32_t err_len) {
+  std::ifstream in(path);
+  if (!in) { set_err(err, err_len, std::string("Could not open input file ") + (path ? path : "(null)")); return nullptr; }
+  std::stringstream ss;
+  ss << in.rdbuf();
+  return tf_load_xcsp3_string(ss.str().c_str(), err, err_len);
+}
+
+int32_t tf_xcsp3_to_fzn(const char* xml, char* buf, int32_t buf_len, char* err, int32_t err_len) {
+  std::string fzn;
+  try {
+    fzn = xcsp3_to_flatzinc(xml ? xml : "");
+  } catch (const std::exception& e) {
+    set_err(err, err_len, e.what());
+    return -1;
+  }
+  if (buf && buf_len > 0) {
+    const size_t n = std::min((size_t)buf_len - 1, fzn.size());
+    std::memcpy(buf, fzn.data(), n);
+    buf[n] = '\0';
+  }
+  return (int32_t)fzn.size();
+}
 
 void tf_free(tf_model* m) { delete m; }
 
@@ -143,6 +225,21 @@ int32_t tf_format_solution(const tf_model* m, const tb_itv* store_in, char* buf,
     buf[n] = '\0';
   }
   return (int32_t)out.size();
+}
+
+const char* tf_fcn_statistics(const tf_model* m) { return m->fcn_stats.c_str(); }
+
+int32_t tf_shuffle_strategy(tf_model* m, int32_t strategy, uint64_t seed) {
+  if (strategy < 0 || strategy >= (int32_t)m->tcn.strategies.size()) return -1;
+  Strategy& s = m->tcn.strategies[(size_t)strategy];
+  if (s.vars.empty()) {  // whole store: materialise it so that it can be permuted
+    for (int32_t v = 0; v < (int32_t)m->tcn.store.size(); ++v) s.vars.push_back(v);
+  }
+  std::mt19937 gen((uint32_t)seed);  // std::mt19937 random_generator(config.seed), common_solving.hpp:632
+  std::shuffle(s.vars.begin(), s.vars.end(), gen);
+  s.var_order = TB_INPUT_ORDER;
+  m->tcn.flatten_strategies();
+  return 0;
 }
 
 const char* tf_var_name(const tf_model* m, int32_t var) {

@@ -64,6 +64,8 @@ struct LowerError : std::runtime_error {
 };
 
 TCN lower_to_tcn(const Model& m);
+// XCSP3-core instance (XML text) -> FlatZinc text (xcsp3_reader.cpp)
+std::string xcsp3_to_flatzinc(const std::string& xml_text);
 
 struct SimplifyInfo {
   int32_t original_vars = 0, original_props = 0, simplified_vars = 0, simplified_props = 0;

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -118,6 +119,52 @@ std::string array_text(const std::vector<int32_t>& v) {  // statistics.hpp:31-43
   return s + "]";
 }
 
+// analyze_tcn (common_solving.hpp:728-826): size of the ternary network and, unless -disable_network_analysis,
+// its histograms.  Symbols: a comparison whose truth variable is the constant 0 counts as its negation, one whose
+// truth variable is not assigned counts as reified as well.  A variable is "assigned" when lb = ub (the domain-size
+// histogram is keyed by ub - lb + 1).
+void analyze_tcn(const Options& o, const Printer& p, const std::string& prefix, const tf_model* m) {
+  const int V = tf_num_vars(m), P = tf_num_props(m);
+  p.u((prefix + "_variables").c_str(), (uint64_t)V);
+  p.u((prefix + "_constraints").c_str(), (uint64_t)P);
+  if (o.disable_network_analysis || !o.print_statistics) return;
+  if (o.verbose) std::printf("%% Analyzing the ternary constraint network...\n");
+  const tb_itv* store = tf_store(m);
+  const tb_prop* props = tf_props(m);
+  static const char* sym[] = {"+", "*", "/", "%", "min", "max", "=", "<="};
+  std::map<std::string, uint64_t> ops, reified;
+  std::vector<uint64_t> occ((size_t)V, 0);
+  for (int i = 0; i < P; ++i) {
+    const tb_prop& q = props[i];
+    occ[(size_t)q.x]++; occ[(size_t)q.y]++; occ[(size_t)q.z]++;
+    const tb_itv x = store[q.x];
+    if (q.op == TB_EQ || q.op == TB_LEQ) {
+      if (x.lb == x.ub) ops[x.lb == 0 ? (q.op == TB_EQ ? "!=" : ">") : sym[q.op]]++;
+      else { ops[sym[q.op]]++; reified[sym[q.op]]++; }
+    } else ops[sym[q.op]]++;
+  }
+  std::map<uint64_t, uint64_t> deg_assigned, deg_unassigned, dom_size;
+  uint64_t assigned = 0, unbounded = 0, occ_assigned = 0, occ_unassigned = 0;
+  for (int v = 0; v < V; ++v) {
+    const tb_itv d = store[v];
+    const bool inf = d.lb == TB_NINF || d.ub == TB_PINF;
+    if (inf) unbounded++; else dom_size[(uint64_t)((int64_t)d.ub - (int64_t)d.lb + 1)]++;
+    if (!inf && d.lb == d.ub) { assigned++; deg_assigned[occ[(size_t)v]]++; occ_assigned += occ[(size_t)v]; }
+    else { deg_unassigned[occ[(size_t)v]]++; occ_unassigned += occ[(size_t)v]; }
+  }
+  auto dict_s = [](const std::map<std::string, uint64_t>& d) { std::string s = "{"; bool f = true; for (auto& kv : d) { s += (f ? "'" : ", '") + kv.first + "': " + std::to_string(kv.second); f = false; } return s + "}"; };
+  auto dict_u = [](const std::map<uint64_t, uint64_t>& d) { std::string s = "{"; bool f = true; for (auto& kv : d) { s += (f ? "" : ", ") + std::to_string(kv.first) + ": " + std::to_string(kv.second); f = false; } return s + "}"; };
+  p.u((prefix + "_assigned_variables").c_str(), assigned);
+  p.u((prefix + "_unbounded_variables").c_str(), unbounded);
+  p.u((prefix + "_unassigned_var_occurrences").c_str(), occ_unassigned);
+  p.u((prefix + "_assigned_var_occurrences").c_str(), occ_assigned);
+  p.s((prefix + "_histogram_symbols").c_str(), dict_s(ops).c_str());
+  p.s((prefix + "_histogram_reified_predicates").c_str(), dict_s(reified).c_str());
+  p.s((prefix + "_histogram_unassigned_vars_degree").c_str(), dict_u(deg_unassigned).c_str());
+  p.s((prefix + "_histogram_assigned_vars_degree").c_str(), dict_u(deg_assigned).c_str());
+  p.s((prefix + "_histogram_vars_dom_size").c_str(), dict_u(dom_size).c_str());
+}
+
 // The preprocessing loop of common_solving.hpp:537-585: root fixpoint (on the GPU, `tb_propagate`), then the
 // network simplifier, until neither changes anything.  The propagators are not restated on the host.
 bool simplify_network(const Options& o, const Printer& p, tf_model* m, std::string& err) {
@@ -145,8 +192,7 @@ bool simplify_network(const Options& o, const Printer& p, tf_model* m, std::stri
   p.s("preprocessing_eliminated_variables", array_text(useless).c_str());
   if (o.verbose) std::printf("%% Formula simplified.\n");
   if (!tf_trivially_unsat(m)) {
-    p.u("preprocessed_tcn_variables", (uint64_t)tf_num_vars(m));
-    p.u("preprocessed_tcn_constraints", (uint64_t)tf_num_props(m));
+    analyze_tcn(o, p, "preprocessed_tcn", m);
   }
   return true;
 }
@@ -246,13 +292,14 @@ int main(int argc, char** argv) {
   const auto start = Clock::now();
 
   // preprocess (common_solving.hpp:605-637)
-  const bool is_fzn = o.problem_path.size() >= 4 && o.problem_path.compare(o.problem_path.size() - 4, 4, ".fzn") == 0;
-  if (!is_fzn) {
-    std::printf("ERROR: Unknown input format for the file %s [supported extension: .fzn].\n", o.problem_path.c_str());
+  auto has_ext = [&](const char* e) { const size_t n = std::strlen(e); return o.problem_path.size() >= n && o.problem_path.compare(o.problem_path.size() - n, n, e) == 0; };
+  const bool is_fzn = has_ext(".fzn"), is_xcsp3 = has_ext(".xml");  // config.hpp:268-278
+  if (!is_fzn && !is_xcsp3) {
+    std::printf("ERROR: Unknown input format for the file %s [supported extension: .xml and .fzn].\n", o.problem_path.c_str());
     return EXIT_FAILURE;
   }
   char err[1024] = {0};
-  tf_model* m = tf_load_fzn(o.problem_path.c_str(), err, sizeof(err));
+  tf_model* m = is_fzn ? tf_load_fzn(o.problem_path.c_str(), err, sizeof(err)) : tf_load_xcsp3(o.problem_path.c_str(), err, sizeof(err));
   if (!m) {
     std::cerr << "Could not parse input file." << std::endl;
     if (o.verbose) std::cerr << err << std::endl;
@@ -260,10 +307,13 @@ int main(int argc, char** argv) {
   }
   p.u("parsed_variables", (uint64_t)tf_parsed_variables(m));
   p.u("parsed_constraints", (uint64_t)tf_parsed_constraints(m));
+  if (!o.disable_network_analysis && o.print_statistics) {  // analyze_cn, common_solving.hpp:608-610
+    const std::string lines = tf_fcn_statistics(m);
+    for (size_t b = 0, e; (e = lines.find('\n', b)) != std::string::npos; b = e + 1) std::printf("%%%%%%mzn-stat: %s\n", lines.substr(b, e - b).c_str());
+  }
   p.s("abstract_domain", "pir_itv32_z");
-  p.s("entailed_prop_removal", "deactivated");
-  p.u("tcn_variables", (uint64_t)tf_num_vars(m));
-  p.u("tcn_constraints", (uint64_t)tf_num_props(m));
+  p.s("entailed_prop_removal", o.fixpoint == Fixpoint::EVENT ? "by_slice_entailment" : "deactivated");
+  analyze_tcn(o, p, "tcn", m);
   if (!o.disable_simplify && !tf_trivially_unsat(m)) {
     std::string err_text;
     if (!simplify_network(o, p, m, err_text)) {
@@ -284,6 +334,7 @@ int main(int argc, char** argv) {
     if (vi < 0) { std::printf("Unrecognized option `-eps_var_order %s`\n", o.eps_var_order.c_str()); return EXIT_FAILURE; }
     if (li < 0) { std::printf("Unrecognized option `-eps_value_order %s`\n", o.eps_value_order.c_str()); return EXIT_FAILURE; }
     tf_push_eps_strategy(m, vi, li);
+    if (o.eps_var_order == "random") tf_shuffle_strategy(m, 0, o.seed);  // common_solving.hpp:632-633
     has_eps = true;
   }
   const int n_vars = tf_num_vars(m), n_props = tf_num_props(m);

@@ -38,6 +38,11 @@ def lib() -> C.CDLL:
         L.tf_load_fzn_string.restype = C.c_void_p
         L.tf_load_fzn_string.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
         L.tf_free.argtypes = [C.c_void_p]
+        for name in ("tf_load_xcsp3", "tf_load_xcsp3_string"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
+        L.tf_xcsp3_to_fzn.restype = C.c_int32
+        L.tf_xcsp3_to_fzn.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32]
         for name in ("tf_num_vars", "tf_num_props", "tf_num_strategies", "tf_obj_var", "tf_goal", "tf_goal_var",
                      "tf_trivially_unsat", "tf_parsed_variables", "tf_parsed_constraints"):
             getattr(L, name).restype = C.c_int32
@@ -61,6 +66,10 @@ def lib() -> C.CDLL:
             getattr(L, name).argtypes = [C.c_void_p]
         L.tf_expand_solution.restype = C.c_int32
         L.tf_expand_solution.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tf_fcn_statistics.restype = C.c_char_p
+        L.tf_fcn_statistics.argtypes = [C.c_void_p]
+        L.tf_shuffle_strategy.restype = C.c_int32
+        L.tf_shuffle_strategy.argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
         L.tf_var_name.restype = C.c_char_p
         L.tf_var_name.argtypes = [C.c_void_p, C.c_int32]
         _lib = L
@@ -139,6 +148,22 @@ class Model:
             raise ValueError(err.value.decode(errors="replace") or "Could not parse input file.")
         return cls(h)
 
+    @classmethod
+    def from_xcsp3_file(cls, path: str) -> "Model":
+        err = C.create_string_buffer(1024)
+        h = lib().tf_load_xcsp3(os.fsencode(path), err, len(err))
+        if not h:
+            raise ValueError(err.value.decode(errors="replace") or "Could not parse input file.")
+        return cls(h)
+
+    @classmethod
+    def from_xcsp3_string(cls, xml: str) -> "Model":
+        err = C.create_string_buffer(1024)
+        h = lib().tf_load_xcsp3_string(xml.encode(), err, len(err))
+        if not h:
+            raise ValueError(err.value.decode(errors="replace") or "Could not parse input file.")
+        return cls(h)
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
@@ -204,8 +229,32 @@ class Model:
         lib().tf_format_solution(self._h, store.ctypes.data, buf, n + 1)
         return buf.value.decode()
 
+    def fcn_statistics(self) -> dict:
+        """analyze_cn statistics of the model as parsed (key -> text)."""
+        out = {}
+        for line in lib().tf_fcn_statistics(self._h).decode().splitlines():
+            k, _, v = line.partition("=")
+            out[k] = v.strip('"')
+        return out
+
+    def shuffle_strategy(self, strategy: int, seed: int) -> None:
+        """`-eps_var_order random`: INPUT_ORDER over the strategy's variables shuffled with mt19937(seed)."""
+        if lib().tf_shuffle_strategy(self._h, strategy, seed) != 0:
+            raise ValueError("no such strategy")
+
     def var_name(self, v: int) -> str:
         return lib().tf_var_name(self._h, v).decode()
+
+
+def xcsp3_to_fzn(xml: str) -> str:
+    """The FlatZinc text an XCSP3 instance is rewritten to (debugging aid)."""
+    err = C.create_string_buffer(1024)
+    n = lib().tf_xcsp3_to_fzn(xml.encode(), None, 0, err, len(err))
+    if n < 0:
+        raise ValueError(err.value.decode(errors="replace"))
+    buf = C.create_string_buffer(n + 1)
+    lib().tf_xcsp3_to_fzn(xml.encode(), buf, n + 1, err, len(err))
+    return buf.value.decode()
 
 
 def load_fzn(path: str, eps_var_order: str = "default", eps_value_order: str = "default") -> TCN:
