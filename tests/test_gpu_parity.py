@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 ROWS = known_answers()
 FAST = [r for r in ROWS if r[0] not in SLOW_FOR_ORACLE]
 HEADLINE = ["example_wordpress7_500.fzn", "accap_a3.fzn"]
+COMPACT = 0x100000  # tb_config.reserved[0]: force the 2-bit Boolean store layout of the event kernels
 
 
 def load(rel):
@@ -71,21 +72,24 @@ def check_batch(tcn, stores, **cfg):
 
 
 @pytest.mark.parametrize("rel", [r[0] for r in ROWS] + HEADLINE)
-@pytest.mark.parametrize("fixpoint", [0, 1, 2], ids=["ac1", "wac1", "event"])
-def test_root_fixpoint_bit_exact(rel, fixpoint):
+@pytest.mark.parametrize("fixpoint,debug", [(0, 0), (1, 0), (2, 0), (2, COMPACT)], ids=["ac1", "wac1", "event", "event_compact"])
+def test_root_fixpoint_bit_exact(rel, fixpoint, debug):
     tcn = load(rel)
-    check_batch(tcn, tcn.store[None, :], fixpoint=fixpoint)
+    check_batch(tcn, tcn.store[None, :], fixpoint=fixpoint, debug=debug)
 
 
 @pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pennies5.fzn",
                                  "test_data/triangular9.fzn", "test_data/bug4.fzn", "accap_a3.fzn"])
-@pytest.mark.parametrize("mode", ["wac1", "ac1", "globalmem", "t1024", "event", "event_globalmem", "event_t1024"])
+@pytest.mark.parametrize("mode", ["wac1", "ac1", "globalmem", "t1024", "event", "event_globalmem", "event_t1024",
+                                  "event_compact", "event_compact_globalmem", "event_compact_t1024"])
 def test_random_nodes_bit_exact(rel, mode):
     tcn = load(rel)
     stores = random_nodes(tcn, 48, seed=zlib.crc32(rel.encode()) % 1000)
     cfg = {"wac1": dict(fixpoint=1), "ac1": dict(fixpoint=0), "globalmem": dict(fixpoint=1, only_global_memory=1),
            "t1024": dict(fixpoint=1, threads_per_block=1024), "event": dict(fixpoint=2),
-           "event_globalmem": dict(fixpoint=2, only_global_memory=1), "event_t1024": dict(fixpoint=2, threads_per_block=1024)}[mode]
+           "event_globalmem": dict(fixpoint=2, only_global_memory=1), "event_t1024": dict(fixpoint=2, threads_per_block=1024),
+           "event_compact": dict(fixpoint=2, debug=COMPACT), "event_compact_globalmem": dict(fixpoint=2, only_global_memory=1, debug=COMPACT),
+           "event_compact_t1024": dict(fixpoint=2, threads_per_block=1024, debug=COMPACT)}[mode]
     check_batch(tcn, stores, **cfg)
 
 
@@ -93,15 +97,17 @@ def test_wordpress_nodes_bit_exact():
     tcn = load("example_wordpress7_500.fzn")
     stores = random_nodes(tcn, 12, seed=7, max_decisions=6)
     check_batch(tcn, stores, fixpoint=1)
+    check_batch(tcn, stores, fixpoint=2)  # compact layout chosen by the engine itself (store moves into LDS)
+    check_batch(tcn, stores, fixpoint=2, debug=0x80000)  # the same without it
 
 
-@pytest.mark.parametrize("fixpoint", [1, 2], ids=["wac1", "event"])
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT)], ids=["wac1", "event", "event_compact"])
 @pytest.mark.parametrize("rel,expected", FAST)
-def test_sequential_tree_identical(rel, expected, fixpoint):
+def test_sequential_tree_identical(rel, expected, fixpoint, debug):
     """One workgroup, one subproblem: the GPU explores exactly the oracle's DFS tree."""
     tcn = load(rel)
     has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=0, timeout_ms=120000)
-    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=0, timeout_ms=120000, fixpoint=fixpoint))
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=0, timeout_ms=120000, fixpoint=fixpoint, debug=debug))
     assert has_g == has_o and st_g["exhaustive"] == st_o["exhaustive"] == 1
     assert tcn.objective_of(best_g) == expected
     for k in ("nodes", "fails", "solutions", "depth_max"):
@@ -111,36 +117,38 @@ def test_sequential_tree_identical(rel, expected, fixpoint):
 
 @pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pat7.fzn", "test_data/sudoku_opt_p0.fzn"])
 @pytest.mark.parametrize("power", [3, 6])
-@pytest.mark.parametrize("fixpoint,levels", [(1, 0), (2, 0), (2, 1), (2, 3)], ids=["wac1", "event", "event_recompute", "event_3levels"])
-def test_sequential_eps_identical(rel, power, fixpoint, levels):
+@pytest.mark.parametrize("fixpoint,levels,debug", [(1, 0, 0), (2, 0, 0), (2, 1, 0), (2, 3, 0), (2, 0, COMPACT), (2, 1, COMPACT)],
+                         ids=["wac1", "event", "event_recompute", "event_3levels", "event_compact", "event_compact_recompute"])
+def test_sequential_eps_identical(rel, power, fixpoint, levels, debug):
     """One workgroup walking 2^d subproblems in index order == the oracle's sequential dive-and-solve
     (snapshot_levels=1 is the reference's recompute-from-root backtracking)."""
     tcn = load(rel)
     has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power)
-    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=power, timeout_ms=120000, fixpoint=fixpoint, snapshot_levels=levels))
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=power, timeout_ms=120000, fixpoint=fixpoint, snapshot_levels=levels, debug=debug))
     assert has_g == has_o
     for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
         assert st_g[k] == st_o[k], k
     np.testing.assert_array_equal(best_g, best_o)
 
 
-@pytest.mark.parametrize("fixpoint", [1, 2], ids=["wac1", "event"])
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT)], ids=["wac1", "event", "event_compact"])
 @pytest.mark.parametrize("rel,expected", ROWS)
-def test_parallel_objective_matches_known_answer(rel, expected, fixpoint):
+def test_parallel_objective_matches_known_answer(rel, expected, fixpoint, debug):
     """Reference regression contract (test_turbo.sh:34-67): the objective of every instance."""
     tcn = load(rel)
-    has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=60000, fixpoint=fixpoint))
+    has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=60000, fixpoint=fixpoint, debug=debug))
     assert has
     assert tcn.objective_of(best) == expected
     assert st["exhaustive"] == 1, "optimality must be proved within the reference's 60 s budget"
 
 
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, COMPACT)], ids=["wac1", "event_compact"])
 @pytest.mark.parametrize("rel,expected", FAST)
-def test_parallel_canonical_solution_bit_exact(rel, expected):
+def test_parallel_canonical_solution_bit_exact(rel, expected, fixpoint, debug):
     """deterministic=1: the returned solution is the DFS-first optimal one, identical to the oracle's."""
     tcn = load(rel)
     power = 8
-    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(timeout_ms=60000, deterministic=1, subproblems_power=power))
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(timeout_ms=60000, deterministic=1, subproblems_power=power, fixpoint=fixpoint, debug=debug))
     assert has_g and st_g["exhaustive"] == 1
     has_b, best_b, st_b = pyoracle.solve(tcn, subproblems_power=power)
     assert st_b["best_bound"] == st_g["best_bound"]

@@ -55,12 +55,12 @@ def assert_valid(tcn, store):
 
 
 @pytest.mark.parametrize("text", [ALLDIFF3, MANY], ids=["alldiff3", "many"])
-@pytest.mark.parametrize("fixpoint", [1, 2], ids=["wac1", "event"])
-def test_all_solutions_of_a_satisfaction_problem(text, fixpoint):
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, 0x100000)], ids=["wac1", "event", "event_compact"])
+def test_all_solutions_of_a_satisfaction_problem(text, fixpoint, debug):
     tcn = frontend.Model.from_string(text).tcn()
     _, _, ost = pyoracle.solve(tcn, stop_after_n_solutions=0)
     assert ost["exhaustive"] and ost["solutions"] > 0
-    got, has, best, st = run_streaming(tcn, fixpoint=fixpoint, stop_after_n_solutions=0)
+    got, has, best, st = run_streaming(tcn, fixpoint=fixpoint, stop_after_n_solutions=0, debug=debug)
     assert has and st["exhaustive"]
     assert st["solutions"] == ost["solutions"] == len(got)
     seen = set()
@@ -83,10 +83,10 @@ def test_first_k_solutions(k):
 
 
 @pytest.mark.parametrize("rel,expected", [("test_data/pennies5.fzn", 5), ("test_data/pat9.fzn", 19), ("test_data/sudoku_opt_p0.fzn", -3)])
-@pytest.mark.parametrize("fixpoint", [1, 2], ids=["wac1", "event"])
-def test_improving_solutions_end_on_the_optimum(rel, expected, fixpoint):
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, 0x100000)], ids=["wac1", "event", "event_compact"])
+def test_improving_solutions_end_on_the_optimum(rel, expected, fixpoint, debug):
     tcn = frontend.load_fzn(os.path.join(BENCH, rel))
-    got, has, best, st = run_streaming(tcn, fixpoint=fixpoint)
+    got, has, best, st = run_streaming(tcn, fixpoint=fixpoint, debug=debug)
     assert has and st["exhaustive"] and tcn.objective_of(best) == expected
     assert got, "an optimisation run that found a solution streams at least one"
     objs = [o for _, o in got]

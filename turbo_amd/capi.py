@@ -128,6 +128,8 @@ def make_config(**kw) -> TbConfig:
     cfg.stop_after_n_solutions = 1
     cfg.fixpoint = 1  # WAC1 is the GPU default (config.hpp:91-97)
     cfg.world_size = 1
+    if "debug" in kw:  # tuning / test knobs of tb_config.reserved[0] (e.g. 0x100000: force the COMPACT store layout)
+        cfg.reserved[0] = int(kw.pop("debug"))
     for k, v in kw.items():
         if not hasattr(cfg, k):
             raise TypeError(f"unknown tb_config field {k}")

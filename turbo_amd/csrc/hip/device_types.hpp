@@ -64,7 +64,9 @@ struct DevProblem {
   const int* adj;       // remaining slice ids of the variables read by more than two slices
   int n_slices;         // ceil(n_props / 64)
   int dirty_words;      // ceil(n_slices / 32)
-  int vext;             // int2 elements of a store slab: n_vars + one "not entailed" byte per slice
+  int vext;             // int2 elements of a store slab (even): intervals, Boolean words, one "not entailed" byte per slice
+  int n_int;            // variables stored as int2 {lb,ub}; variables >= n_int are 2-bit Booleans (COMPACT layout), else n_int = n_vars
+  int unent_off;        // byte offset of the per-slice bytes in a slab
   int chg_cap;          // capacity of one change list (entries)
   // configuration
   int fixpoint;            // 0 AC1, 1 WAC1, 2 event-driven WAC1

@@ -76,14 +76,74 @@ struct LaunchPlan {
   int snapshot_levels = 1;
   int max_depth = 16384;
   int n_slices = 0, dirty_words = 0, vext = 0, chg_cap = 64;
+  int compact = 0, n_int = 0, unent_off = 0;  // store layout (Layout below)
 };
+
+// Store layout of a session.  COMPACT: the variables whose root domain lies within 0..1 are renumbered behind the
+// others and kept as 2 bits each (kernels.hpp: load_dom / raise_lb / lower_ub); everything the engine works on --
+// propagators, strategies, objective, adjacency -- is expressed in the internal numbering, and stores are
+// converted at the boundary (encode_slab / decode_slab).  Without COMPACT the numbering is the caller's.
+struct Layout {
+  bool compact = false;
+  int n_vars = 0, n_int = 0, n_bool = 0;
+  std::vector<int> perm, inv;  // perm[caller's id] = internal id, inv = its inverse
+  int bool_words() const { return (n_bool + 15) / 16; }
+  int unent_off() const { return n_int * 8 + bool_words() * 4; }
+  int vext(int n_slices) const { return (int)((((size_t)unent_off() + (size_t)n_slices + 15) / 16) * 2); }
+};
+
+Layout make_layout(int32_t n_vars, int32_t n_stores, const tb_itv* stores, bool compact) {
+  Layout L;
+  L.n_vars = n_vars; L.compact = compact;
+  L.perm.resize((size_t)n_vars); L.inv.resize((size_t)n_vars);
+  std::vector<char> is_bool((size_t)n_vars, 0);
+  if (compact) {
+    for (int32_t v = 0; v < n_vars; ++v) {
+      bool b = n_stores > 0;
+      for (int32_t k = 0; k < n_stores && b; ++k) { const tb_itv d = stores[(size_t)k * (size_t)n_vars + (size_t)v]; b = d.lb >= 0 && d.ub <= 1; }
+      is_bool[(size_t)v] = b ? 1 : 0;
+    }
+  }
+  int next = 0;
+  for (int32_t v = 0; v < n_vars; ++v) if (!is_bool[(size_t)v]) L.perm[(size_t)v] = next++;
+  L.n_int = next;
+  for (int32_t v = 0; v < n_vars; ++v) if (is_bool[(size_t)v]) L.perm[(size_t)v] = next++;
+  L.n_bool = n_vars - L.n_int;
+  for (int32_t v = 0; v < n_vars; ++v) L.inv[(size_t)L.perm[(size_t)v]] = v;
+  if (L.n_bool == 0) L.compact = false;
+  return L;
+}
+
+// caller's store -> slab (zero-initialised by the caller of this function, `vext * 8` bytes)
+void encode_slab(const Layout& L, const tb_itv* orig, unsigned char* slab) {
+  tb_itv* ints = reinterpret_cast<tb_itv*>(slab);
+  unsigned* words = reinterpret_cast<unsigned*>(slab + (size_t)L.n_int * 8);
+  for (int v = 0; v < L.n_vars; ++v) {
+    const int i = L.perm[(size_t)v];
+    if (i < L.n_int) { ints[i] = orig[v]; continue; }
+    const int b = i - L.n_int;
+    const unsigned bits = (orig[v].lb >= 1 ? 1u : 0u) | (orig[v].ub <= 0 ? 2u : 0u);
+    words[b >> 4] |= bits << ((b & 15) * 2);
+  }
+}
+void decode_slab(const Layout& L, const unsigned char* slab, tb_itv* orig_out) {
+  const tb_itv* ints = reinterpret_cast<const tb_itv*>(slab);
+  const unsigned* words = reinterpret_cast<const unsigned*>(slab + (size_t)L.n_int * 8);
+  for (int i = 0; i < L.n_vars; ++i) {
+    tb_itv d;
+    if (i < L.n_int) d = ints[i];
+    else { const int b = i - L.n_int; const unsigned bits = (words[b >> 4] >> ((b & 15) * 2)) & 3u; d.lb = (int)(bits & 1u); d.ub = 1 - (int)(bits >> 1); }
+    orig_out[L.inv[(size_t)i]] = d;
+  }
+}
 
 inline size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 
 // Which memory holds what (the MemoryKind decision of memory_gpu.hpp:56-83 with CDNA4 numbers:
 // 160 KiB of LDS per CU, wave64, at most 32 waves per CU) and how many workgroups to launch
 // (barebones:530-546: occupancy x CUs, capped by -or).
-int plan_launch(const tb_config& cfg, const DeviceCaps& caps, int n_vars, int n_props, LaunchPlan* plan) {
+int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay, int n_props, LaunchPlan* plan) {
+  const int n_vars = lay.n_vars;
   LaunchPlan p;
   int T = cfg.threads_per_block;
   // Full sweeps (AC1/WAC1) want a wide workgroup: the sweep is throughput bound.  The event-driven fixpoint
@@ -96,8 +156,9 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, int n_vars, int n_
   const size_t lds = (size_t)caps.lds_per_cu;
   // slab = domains + one entailment byte per slice, rounded to an even number of intervals so that every slab of a
   // stack (stores, snapshots) starts 16-byte aligned and copies as 16-byte words
-  const int n_slices = (n_props + 63) / 64, dirty_words = (n_slices + 31) / 32, vext = (n_vars + (n_slices + 7) / 8 + 1) & ~1;
+  const int n_slices = (n_props + 63) / 64, dirty_words = (n_slices + 31) / 32, vext = lay.vext(n_slices);
   p.n_slices = n_slices; p.dirty_words = dirty_words; p.vext = vext;
+  p.compact = lay.compact ? 1 : 0; p.n_int = lay.n_int; p.unent_off = lay.unent_off();
   // store slab = domains + one entailment byte per 64-propagator slice; the three dirty bitmaps of the
   // event-driven fixpoint always live in LDS
   // one dirty bitmap + two change lists of (variable, slice) pairs; an overflowing list falls back to a full sweep
@@ -232,18 +293,18 @@ void find_constants(int32_t n_vars, int32_t n_stores, const tb_itv* stores, std:
   }
 }
 
-template <int MEM, int TMAX, bool EVENT>
+template <int MEM, int TMAX, bool EVENT, bool C>
 int prepare_solve(int bytes, int threads, int* max_blocks_per_cu) {
-  const void* k = reinterpret_cast<const void*>(&solve_kernel<MEM, TMAX, EVENT>);
+  const void* k = reinterpret_cast<const void*>(&solve_kernel<MEM, TMAX, EVENT, C>);
   HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   int nb = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, threads, (size_t)bytes));
   *max_blocks_per_cu = nb;
   return TB_OK;
 }
-template <int MEM, int TMAX, bool EVENT>
+template <int MEM, int TMAX, bool EVENT, bool C>
 int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
-  const void* k = reinterpret_cast<const void*>(&propagate_kernel<MEM, TMAX, EVENT>);
+  const void* k = reinterpret_cast<const void*>(&propagate_kernel<MEM, TMAX, EVENT, C>);
   HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   int nb = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, threads, (size_t)bytes));
@@ -251,30 +312,67 @@ int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
   return TB_OK;
 }
 
-#define DISPATCH_MEM(FN, TM, EV, mem, ...)                                          \
-  do {                                                                              \
-    if (mem == TB_MEM_GLOBAL) FN<TB_MEM_GLOBAL, TM, EV> __VA_ARGS__;                \
-    else if (mem == TB_MEM_STORE_SHARED) FN<TB_MEM_STORE_SHARED, TM, EV> __VA_ARGS__; \
-    else FN<TB_MEM_TCN_SHARED, TM, EV> __VA_ARGS__;                                 \
+#define DISPATCH_MEM(FN, TM, EV, CP, mem, ...)                                          \
+  do {                                                                                  \
+    if (mem == TB_MEM_GLOBAL) FN<TB_MEM_GLOBAL, TM, EV, CP> __VA_ARGS__;                \
+    else if (mem == TB_MEM_STORE_SHARED) FN<TB_MEM_STORE_SHARED, TM, EV, CP> __VA_ARGS__; \
+    else FN<TB_MEM_TCN_SHARED, TM, EV, CP> __VA_ARGS__;                                 \
   } while (0)
-#define DISPATCH_KERNEL(FN, mem, tmax, event, ...)                                  \
-  do {                                                                              \
-    if (tmax == 256) {                                                              \
-      if (event) DISPATCH_MEM(FN, 256, true, mem, __VA_ARGS__);                     \
-      else DISPATCH_MEM(FN, 256, false, mem, __VA_ARGS__);                          \
-    } else {                                                                        \
-      if (event) DISPATCH_MEM(FN, 1024, true, mem, __VA_ARGS__);                    \
-      else DISPATCH_MEM(FN, 1024, false, mem, __VA_ARGS__);                         \
-    }                                                                               \
+// the COMPACT store layout exists for the event-driven kernels only (the sweeps are VALU bound: decoding 2-bit
+// Booleans would cost them more than the LDS it frees)
+#define DISPATCH_KERNEL(FN, mem, tmax, event, compact, ...)                             \
+  do {                                                                                  \
+    if (tmax == 256) {                                                                  \
+      if (event && compact) DISPATCH_MEM(FN, 256, true, true, mem, __VA_ARGS__);        \
+      else if (event) DISPATCH_MEM(FN, 256, true, false, mem, __VA_ARGS__);             \
+      else DISPATCH_MEM(FN, 256, false, false, mem, __VA_ARGS__);                       \
+    } else {                                                                            \
+      if (event && compact) DISPATCH_MEM(FN, 1024, true, true, mem, __VA_ARGS__);       \
+      else if (event) DISPATCH_MEM(FN, 1024, true, false, mem, __VA_ARGS__);            \
+      else DISPATCH_MEM(FN, 1024, false, false, mem, __VA_ARGS__);                      \
+    }                                                                                   \
   } while (0)
 
 // Sets the dynamic-LDS limit of the kernel that will run and returns how many of its workgroups a CU holds
 // (register / LDS limited).  A persistent kernel gains nothing from queued workgroups, so the grid is capped.
-int prepare_kernel(bool solve, int mem, int tmax, bool event, int bytes, int threads, int* max_blocks_per_cu) {
+int prepare_kernel(bool solve, int mem, int tmax, bool event, bool compact, int bytes, int threads, int* max_blocks_per_cu) {
   int rc = TB_OK;
-  if (solve) DISPATCH_KERNEL(rc = prepare_solve, mem, tmax, event, (bytes, threads, max_blocks_per_cu));
-  else DISPATCH_KERNEL(rc = prepare_prop, mem, tmax, event, (bytes, threads, max_blocks_per_cu));
+  if (solve) DISPATCH_KERNEL(rc = prepare_solve, mem, tmax, event, compact, (bytes, threads, max_blocks_per_cu));
+  else DISPATCH_KERNEL(rc = prepare_prop, mem, tmax, event, compact, (bytes, threads, max_blocks_per_cu));
   return rc;
+}
+
+// Layout + launch plan of a network.  The COMPACT layout is chosen for the event-driven fixpoint when it brings a
+// store that would otherwise sit in global memory into LDS (tb_config.reserved[0]: 0x80000 never, 0x100000 always).
+int choose_layout(const tb_config& cfg, const DeviceCaps& caps, int32_t n_vars, int32_t n_stores, const tb_itv* stores, int32_t n_props,
+                  Layout* lay, LaunchPlan* plan) {
+  *lay = make_layout(n_vars, n_stores, stores, false);
+  int rc = plan_launch(cfg, caps, *lay, n_props, plan);
+  if (rc != TB_OK || cfg.fixpoint != 2 || (cfg.reserved[0] & 0x80000)) return rc;
+  Layout lc = make_layout(n_vars, n_stores, stores, true);
+  if (!lc.compact) return rc;
+  LaunchPlan pc;
+  if ((rc = plan_launch(cfg, caps, lc, n_props, &pc)) != TB_OK) return rc;
+  const bool forced = (cfg.reserved[0] & 0x100000) != 0;
+  if (forced || (plan->mem_kind == TB_MEM_GLOBAL && pc.mem_kind != TB_MEM_GLOBAL)) { *lay = std::move(lc); *plan = pc; }
+  return TB_OK;
+}
+
+// The caller's network in the internal numbering of a layout.
+struct InternalNet {
+  std::vector<tb_itv> store;  // first store of the batch, internal order
+  std::vector<tb_prop> props;
+};
+InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, const tb_prop* props) {
+  InternalNet n;
+  n.store.resize((size_t)L.n_vars);
+  for (int v = 0; v < L.n_vars; ++v) n.store[(size_t)L.perm[(size_t)v]] = store[v];
+  n.props.resize((size_t)n_props);
+  for (int32_t i = 0; i < n_props; ++i) {
+    const tb_prop& q = props[i];
+    n.props[(size_t)i] = tb_prop{q.op, L.perm[(size_t)q.x], L.perm[(size_t)q.y], L.perm[(size_t)q.z]};
+  }
+  return n;
 }
 
 struct DevBuffers {
@@ -298,6 +396,7 @@ struct DevBuffers {
 struct tb_session {
   tb_config cfg{};
   DeviceCaps caps;
+  Layout lay;
   LaunchPlan plan;
   DevProblem P{};
   DevBuffers bufs;
@@ -323,7 +422,7 @@ struct tb_session {
   }
   unsigned long long* ring_consumed() const { return reinterpret_cast<unsigned long long*>(ring_host); }
   unsigned long long* ring_seq() const { return reinterpret_cast<unsigned long long*>(ring_host + 64); }
-  tb_itv* ring_data() const { return reinterpret_cast<tb_itv*>(ring_host + 64 + align16((size_t)ring_slots * 8)); }
+  unsigned char* ring_data() const { return ring_host + 64 + align16((size_t)ring_slots * 8); }  // [slots] slabs of plan.vext intervals
 };
 
 extern "C" {
@@ -376,21 +475,25 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   if (n_stores == 0) return TB_OK;
   DeviceCaps caps;
   if ((rc = query_caps(cfg.device, &caps)) != TB_OK) return rc;
+  Layout lay;
   LaunchPlan plan;
-  if ((rc = plan_launch(cfg, caps, n_vars, n_props, &plan)) != TB_OK) return rc;
+  if ((rc = choose_layout(cfg, caps, n_vars, n_stores, stores_inout, n_props, &lay, &plan)) != TB_OK) return rc;
+  const size_t VX = (size_t)plan.vext, slab_bytes = VX * 8;
 
   DevBuffers bufs;
   DevProblem P{};
   int4* d_props = nullptr; int2* d_stores = nullptr; PropagateOut* d_out = nullptr;
   if ((rc = bufs.alloc(&d_props, (size_t)n_props)) != TB_OK) return rc;
-  if ((rc = bufs.alloc(&d_stores, (size_t)n_stores * (size_t)n_vars)) != TB_OK) return rc;
+  if ((rc = bufs.alloc(&d_stores, (size_t)n_stores * VX)) != TB_OK) return rc;
   if ((rc = bufs.alloc(&d_out, (size_t)n_stores)) != TB_OK) return rc;
   {
-    std::vector<char> is_const;
-    std::vector<int> value;
-    find_constants(n_vars, n_stores, stores_inout, &is_const, &value);
-    const Adjacency adj = build_adjacency(n_vars, n_props, props, is_const);
-    const std::vector<int4> packed = pack_props(n_props, props, is_const, value, adj);
+    std::vector<char> c0, is_const((size_t)n_vars);
+    std::vector<int> v0, value((size_t)n_vars);
+    find_constants(n_vars, n_stores, stores_inout, &c0, &v0);
+    for (int v = 0; v < n_vars; ++v) { is_const[(size_t)lay.perm[(size_t)v]] = c0[(size_t)v]; value[(size_t)lay.perm[(size_t)v]] = v0[(size_t)v]; }
+    const InternalNet net = to_internal(lay, stores_inout, n_props, props);
+    const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const);
+    const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), (size_t)n_props * sizeof(int4), hipMemcpyHostToDevice));
     int4* d_head = nullptr; int* d_adj = nullptr;
     if ((rc = bufs.alloc(&d_head, adj.heads.size())) != TB_OK) return rc;
@@ -398,19 +501,19 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     HIP_TRY(hipMemcpy(d_head, adj.heads.data(), adj.heads.size() * sizeof(int4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_adj, adj.rest.data(), adj.rest.size() * 4, hipMemcpyHostToDevice));
     P.adj_head = d_head; P.adj = d_adj;
-    if (plan.mem_kind == TB_MEM_GLOBAL) { if ((rc = bufs.alloc(&P.g_store, (size_t)plan.num_blocks * (size_t)plan.vext)) != TB_OK) return rc; }
   }
   P.n_slices = plan.n_slices; P.dirty_words = plan.dirty_words; P.vext = plan.vext; P.chg_cap = plan.chg_cap;
-  if (n_vars) HIP_TRY(hipMemcpy(d_stores, stores_inout, (size_t)n_stores * (size_t)n_vars * sizeof(tb_itv), hipMemcpyHostToDevice));
+  P.n_int = plan.n_int; P.unent_off = plan.unent_off;
+  std::vector<unsigned char> slabs((size_t)n_stores * slab_bytes, 0);
+  for (int32_t k = 0; k < n_stores; ++k) encode_slab(lay, stores_inout + (size_t)k * (size_t)n_vars, slabs.data() + (size_t)k * slab_bytes);
+  HIP_TRY(hipMemcpy(d_stores, slabs.data(), slabs.size(), hipMemcpyHostToDevice));
   P.n_vars = n_vars; P.n_props = n_props; P.props = d_props;
   P.fixpoint = cfg.fixpoint; P.wac1_threshold = (int)std::min<uint64_t>(cfg.wac1_threshold, 0x7fffffffu);
   P.mem_kind = plan.mem_kind; P.debug = cfg.reserved[0];
-  const uint64_t timeout_ms = cfg.timeout_ms ? cfg.timeout_ms : 60000;
-  // watchdog deadline in device wall-clock ticks (read the counter through a tiny query below)
-  const bool event = cfg.fixpoint == 2;
+  const bool event = cfg.fixpoint == 2, compact = plan.compact != 0;
   {
     int occ = 0;
-    if ((rc = prepare_kernel(false, plan.mem_kind, plan.tmax, event, plan.shared_bytes, plan.threads, &occ)) != TB_OK) return rc;
+    if ((rc = prepare_kernel(false, plan.mem_kind, plan.tmax, event, compact, plan.shared_bytes, plan.threads, &occ)) != TB_OK) return rc;
     if (occ > 0) plan.num_blocks = std::min(plan.num_blocks, occ * caps.cus);
   }
   hipStream_t stream;
@@ -418,11 +521,10 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
-  (void)timeout_ms;
   P.deadline_ticks = 0;
   const int grid = std::min(n_stores, plan.num_blocks);
   HIP_TRY(hipEventRecord(e0, stream));
-  DISPATCH_KERNEL(propagate_kernel, plan.mem_kind, plan.tmax, event, <<<dim3(grid), dim3(plan.threads), plan.shared_bytes, stream>>>(P, d_stores, d_out, n_stores));
+  DISPATCH_KERNEL(propagate_kernel, plan.mem_kind, plan.tmax, event, compact, <<<dim3(grid), dim3(plan.threads), plan.shared_bytes, stream>>>(P, d_stores, d_out, n_stores));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e1, stream));
   HIP_TRY(hipStreamSynchronize(stream));
@@ -432,7 +534,8 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(stream);
   std::vector<PropagateOut> outs((size_t)n_stores);
   HIP_TRY(hipMemcpy(outs.data(), d_out, (size_t)n_stores * sizeof(PropagateOut), hipMemcpyDeviceToHost));
-  if (n_vars) HIP_TRY(hipMemcpy(stores_inout, d_stores, (size_t)n_stores * (size_t)n_vars * sizeof(tb_itv), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(slabs.data(), d_stores, slabs.size(), hipMemcpyDeviceToHost));
+  for (int32_t k = 0; k < n_stores; ++k) decode_slab(lay, slabs.data() + (size_t)k * slab_bytes, stores_inout + (size_t)k * (size_t)n_vars);
   for (int32_t s = 0; s < n_stores; ++s) {
     if (failed_out) failed_out[s] = outs[(size_t)s].failed;
     if (all_entailed_out) all_entailed_out[s] = outs[(size_t)s].all_entailed;
@@ -468,36 +571,51 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   s->cfg = *cfg_in;
   s->n_vars = n_vars; s->obj_var = obj_var;
   if ((rc = query_caps(s->cfg.device, &s->caps)) != TB_OK) return rc;
-  if ((rc = plan_launch(s->cfg, s->caps, n_vars, n_props, &s->plan)) != TB_OK) return rc;
+  if ((rc = choose_layout(s->cfg, s->caps, n_vars, 1, root_store, n_props, &s->lay, &s->plan)) != TB_OK) return rc;
   {
     // cap the grid by what is actually resident (registers, LDS): queued workgroups of a persistent kernel only
     // add tail latency; re-plan so that the subproblem count follows the real workgroup count
     int occ = 0;
-    if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->cfg.fixpoint == 2, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
+    if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->cfg.fixpoint == 2, s->plan.compact != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     if (occ > 0 && (long long)occ * s->caps.cus < (long long)s->plan.num_blocks) {
       tb_config capped = s->cfg;
       capped.or_nodes = (uint64_t)occ * (uint64_t)s->caps.cus;
-      if ((rc = plan_launch(capped, s->caps, n_vars, n_props, &s->plan)) != TB_OK) return rc;
-      if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->cfg.fixpoint == 2, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
+      if ((rc = choose_layout(capped, s->caps, n_vars, 1, root_store, n_props, &s->lay, &s->plan)) != TB_OK) return rc;
+      if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->cfg.fixpoint == 2, s->plan.compact != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     }
   }
   const LaunchPlan& plan = s->plan;
+  const Layout& lay = s->lay;
   DevProblem& P = s->P;
   const size_t V = (size_t)n_vars, B = (size_t)plan.num_blocks;
+  const size_t VX = (size_t)plan.vext;
+
+  // strategies in the internal numbering; with a renumbered store a whole-store strategy (empty list) becomes the
+  // explicit list of all variables in the caller's order, so that ties still resolve to the caller's lowest index
+  std::vector<int32_t> i_off((size_t)n_strats + 1, 0), i_vars;
+  for (int32_t k = 0; k < n_strats; ++k) {
+    i_off[(size_t)k] = (int32_t)i_vars.size();
+    if (strat_off[k] == strat_off[k + 1] && lay.compact) for (int32_t v = 0; v < n_vars; ++v) i_vars.push_back(lay.perm[(size_t)v]);
+    else for (int32_t j = strat_off[k]; j < strat_off[k + 1]; ++j) i_vars.push_back(lay.perm[(size_t)strat_vars[j]]);
+  }
+  i_off[(size_t)n_strats] = (int32_t)i_vars.size();
+  total_svars = (int32_t)i_vars.size();
+  const int32_t i_obj = obj_var >= 0 ? lay.perm[(size_t)obj_var] : -1;
 
   int4* d_props = nullptr; int2* d_root = nullptr; int *d_vo = nullptr, *d_vl = nullptr, *d_off = nullptr, *d_sv = nullptr;
   if ((rc = s->bufs.alloc(&d_props, (size_t)n_props)) != TB_OK) return rc;
-  if ((rc = s->bufs.alloc(&d_root, V)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&d_root, VX)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_vo, (size_t)n_strats)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_vl, (size_t)n_strats)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_off, (size_t)n_strats + 1)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_sv, (size_t)total_svars)) != TB_OK) return rc;
   {
+    const InternalNet net = to_internal(lay, root_store, n_props, props);
     std::vector<char> is_const;
     std::vector<int> value;
-    find_constants(n_vars, 1, root_store, &is_const, &value);  // constants = singleton variables of the root store
-    const Adjacency adj = build_adjacency(n_vars, n_props, props, is_const);
-    const std::vector<int4> packed = pack_props(n_props, props, is_const, value, adj);
+    find_constants(n_vars, 1, net.store.data(), &is_const, &value);  // constants = singleton variables of the root store
+    const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const);
+    const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), (size_t)n_props * sizeof(int4), hipMemcpyHostToDevice));
     int4* d_head = nullptr; int* d_adj = nullptr;
     if ((rc = s->bufs.alloc(&d_head, adj.heads.size())) != TB_OK) return rc;
@@ -507,27 +625,28 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     s->P.adj_head = d_head; s->P.adj = d_adj;
   }
   s->P.n_slices = s->plan.n_slices; s->P.dirty_words = s->plan.dirty_words; s->P.vext = s->plan.vext; s->P.chg_cap = s->plan.chg_cap;
-  if (n_vars) HIP_TRY(hipMemcpy(d_root, root_store, V * sizeof(tb_itv), hipMemcpyHostToDevice));
+  s->P.n_int = s->plan.n_int; s->P.unent_off = s->plan.unent_off;
+  {
+    std::vector<unsigned char> slab(std::max<size_t>(16, VX * 8), 0);
+    if (n_vars) encode_slab(lay, root_store, slab.data());
+    HIP_TRY(hipMemcpy(d_root, slab.data(), VX * 8, hipMemcpyHostToDevice));
+  }
   if (n_strats) {
     HIP_TRY(hipMemcpy(d_vo, strat_var_order, (size_t)n_strats * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_vl, strat_val_order, (size_t)n_strats * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_off, strat_off, ((size_t)n_strats + 1) * 4, hipMemcpyHostToDevice));
-  } else {
-    int zero = 0;
-    HIP_TRY(hipMemcpy(d_off, &zero, 4, hipMemcpyHostToDevice));
   }
-  if (total_svars) HIP_TRY(hipMemcpy(d_sv, strat_vars, (size_t)total_svars * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_off, i_off.data(), ((size_t)n_strats + 1) * 4, hipMemcpyHostToDevice));
+  if (total_svars) HIP_TRY(hipMemcpy(d_sv, i_vars.data(), (size_t)total_svars * 4, hipMemcpyHostToDevice));
 
-  const size_t VX = (size_t)plan.vext;
   if (plan.mem_kind == TB_MEM_GLOBAL) { if ((rc = s->bufs.alloc(&P.g_store, B * VX)) != TB_OK) return rc; }
   if ((rc = s->bufs.alloc(&P.g_snap, B * (size_t)plan.snapshot_levels * VX)) != TB_OK) return rc;
-  if ((rc = s->bufs.alloc(&P.g_best, B * V)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&P.g_best, B * VX)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&P.g_dec, B * (size_t)plan.max_depth)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&P.g_stats, B)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&P.ctrl, 1)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&s->d_now, 1)) != TB_OK) return rc;
 
-  P.n_vars = n_vars; P.n_props = n_props; P.n_strats = n_strats; P.obj_var = obj_var;
+  P.n_vars = n_vars; P.n_props = n_props; P.n_strats = n_strats; P.obj_var = i_obj;
   P.props = d_props; P.root_store = d_root;
   P.strat_var_order = d_vo; P.strat_val_order = d_vl; P.strat_off = d_off; P.strat_vars = d_sv;
   P.fixpoint = s->cfg.fixpoint;
@@ -551,7 +670,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->mbox_dev), s->mbox_host, 0));
   if (s->cfg.stream_solutions && !s->cfg.use_fixed_bound) {
     s->ring_slots = 8;
-    const size_t bytes = 64 + align16((size_t)s->ring_slots * 8) + (size_t)s->ring_slots * std::max<size_t>(1, V) * sizeof(tb_itv);
+    const size_t bytes = 64 + align16((size_t)s->ring_slots * 8) + (size_t)s->ring_slots * std::max<size_t>(2, VX) * sizeof(tb_itv);
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->ring_host), bytes, hipHostMallocMapped));
     std::memset(s->ring_host, 0, bytes);
     unsigned char* dev = nullptr;
@@ -600,7 +719,7 @@ int tb_session_start(tb_session* s) {
   s->t_start = std::chrono::steady_clock::now();
   HIP_TRY(hipEventRecord(s->ev_start, s->stream));
   const LaunchPlan& plan = s->plan;
-  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, s->cfg.fixpoint == 2, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->mbox_dev));
+  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, s->cfg.fixpoint == 2, plan.compact != 0, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->mbox_dev));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev_stop, s->stream));
   s->started = true;
@@ -642,9 +761,10 @@ int tb_session_next_solution(tb_session* s, tb_itv* store_out, int32_t* objectiv
   const int slot = (int)(s->ring_next % (unsigned long long)s->ring_slots);
   const unsigned long long seq = __atomic_load_n(&s->ring_seq()[slot], __ATOMIC_ACQUIRE);
   if (seq != s->ring_next + 1) return TB_OK;
-  const tb_itv* src = s->ring_data() + (size_t)slot * (size_t)s->n_vars;
-  if (store_out && s->n_vars) std::memcpy(store_out, src, (size_t)s->n_vars * sizeof(tb_itv));
-  if (objective_out) *objective_out = s->obj_var >= 0 ? src[s->obj_var].lb : 0;
+  std::vector<tb_itv> sol((size_t)std::max(1, s->n_vars));
+  decode_slab(s->lay, s->ring_data() + (size_t)slot * (size_t)s->plan.vext * 8, sol.data());
+  if (store_out && s->n_vars) std::memcpy(store_out, sol.data(), (size_t)s->n_vars * sizeof(tb_itv));
+  if (objective_out) *objective_out = s->obj_var >= 0 ? sol[(size_t)s->obj_var].lb : 0;
   s->ring_next += 1;
   __atomic_store_n(s->ring_consumed(), s->ring_next, __ATOMIC_RELEASE);  // frees the slot for ticket ring_next + slots - 1
   *has_out = 1;
@@ -704,7 +824,12 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
     st.best_bound = s->obj_var >= 0 ? w.best_bound : 0;
     st.best_subproblem = (int32_t)std::min<long long>(w.best_sub, 0x7fffffffll);
     st.timers_ns[TB_T_LATEST_BEST_OBJ_FOUND] = (int64_t)((double)w.best_time * ns_per_tick);
-    if (best_store_out && V) HIP_TRY(hipMemcpy(best_store_out, s->P.g_best + (size_t)best_block * V, V * sizeof(tb_itv), hipMemcpyDeviceToHost));
+    if (best_store_out && V) {
+      const size_t VX = (size_t)s->plan.vext;
+      std::vector<unsigned char> slab(VX * 8);
+      HIP_TRY(hipMemcpy(slab.data(), s->P.g_best + (size_t)best_block * VX, VX * 8, hipMemcpyDeviceToHost));
+      decode_slab(s->lay, slab.data(), best_store_out);
+    }
   }
   if (has_solution_out) *has_solution_out = best_block >= 0 ? 1 : 0;
   st.eps_num_subproblems = 1ull << s->plan.subproblems_power;

@@ -54,15 +54,44 @@ struct alignas(16) BlockShared {
 __device__ __forceinline__ int ld(const int* p) { return __hip_atomic_load(p, TB_RLX, TB_WG); }
 __device__ __forceinline__ void st(int* p, int v) { __hip_atomic_store(p, v, TB_RLX, TB_WG); }
 
-__device__ __forceinline__ Itv load_dom(const int2* store, int v) {
-  long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + v), TB_RLX, TB_WG);
+// Store slab of a workgroup: [ni x int2 {lb,ub}] [Boolean words: 16 variables x 2 bits] [one byte per slice].
+// Variables >= ni are the Boolean ones of the COMPACT layout (root domain within 0..1): bit 2k of their word says
+// "lb raised to 1", bit 2k+1 "ub lowered to 0" -- narrowing is a `ds_or` (monotone like max/min), 3 = empty.
+// Without COMPACT ni = n_vars and there are no Boolean words.
+template <bool C>
+__device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v) {
   Itv d;
+  if (C && v >= ni) {
+    const int b = v - ni;
+    const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store + ni) + (b >> 4), TB_RLX, TB_WG);
+    const unsigned bits = (w >> ((b & 15) * 2)) & 3u;
+    d.lb = (int)(bits & 1u);
+    d.ub = 1 - (int)(bits >> 1);
+    return d;
+  }
+  long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + v), TB_RLX, TB_WG);
   d.lb = (int)(raw & 0xffffffffll);
   d.ub = (int)(raw >> 32);
   return d;
 }
-__device__ __forceinline__ void raise_lb(int2* store, int v, int val) { (void)__hip_atomic_fetch_max(&store[v].x, val, TB_RLX, TB_WG); }
-__device__ __forceinline__ void lower_ub(int2* store, int v, int val) { (void)__hip_atomic_fetch_min(&store[v].y, val, TB_RLX, TB_WG); }
+template <bool C>
+__device__ __forceinline__ void raise_lb(int2* store, int ni, int v, int val) {
+  if (C && v >= ni) {
+    const int b = v - ni;
+    if (val >= 1) (void)__hip_atomic_fetch_or(reinterpret_cast<unsigned*>(store + ni) + (b >> 4), 1u << ((b & 15) * 2), TB_RLX, TB_WG);
+    return;
+  }
+  (void)__hip_atomic_fetch_max(&store[v].x, val, TB_RLX, TB_WG);
+}
+template <bool C>
+__device__ __forceinline__ void lower_ub(int2* store, int ni, int v, int val) {
+  if (C && v >= ni) {
+    const int b = v - ni;
+    if (val <= 0) (void)__hip_atomic_fetch_or(reinterpret_cast<unsigned*>(store + ni) + (b >> 4), 2u << ((b & 15) * 2), TB_RLX, TB_WG);
+    return;
+  }
+  (void)__hip_atomic_fetch_min(&store[v].y, val, TB_RLX, TB_WG);
+}
 
 // Per-thread counters kept in registers for the whole kernel and reduced once at the end.
 struct ThreadCounters {
@@ -90,13 +119,13 @@ __device__ __forceinline__ void append_change(const ChangeList& cl, int v) {
   if (pos < cl.cap) cl.list[pos] = v;  // an overflowing list degrades to "run every slice"
 }
 
-template <bool EVENT>
-__device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store, int* bot, bool& changed, bool& un, ThreadCounters& tc, const int dbg = 0,
+template <bool EVENT, bool C>
+__device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store, const int ni, int* bot, bool& changed, bool& un, ThreadCounters& tc, const int dbg = 0,
                                       int* narrowed = nullptr) {
   const int w0 = pr.x;
   // three gathers issued back to back, one s_waitcnt (the LDS is ~1 % busy: gathers are cheap, VALU is not)
   Itv X{0, 1}, Y{0, 1}, Z{0, 1};
-  if (!(dbg & 2)) { X = load_dom(store, pr.y); Y = load_dom(store, pr.z); Z = load_dom(store, pr.w); }
+  if (!(dbg & 2)) { X = load_dom<C>(store, ni, pr.y); Y = load_dom<C>(store, ni, pr.z); Z = load_dom<C>(store, ni, pr.w); }
   Cand c;
   if (!(dbg & 1)) c = evaluate_packed(w0, X, Y, Z); else c.ent = (pr.y != 0x7fffffff);
   if (dbg & 4) { un |= act & !c.ent; return; }
@@ -111,12 +140,12 @@ __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store
       if (empty_in | (nxl > nxu) | (nyl > nyu) | (nzl > nzu)) st(bot, 1);
       if (!empty_in) {
         int k = 0;
-        if (nxl != X.lb) { raise_lb(store, pr.y, nxl); ++k; }
-        if (nxu != X.ub) { lower_ub(store, pr.y, nxu); ++k; }
-        if (nyl != Y.lb) { raise_lb(store, pr.z, nyl); ++k; }
-        if (nyu != Y.ub) { lower_ub(store, pr.z, nyu); ++k; }
-        if (nzl != Z.lb) { raise_lb(store, pr.w, nzl); ++k; }
-        if (nzu != Z.ub) { lower_ub(store, pr.w, nzu); ++k; }
+        if (nxl != X.lb) { raise_lb<C>(store, ni, pr.y, nxl); ++k; }
+        if (nxu != X.ub) { lower_ub<C>(store, ni, pr.y, nxu); ++k; }
+        if (nyl != Y.lb) { raise_lb<C>(store, ni, pr.z, nyl); ++k; }
+        if (nyu != Y.ub) { lower_ub<C>(store, ni, pr.z, nyu); ++k; }
+        if (nzl != Z.lb) { raise_lb<C>(store, ni, pr.w, nzl); ++k; }
+        if (nzu != Z.ub) { lower_ub<C>(store, ni, pr.w, nzu); ++k; }
         tc.writes += (unsigned)k;
         changed |= (k != 0);
         if (EVENT) *narrowed = (int)((nxl != X.lb) | (nxu != X.ub)) | ((int)((nyl != Y.lb) | (nyu != Y.ub)) << 1) | ((int)((nzl != Z.lb) | (nzu != Z.ub)) << 2);
@@ -155,7 +184,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         const int4 pr = pr_next;
         pr_next = idle_record();
         if (i + T < n) pr_next = (dbg & 8) ? make_int4(K_EQ_R | (1 << (16 + K_EQ_R)), (i + T) % P.n_vars, (i * 7) % P.n_vars, (i * 13) % P.n_vars) : props[i + T];
-        apply<false>(pr, act, store, &sh.bot, changed, un, tc, dbg);
+        apply<false, false>(pr, act, store, P.n_int, &sh.bot, changed, un, tc, dbg);
       }
     } else {
       // WAC1: a wave iterates its 64 propagators to a local fixpoint before moving on (config.cpp:26,
@@ -168,7 +197,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         if (i + T < n) pr_next = (dbg & 8) ? make_int4(K_EQ_R | (1 << (16 + K_EQ_R)), (i + T) % P.n_vars, (i * 7) % P.n_vars, (i * 13) % P.n_vars) : props[i + T];
         for (;;) {
           bool ch = false, un_i = false;
-          apply<false>(pr, act, store, &sh.bot, ch, un_i, tc, dbg);
+          apply<false, false>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
           if (lane == 0) tc.deductions += 64;  // barebones:958-960 counts warp iterations x warp width
           if (!__any(ch)) { un |= un_i; break; }
           changed = true;
@@ -274,6 +303,7 @@ __device__ __forceinline__ int claim_slice(const EventState& es, int rot) {
 // "sweeps" -- a propagation chain advances at the latency of one slice run, not of one workgroup barrier.
 // A wave leaves when the bitmap is empty and no wave is running a slice (`busy`): a wave that marks slices
 // re-scans the bitmap itself, so no work is lost when others have already left.
+template <bool C>
 __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
                                               const EventState& es, ThreadCounters& tc, bool& all_entailed) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
@@ -337,7 +367,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     for (;;) {
       bool ch = false, un_i = false;
       int nar = 0;
-      apply<true>(pr, act, store, &sh.bot, ch, un_i, tc, 0, &nar);
+      apply<true, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, 0, &nar);
       if (lane == 0) tc.deductions += 64;
       if (!__any(ch)) {
         // The byte only ever goes 1 -> 0 below a node (entailment is monotone): two waves may run the same slice
@@ -418,18 +448,19 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 }
 
 // Thread 0 only: VStore::embed of one interval (decisions, objective bound).
-__device__ __forceinline__ bool embed0(int2* store, int* bot, int v, int lb, int ub) {
-  Itv d = load_dom(store, v);
+template <bool C>
+__device__ __forceinline__ bool embed0(int2* store, int ni, int* bot, int v, int lb, int ub) {
+  Itv d = load_dom<C>(store, ni, v);
   bool changed = false;
-  if (lb > d.lb) { raise_lb(store, v, lb); d.lb = lb; changed = true; }
-  if (ub < d.ub) { lower_ub(store, v, ub); d.ub = ub; changed = true; }
+  if (lb > d.lb) { raise_lb<C>(store, ni, v, lb); d.lb = lb; changed = true; }
+  if (ub < d.ub) { lower_ub<C>(store, ni, v, ub); d.ub = ub; changed = true; }
   if (d.lb > d.ub) st(bot, 1);
   return changed;
 }
 // embed0 + event bookkeeping: the slices reading v must run in the first sweep of the next fixpoint
-template <bool EVENT>
+template <bool EVENT, bool C>
 __device__ __forceinline__ void embed0_mark(const DevProblem& P, BlockShared& sh, const EventState& es, int2* store, int* bot, int v, int lb, int ub) {
-  const bool changed = embed0(store, bot, v, lb, ub);
+  const bool changed = embed0<C>(store, P.n_int, bot, v, lb, ub);
   if (EVENT && changed) note_change(sh, es, v);
 }
 
@@ -446,11 +477,12 @@ __device__ __forceinline__ unsigned order_key(int var_order, const Itv d) {
 }
 
 // Thread 0 only (barebones:355-405).
+template <bool C>
 __device__ __forceinline__ bool push_decision(const DevProblem& P, BlockShared& sh, Decision* dec, const int2* store, int val_order, int var) {
   const int depth = sh.depth;
   if (depth + 1 >= P.max_depth) { __hip_atomic_store(&P.ctrl->error, 1, TB_RLX, TB_AGENT); return false; }
   Decision d;
-  const Itv dom = load_dom(store, var);
+  const Itv dom = load_dom<C>(store, P.n_int, var);
   d.var = var;
   d.cur = -1;
   const int mid = (int)((long long)dom.lb + ((long long)dom.ub - (long long)dom.lb) / 2);
@@ -471,6 +503,7 @@ __device__ __forceinline__ bool push_decision(const DevProblem& P, BlockShared& 
 // input_order_split / lattice_smallest_split (barebones:240-349) by one strided scan, a wave-level
 // min reduction (DPP/bpermute shuffles) and one LDS round per strategy.
 // Ends with a barrier; sh.found tells whether a decision was pushed at sh.depth-1.
+template <bool C>
 __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Decision* dec, const int2* store) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
   for (;;) {
@@ -496,7 +529,7 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         d[k] = Itv{0, 0};
-        if (v[k] >= 0) d[k] = load_dom(store, v[k]);
+        if (v[k] >= 0) d[k] = load_dom<C>(store, P.n_int, v[k]);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -521,7 +554,7 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
       if (best != ~0ull) {
         const int i = (int)(best & 0xffffffffu);
         const int v = in_store ? i : P.strat_vars[off + i];
-        sh.found = push_decision(P, sh, dec, store, P.strat_val_order[s], v) ? 1 : 0;
+        sh.found = push_decision<C>(P, sh, dec, store, P.strat_val_order[s], v) ? 1 : 0;
         if (!sh.found) sh.stop = 1;
         sh.skip = 1;  // leave the strategy loop
       } else {
@@ -553,7 +586,7 @@ __device__ __forceinline__ void produce_solution(const DevProblem& P, BlockShare
   __syncthreads();
   if (sh.ticket >= 0) {
     const int slot = (int)(ticket % (unsigned long long)r.slots);
-    copy_store(r.data + (size_t)slot * P.n_vars, store, P.n_vars);
+    copy_store(r.data + (size_t)slot * P.vext, store, P.vext);
     __threadfence_system();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&r.seq[slot], ticket + 1ull, __ATOMIC_RELEASE, TB_SYS);
@@ -565,7 +598,7 @@ __device__ __forceinline__ void produce_solution(const DevProblem& P, BlockShare
 
 struct NodeTimers { long long t_last; };
 
-template <bool EVENT>
+template <bool EVENT, bool C>
 __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
                                                int2* best_store, Mailbox* mbox, ThreadCounters& tc,
                                                long long& t_mark, long long t_start) {
@@ -575,7 +608,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
   if (tid == 0) { t0 = wall_clock64(); bs.timers[TB_T_SEARCH] += t0 - t_mark; }
   bool all_entailed = false;
   int iters;
-  if constexpr (EVENT) iters = fixpoint_event(P, sh, store, props, es, tc, all_entailed);
+  if constexpr (EVENT) iters = fixpoint_event<C>(P, sh, store, props, es, tc, all_entailed);
   else iters = fixpoint(P, sh, store, props, tc, all_entailed);
   const bool aborted = ld(&sh.abort) != 0;
   const bool failed = !aborted && ld(&sh.bot) != 0;
@@ -589,7 +622,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
     if (!failed && all_entailed) {
       leaf = 1;
       if (P.obj_var >= 0) {
-        const int obj = load_dom(store, P.obj_var).lb;
+        const int obj = load_dom<C>(store, P.n_int, P.obj_var).lb;
         if (sh.best_bound > obj && (!P.use_fixed_bound || obj <= P.fixed_bound)) {  // barebones:994
           sh.best_bound = obj;
           sol = 1;
@@ -647,7 +680,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
   }
   __syncthreads();
   if (sh.sol) {  // uniform
-    copy_store(best_store, store, P.n_vars);
+    copy_store(best_store, store, P.vext);
     __syncthreads();
     if (sh.ticket >= 0) produce_solution(P, sh, store, mbox);
   }
@@ -659,7 +692,7 @@ constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 255) / 256 * 256);
 
 // The event-driven variant is latency bound: its 256-thread form asks the register allocator for 6 waves per
 // SIMD (<= 80 VGPRs) so that 6 workgroups are resident per CU; the sweep variants are VALU bound and keep 4.
-template <int MEM, int TMAX, bool EVENT>
+template <int MEM, int TMAX, bool EVENT, bool C>
 #ifndef TB_EVENT_WAVES
 #define TB_EVENT_WAVES 6
 #endif
@@ -675,7 +708,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   EventState es;
   es.dirty = reinterpret_cast<unsigned*>(smem + SH_BYTES + store_bytes);
   es.list = reinterpret_cast<int*>(smem + SH_BYTES + store_bytes + (((size_t)P.dirty_words * 4 + 15) / 16) * 16);
-  es.unent = reinterpret_cast<unsigned char*>(store + V);
+  es.unent = reinterpret_cast<unsigned char*>(store) + P.unent_off;
   es.words = P.dirty_words; es.cap = P.chg_cap;
   const int4* props = P.props;
   if (MEM == TB_MEM_TCN_SHARED) {
@@ -685,7 +718,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   }
   for (int i = tid; i < P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
   int2* snap = P.g_snap + (size_t)b * P.snapshot_levels * VX;
-  int2* best_store = P.g_best + (size_t)b * V;
+  int2* best_store = P.g_best + (size_t)b * VX;
   Decision* dec = P.g_dec + (size_t)b * P.max_depth;
   BlockStats& bs = sh.bs;
   ThreadCounters tc;
@@ -706,7 +739,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   // B. dive-and-solve loop (barebones:656-886)
   while (sh.sub_idx < P.sub_hi && !sh.stop) {
     // C. restore the root
-    copy_store(store, P.root_store, V);
+    copy_store(store, P.root_store, VX);  // the root slab is laid out like a workgroup slab
     if (EVENT && tid == 0) sh.ev_all = 1;  // the root store is not a fixpoint: every slice runs once
     long long t_dive = 0;
     if (tid == 0) {
@@ -718,16 +751,16 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     __syncthreads();
     // D. dive: no objective bound while diving (gpu_dive_and_solve.hpp:370-372)
     while (sh.remaining > 0 && !sh.leaf && !sh.stop) {
-      propagate_node<EVENT>(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
+      propagate_node<EVENT, C>(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
       if (!sh.leaf && !sh.stop) {
-        split(P, sh, dec, store);
+        split<C>(P, sh, dec, store);
         if (tid == 0) {
           if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; bs.why |= 1; }  // unsplittable infinite domains (barebones:688-694)
           else {
             --sh.remaining;
             --sh.depth;  // decisions are not recorded while diving
             const int bit = (int)((sh.sub_idx >> sh.remaining) & 1ull);
-            embed0_mark<EVENT>(P, sh, es, store, &sh.bot, dec[0].var, dec[0].child[bit].x, dec[0].child[bit].y);
+            embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dec[0].var, dec[0].child[bit].x, dec[0].child[bit].y);
           }
         }
       }
@@ -749,7 +782,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
       while (!sh.stop) {
         // I. tighten the objective with the incumbent (barebones:756-771)
         if (tid == 0 && P.obj_var >= 0) {
-          if (P.use_fixed_bound) embed0_mark<EVENT>(P, sh, es, store, &sh.bot, P.obj_var, NINF, P.fixed_bound);
+          if (P.use_fixed_bound) embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, P.obj_var, NINF, P.fixed_bound);
           else {
             int g = __hip_atomic_load(&P.ctrl->best_bound, TB_RLX, TB_AGENT);
             const int f = __hip_atomic_load(&P.ctrl->foreign_bound, TB_RLX, TB_AGENT);
@@ -757,14 +790,14 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
             g = sh.best_bound < g ? sh.best_bound : g;
             if (g != PINF) {
               if (g == NINF) { sh.stop = 1; __hip_atomic_store(&P.ctrl->gpu_stop, 1, TB_RLX, TB_AGENT); }  // unbounded objective
-              else embed0_mark<EVENT>(P, sh, es, store, &sh.bot, P.obj_var, NINF, g - 1);
+              else embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, P.obj_var, NINF, g - 1);
             }
           }
         }
         __syncthreads();
         if (sh.stop) break;
         // II. propagate
-        propagate_node<EVENT>(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
+        propagate_node<EVENT, C>(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
         if (sh.stop) break;
         // III. branch
         if (!sh.leaf) {
@@ -776,7 +809,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
           if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
           __syncthreads();
           if (prof && tid == 0) { const long long t = wall_clock64(); bs.timers[TB_T_PREPROCESSING] += t - tp; tp = t; }  // profiling: snapshot push
-          split(P, sh, dec, store);
+          split<C>(P, sh, dec, store);
           if (prof && tid == 0) bs.timers[TB_T_SELECT_FP_FUNCTIONS] += wall_clock64() - tp;  // profiling: variable selection
           if (sh.stop) break;
           if (tid == 0) {
@@ -784,7 +817,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
             else {
               Decision& dd = dec[sh.depth - 1];
               const int c = ++dd.cur;
-              embed0_mark<EVENT>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+              embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
             }
           }
           __syncthreads();
@@ -806,15 +839,15 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
           for (int i = lvl + tid; i < depth - 1; i += blockDim.x) {
             const Decision& di = dec[i];
             const int2 ch = di.child[di.cur];
-            raise_lb(store, di.var, ch.x);
-            lower_ub(store, di.var, ch.y);
+            raise_lb<C>(store, P.n_int, di.var, ch.x);
+            lower_ub<C>(store, P.n_int, di.var, ch.y);
             if (EVENT) note_change(sh, es, di.var);
           }
           __syncthreads();
           if (tid == 0) {
             Decision& dd = dec[depth - 1];
             const int c = ++dd.cur;
-            embed0_mark<EVENT>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+            embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
             sh.cur_strategy = sh.snap_strategy;
             sh.next_unassigned = sh.snap_next_unassigned;
           }
@@ -865,7 +898,8 @@ struct PropagateOut {
   unsigned long long iterations, deductions, writes;
 };
 
-template <int MEM, int TMAX, bool EVENT>
+// `stores` holds n_stores slabs of P.vext intervals each (the layout of a workgroup slab, encoded by the host).
+template <int MEM, int TMAX, bool EVENT, bool C>
 __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* stores, PropagateOut* out, int n_stores) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
@@ -885,24 +919,24 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
     props = lprops;
   }
   for (int s = blockIdx.x; s < n_stores; s += gridDim.x) {
-    int2* gstore = stores + (size_t)s * V;
-    // GLOBAL mode works in place on the caller's store; its entailment bytes go to a per-workgroup scratch slab
+    int2* gstore = stores + (size_t)s * VX;
+    // GLOBAL mode works in place on the caller's slab
     int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : gstore;
-    es.unent = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<unsigned char*>(store + V) : reinterpret_cast<unsigned char*>(P.g_store + (size_t)blockIdx.x * VX + V);
+    es.unent = reinterpret_cast<unsigned char*>(store) + P.unent_off;
     ThreadCounters tc;
     if (tid == 0) { sh.bot = 0; sh.abort = 0; sh.red_key[0] = 0; sh.red_key[1] = 0; }
     __syncthreads();
-    if (MEM >= TB_MEM_STORE_SHARED) copy_store(store, gstore, V);
-    for (int i = tid; i < V; i += blockDim.x) { const int2 d = gstore[i]; if (d.x > d.y) st(&sh.bot, 1); }
+    if (MEM >= TB_MEM_STORE_SHARED) { copy_store(store, gstore, VX); __syncthreads(); }
+    for (int i = tid; i < V; i += blockDim.x) { const Itv d = load_dom<C>(store, P.n_int, i); if (d.lb > d.ub) st(&sh.bot, 1); }
     __syncthreads();
     bool all_entailed = false;
     int iters = 0;
     if (EVENT) { if (tid == 0) { sh.ev_all = 1; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; } __syncthreads(); }
     if (!ld(&sh.bot)) {
-      if constexpr (EVENT) iters = fixpoint_event(P, sh, store, props, es, tc, all_entailed);
+      if constexpr (EVENT) iters = fixpoint_event<C>(P, sh, store, props, es, tc, all_entailed);
       else iters = fixpoint(P, sh, store, props, tc, all_entailed);
     }
-    if (MEM >= TB_MEM_STORE_SHARED) copy_store(gstore, store, V);
+    if (MEM >= TB_MEM_STORE_SHARED) copy_store(gstore, store, VX);
     unsigned long long w = tc.writes, d = tc.deductions;
     for (int off = 32; off > 0; off >>= 1) { w += __shfl_xor(w, off, 64); d += __shfl_xor(d, off, 64); }
     if ((tid & 63) == 0) {
