@@ -362,13 +362,12 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       if (lane == 0) (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG);
       continue;
     }
-    int4 hx = make_int4(0, 0, 0, 0), hy = hx, hz = hx;  // adjacency heads of my three operands, loaded on first use
-    int have = 0;
+    int wave_iters = 0;  // wave-uniform
     for (;;) {
       bool ch = false, un_i = false;
       int nar = 0;
       apply<true, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, 0, &nar);
-      if (lane == 0) tc.deductions += 64;
+      ++wave_iters;
       if (!__any(ch)) {
         // The byte only ever goes 1 -> 0 below a node (entailment is monotone): two waves may run the same slice
         // at once, and the one that read the older domains must not overwrite the verdict of the other.
@@ -377,10 +376,13 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       }
       // successors: every other slice reading a variable I narrowed (operands private to this slice are
       // flagged at pack time in word0 and skipped)
+      // (the adjacency heads are not kept across iterations: they would be live through the evaluation, and the
+      //  kernel is register bound)
       nar &= ~(pr.x >> 8) & 7;
-      if ((nar & 1) && !(have & 1)) { hx = P.adj_head[pr.y]; have |= 1; }
-      if ((nar & 2) && !(have & 2)) { hy = P.adj_head[pr.z]; have |= 2; }
-      if ((nar & 4) && !(have & 4)) { hz = P.adj_head[pr.w]; have |= 4; }
+      int4 hx = make_int4(0, 0, 0, 0), hy = hx, hz = hx;
+      if (nar & 1) hx = P.adj_head[pr.y];
+      if (nar & 2) hy = P.adj_head[pr.z];
+      if (nar & 4) hz = P.adj_head[pr.w];
       // my narrowings are performed (global-memory atomics included) before any slice I mark can be claimed
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       const bool lx = (nar & 1) && mark_head(es.dirty, hx, s);
@@ -393,7 +395,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       if (ld(&sh.bot)) break;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my marks are visible before I stop being busy
-    if (lane == 0) (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG);
+    if (lane == 0) { (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG); tc.deductions += 64ull * (unsigned)wave_iters; }
   }
   if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += t - tp0; tp0 = t; }  // profiling: own work
   __syncthreads();
