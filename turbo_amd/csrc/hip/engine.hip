@@ -159,9 +159,8 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   const int n_slices = (n_props + 63) / 64, dirty_words = (n_slices + 31) / 32, vext = lay.vext(n_slices);
   p.n_slices = n_slices; p.dirty_words = dirty_words; p.vext = vext;
   p.compact = lay.compact ? 1 : 0; p.n_int = lay.n_int; p.unent_off = lay.unent_off();
-  // store slab = domains + one entailment byte per 64-propagator slice; the three dirty bitmaps of the
-  // event-driven fixpoint always live in LDS
-  // one dirty bitmap + two change lists of (variable, slice) pairs; an overflowing list falls back to a full sweep
+  // store slab = domains + one entailment byte per 64-propagator slice; the dirty bitmap and the change list of the
+  // event-driven fixpoint always live in LDS (an overflowing change list falls back to running every slice)
   p.chg_cap = std::min(1024, std::max(64, n_vars / 4));
   if (cfg.reserved[1] > 0) p.chg_cap = cfg.reserved[1];  // tuning knob
   const size_t dirty_b = align16((size_t)dirty_words * 4) + align16((size_t)p.chg_cap * 4);
@@ -177,7 +176,8 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b);
   } else if (fixed + store_b <= lds && !(event && (int)(lds / (fixed + store_b)) < 4 && !(cfg.reserved[0] & 0x40000))) {
     // (event mode: a store that leaves fewer than 4 workgroups per CU goes to global memory instead --
-    //  measured 1.2-1.5x more nodes/s on wordpress7_500 / trains15 with 8 x 256-thread workgroups per CU)
+    //  measured 1.2-1.5x more nodes/s on wordpress7_500 / trains15 with 6 x 256-thread workgroups per CU;
+    //  choose_layout then tries the COMPACT layout, which usually brings the store back into LDS)
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / (fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
   } else {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);

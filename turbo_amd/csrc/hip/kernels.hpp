@@ -1,10 +1,11 @@
 // HIP kernels of the dive-and-solve engine for gfx950 (MI355X, CDNA4).
 //
 // One EPS subproblem per workgroup at a time; the variable-domain store of the subproblem lives in
-// LDS (int2 {lb,ub} per variable, ds_read_b64 / ds_max_i32 / ds_min_i32), the propagator bytecodes
-// are 16-byte records read one per lane (coalesced global_load_dwordx4, or ds_read_b128 when they fit
-// in LDS too), the "has changed" flag of the fixpoint is reduced per wave with a ballot and published
-// through one LDS word, and one s_barrier separates two sweeps.
+// LDS (int2 {lb,ub} per variable, ds_read_b64 / ds_max_i32 / ds_min_i32; Booleans as 2 bits in the COMPACT
+// layout of the event kernels), the propagator bytecodes are 16-byte records read one per lane (coalesced
+// global_load_dwordx4, or ds_read_b128 when they fit in LDS too).  Sweeping fixpoints (AC1 / WAC1): the "has
+// changed" flag is reduced per wave with a ballot and published through one LDS word, one s_barrier separates
+// two sweeps.  Event-driven fixpoint: an asynchronous worklist of dirty 64-propagator slices, no barrier.
 //
 // Mirrors, without their data structures:
 //   gpu_barebones_solve   include/barebones_dive_and_solve.hpp:620-901   (workgroup main loop)
@@ -227,10 +228,10 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
   return it;
 }
 
-// Event-driven WAC1 (tb_config.fixpoint = 2).  Same fixpoint, same wave-local iteration, but a sweep only
-// evaluates the 64-propagator slices that read a variable narrowed in the previous sweep (three rotating
-// dirty bitmaps in LDS, filled through the variable -> slices adjacency on every narrowing).  The first
-// sweep of a node starts from the slices of the decision variable, because backtracking restores the
+// Event-driven WAC1 (tb_config.fixpoint = 2): state shared by its functions.  Same fixpoint, same wave-local
+// iteration as `fixpoint`, but only the 64-propagator slices that read a narrowed variable are evaluated (one
+// dirty bitmap in LDS, filled through the variable -> slices adjacency on every narrowing; see fixpoint_event).
+// A node starts from the slices of the variables its caller changed, because backtracking restores the
 // parent's PROPAGATED store from the HBM snapshot stack.  Entailment is kept as one byte per slice, stored
 // right behind the store so that snapshots carry it: a slice that did not run has not changed status.
 // This is the role of FixpointSubsetGPU / entailed-propagator removal in the reference (gpu_dive_and_solve.hpp:334,
@@ -702,7 +703,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, b = blockIdx.x, V = P.n_vars;
-  // LDS: [control block][store: vext x int2 (STORE/TCN_SHARED)][dirty bitmaps: 3 x words][bytecodes (TCN_SHARED)]
+  // LDS: [control block][store slab: vext x 8 B (STORE/TCN_SHARED)][dirty bitmap][change list][bytecodes (TCN_SHARED)]
   const int VX = P.vext;
   const size_t store_bytes = MEM >= TB_MEM_STORE_SHARED ? (((size_t)VX * 8 + 15) / 16) * 16 : 0;
   const size_t dirty_bytes = (((size_t)P.dirty_words * 4 + 15) / 16) * 16 + (((size_t)P.chg_cap * 4 + 15) / 16) * 16;
