@@ -587,7 +587,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   const LaunchPlan& plan = s->plan;
   const Layout& lay = s->lay;
   DevProblem& P = s->P;
-  const size_t V = (size_t)n_vars, B = (size_t)plan.num_blocks;
+  const size_t B = (size_t)plan.num_blocks;
   const size_t VX = (size_t)plan.vext;
 
   // strategies in the internal numbering; with a renumbered store a whole-store strategy (empty list) becomes the

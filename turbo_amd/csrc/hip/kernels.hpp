@@ -396,7 +396,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       if (ld(&sh.bot)) break;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my marks are visible before I stop being busy
-    if (lane == 0) { (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG); tc.deductions += 64ull * (unsigned)wave_iters; }
+    if (lane == 0) { (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG); tc.deductions += 64ull * (unsigned)((P.debug & 0x400000) ? 1 : wave_iters); }  // 0x400000: count slice runs (profiling)
   }
   if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += t - tp0; tp0 = t; }  // profiling: own work
   __syncthreads();
@@ -702,7 +702,7 @@ template <int MEM, int TMAX, bool EVENT, bool C>
 __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES : 4) solve_kernel(DevProblem P, Mailbox* mbox) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
-  const int tid = threadIdx.x, b = blockIdx.x, V = P.n_vars;
+  const int tid = threadIdx.x, b = blockIdx.x;
   // LDS: [control block][store slab: vext x 8 B (STORE/TCN_SHARED)][dirty bitmap][change list][bytecodes (TCN_SHARED)]
   const int VX = P.vext;
   const size_t store_bytes = MEM >= TB_MEM_STORE_SHARED ? (((size_t)VX * 8 + 15) / 16) * 16 : 0;
