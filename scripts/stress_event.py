@@ -12,11 +12,11 @@ for rel in sys.argv[1:] or ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "
     exp = [pyoracle.propagate(nodes[i], tcn.props) for i in range(nodes.shape[0])]
     reps = 256
     stores = np.tile(nodes, (reps, 1))
-    for fp in (2, 1):
-        got, failed, ent, iters, ded, _ = capi.propagate(tcn.props, stores, capi.make_config(fixpoint=fp))
+    for fp, dbg in ((2, 0), (2, 0x100000), (1, 0)):  # event, event with the compact store layout, wac1
+        got, failed, ent, iters, ded, _ = capi.propagate(tcn.props, stores, capi.make_config(fixpoint=fp, debug=dbg))
         bad = 0
         for j in range(stores.shape[0]):
             e = exp[j % nodes.shape[0]]
             if bool(failed[j]) != e[1]: bad += 1; continue
             if not e[1] and (bool(ent[j]) != e[2] or not np.array_equal(got[j], e[0])): bad += 1
-        print(rel, "fp", fp, "stores", stores.shape[0], "mismatches", bad, flush=True)
+        print(rel, "fp", fp, "debug", hex(dbg), "stores", stores.shape[0], "mismatches", bad, flush=True)

@@ -1,0 +1,46 @@
+"""Random small FlatZinc models over the constraint vocabulary of the front-end (shared by the fuzz tests)."""
+import random
+
+
+def random_model(seed: int) -> str:
+    rng = random.Random(seed)
+    n, nb = rng.randint(2, 5), rng.randint(0, 3)
+    lines = []
+    for i in range(n):
+        lo = rng.randint(-3, 2)
+        lines.append(f"var {lo}..{lo + rng.randint(0, 5)}: x{i} :: output_var;")
+    for i in range(nb):
+        lines.append(f"var bool: b{i} :: output_var;")
+    xs, bs = [f"x{i}" for i in range(n)], [f"b{i}" for i in range(nb)]
+
+    def term():
+        return rng.choice(xs) if rng.random() < 0.8 else str(rng.randint(-2, 3))
+
+    for _ in range(rng.randint(1, 6)):
+        k = rng.random()
+        if k < 0.25:
+            m = rng.randint(1, 3)
+            vs, cs = [rng.choice(xs) for _ in range(m)], [rng.choice([-2, -1, 1, 1, 2]) for _ in range(m)]
+            op = rng.choice(["int_lin_le", "int_lin_eq", "int_lin_ne"])
+            lines.append(f"constraint {op}([{','.join(map(str, cs))}],[{','.join(vs)}],{rng.randint(-3, 6)});")
+        elif k < 0.4:
+            lines.append(f"constraint {rng.choice(['int_eq', 'int_le', 'int_ne', 'int_lt'])}({term()},{term()});")
+        elif k < 0.55 and bs:
+            lines.append(f"constraint {rng.choice(['int_le_reif', 'int_eq_reif', 'int_ne_reif'])}({term()},{term()},{rng.choice(bs)});")
+        elif k < 0.65 and bs:
+            pos, neg = [rng.choice(bs) for _ in range(rng.randint(0, 2))], [rng.choice(bs) for _ in range(rng.randint(0, 2))]
+            if pos or neg:
+                lines.append(f"constraint bool_clause([{','.join(pos)}],[{','.join(neg)}]);")
+        elif k < 0.75:
+            lines.append(f"constraint {rng.choice(['int_plus', 'int_times', 'int_max', 'int_min', 'int_minus', 'int_div', 'int_mod'])}"
+                         f"({term()},{term()},{rng.choice(xs)});")
+        elif k < 0.85:
+            arr = [rng.randint(-2, 4) for _ in range(rng.randint(2, 4))]
+            lines.append(f"constraint array_int_element({rng.choice(xs)},[{','.join(map(str, arr))}],{rng.choice(xs)});")
+        elif k < 0.92 and bs:
+            lines.append(f"constraint bool2int({rng.choice(bs)},{rng.choice(xs)});")
+        else:
+            lines.append(f"constraint int_abs({rng.choice(xs)},{rng.choice(xs)});")
+    g = rng.random()
+    lines.append(f"solve minimize {rng.choice(xs)};" if g < 0.4 else f"solve maximize {rng.choice(xs)};" if g < 0.8 else "solve satisfy;")
+    return "\n".join(lines) + "\n"

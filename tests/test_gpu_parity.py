@@ -158,6 +158,24 @@ def test_parallel_canonical_solution_bit_exact(rel, expected, fixpoint, debug):
     assert st_g["best_subproblem"] == st_o["best_subproblem"]
 
 
+@pytest.mark.parametrize("chunk", range(4))
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT)], ids=["wac1", "event", "event_compact"])
+def test_random_models_tree_identical(chunk, fixpoint, debug):
+    """Fuzz: random small models over the whole constraint vocabulary (divisions, products, elements, clauses):
+    root fixpoint bit-exact, and one workgroup explores exactly the oracle's tree."""
+    from fuzz_models import random_model
+    for seed in range(1000 + chunk * 25, 1000 + chunk * 25 + 25):
+        tcn = frontend.Model.from_string(random_model(seed)).tcn()
+        check_batch(tcn, tcn.store[None, :], fixpoint=fixpoint, debug=debug)
+        has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=0)
+        has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=0, timeout_ms=60000, fixpoint=fixpoint, debug=debug))
+        assert has_g == has_o and st_g["exhaustive"] == st_o["exhaustive"], seed
+        for k in ("nodes", "fails", "solutions", "depth_max"):
+            assert st_g[k] == st_o[k], (seed, k)
+        if has_o:
+            np.testing.assert_array_equal(best_g, best_o, err_msg=str(seed))
+
+
 def test_unsat_and_errors():
     tcn = frontend.Model.from_string("var 1..3: x; var 1..3: y; constraint int_lt(x,y); constraint int_lt(y,x); solve satisfy;").tcn()
     has, _, st = capi.solve(tcn, capi.make_config(timeout_ms=20000))

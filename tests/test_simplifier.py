@@ -132,3 +132,38 @@ def test_gpu_and_oracle_preprocessing_agree(rel):
     np.testing.assert_array_equal(a.store, b.store)
     np.testing.assert_array_equal(a.props, b.props)
     np.testing.assert_array_equal(a.strat_vars[: int(a.strat_off[-1])], b.strat_vars[: int(b.strat_off[-1])])
+
+
+@pytest.mark.parametrize("chunk", range(8))
+def test_random_models_keep_status_optimum_and_valid_solutions(chunk):
+    """Fuzz: on random small models the simplified network has the same status and optimum as the network as first
+    lowered, and the lower corner of every expanded solution box satisfies the original propagators."""
+    from fuzz_models import random_model
+    for seed in range(chunk * 60, chunk * 60 + 60):
+        text = random_model(seed)
+        raw = frontend.Model.from_string(text).tcn()
+        has0, best0, st0 = pyoracle.solve(raw, timeout_ms=20000)
+        assert st0["exhaustive"] or (raw.goal == 0 and has0), seed  # a satisfaction search stops at its first solution
+        m = frontend.Model.from_string(text)
+        for _ in range(16):
+            t = m.tcn()
+            if t.trivially_unsat:
+                break
+            root, failed = oracle_propagate(t.store, t.props)
+            st = m.simplify(root)
+            if failed or not any(st[k] for k in ("merged_variables", "cse_merges", "entailed_props", "duplicate_props", "eliminated_variables")):
+                break
+        t = m.tcn()
+        has1, best1, st1 = pyoracle.solve(t, timeout_ms=20000)
+        assert has1 == has0, (seed, text)
+        if not has0:
+            continue
+        if raw.goal != 0:
+            assert t.objective_of(best1) == raw.objective_of(best0), (seed, text)
+        o_store, o_props = m.original_network()
+        full = m.expand_solution(best1)
+        assert np.all(full["lb"] >= o_store["lb"]) and np.all(full["ub"] <= o_store["ub"]), (seed, text)
+        corner = full.copy()
+        corner["ub"] = corner["lb"]
+        _, failed, entailed, _, _ = pyoracle.propagate(corner, o_props)
+        assert not failed and entailed, (seed, text)

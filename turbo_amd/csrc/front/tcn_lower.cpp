@@ -726,7 +726,11 @@ void TCN::flatten_strategies() {
 
 TCN lower_to_tcn(const Model& m) {
   Lowerer l(m);
-  return l.run();
+  TCN t = l.run();
+  // A constraint that is false on constants leaves no propagator behind; besides the flag, make the network itself
+  // unsatisfiable for callers that only look at the arrays: `0 = (0 = 0)` over the interned constant 0.
+  if (t.trivially_unsat && !t.store.empty()) t.props.push_back(tb_prop{TB_EQ, 0, 0, 0});
+  return t;
 }
 
 }  // namespace turbo_front
