@@ -1,6 +1,8 @@
 """Random small FlatZinc models over the constraint vocabulary of the front-end (shared by the fuzz tests)."""
 import random
 
+import numpy as np
+
 
 def random_model(seed: int) -> str:
     rng = random.Random(seed)
@@ -44,3 +46,37 @@ def random_model(seed: int) -> str:
     g = rng.random()
     lines.append(f"solve minimize {rng.choice(xs)};" if g < 0.4 else f"solve maximize {rng.choice(xs)};" if g < 0.8 else "solve satisfy;")
     return "\n".join(lines) + "\n"
+
+
+NINF, PINF = -2**31, 2**31 - 1
+
+
+def random_network(rng):
+    """Random ternary network (numpy store, props) over all operators with small, Boolean, wide, huge and unbounded domains."""
+    from turbo_amd.frontend import ITV_DTYPE, PROP_DTYPE
+    V = int(rng.integers(6, 25))
+    store = np.zeros(V, dtype=ITV_DTYPE)
+    store[0], store[1], store[2] = (0, 0), (1, 1), (2, 2)
+    for v in range(3, V):
+        kind = rng.random()
+        if kind < 0.35:      # small
+            lo = int(rng.integers(-6, 6)); hi = lo + int(rng.integers(0, 8))
+        elif kind < 0.55:    # Boolean
+            lo, hi = 0, 1
+        elif kind < 0.8:     # wide
+            lo = int(rng.integers(-10**6, 10**6)); hi = lo + int(rng.integers(0, 10**6))
+        elif kind < 0.9:     # huge (saturation)
+            lo = int(rng.integers(-2**30, 2**30)); hi = min(PINF - 1, lo + int(rng.integers(0, 2**30)))
+        else:                # half or fully unbounded
+            lo = NINF if rng.random() < 0.7 else int(rng.integers(-100, 100))
+            hi = PINF if rng.random() < 0.7 else max(lo if lo != NINF else -100, int(rng.integers(-100, 100)))
+        store[v] = (lo, hi)
+    P = int(rng.integers(4, 41))
+    props = np.zeros(P, dtype=PROP_DTYPE)
+    for i in range(P):
+        op = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 6, 6, 7, 7]))
+        x = int(rng.integers(0, V)) if op < 6 else int(rng.choice([0, 1, int(rng.integers(0, V))]))
+        props[i] = (op, x, int(rng.integers(0, V)), int(rng.integers(0, V)))
+    return store, props
+
+

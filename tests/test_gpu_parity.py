@@ -176,6 +176,38 @@ def test_random_models_tree_identical(chunk, fixpoint, debug):
             np.testing.assert_array_equal(best_g, best_o, err_msg=str(seed))
 
 
+@pytest.mark.parametrize("mode", ["ac1", "wac1", "event", "event_compact"])
+def test_random_networks_with_wide_and_infinite_domains(mode):
+    """Fuzz at the node level: all eight operators over small, Boolean, wide (1e6), huge (2^30: saturation) and
+    unbounded domains; the fixpoint must be the oracle's, bit for bit."""
+    from fuzz_models import random_network
+    cfg = {"ac1": dict(fixpoint=0), "wac1": dict(fixpoint=1), "event": dict(fixpoint=2), "event_compact": dict(fixpoint=2, debug=COMPACT)}[mode]
+    for seed in range(200):
+        rng = np.random.default_rng(seed)
+        store, props = random_network(rng)
+        stores = [store]
+        for _ in range(3):
+            s = store.copy()
+            for v in rng.choice(np.arange(3, s.shape[0]), size=min(3, s.shape[0] - 3), replace=False):
+                lo, hi = int(s["lb"][v]), int(s["ub"][v])
+                if lo == capi.TB_NINF or hi == capi.TB_PINF or lo >= hi:
+                    continue
+                m = int(rng.integers(lo, hi + 1))
+                if rng.random() < 0.5:
+                    s["ub"][v] = m
+                else:
+                    s["lb"][v] = m
+            stores.append(s)
+        stores = np.stack(stores)
+        got, failed, ent, _, _, _ = capi.propagate(props, stores, capi.make_config(timeout_ms=20000, **cfg))
+        for i in range(stores.shape[0]):
+            exp, efailed, eent, _, _ = pyoracle.propagate(stores[i], props)
+            assert bool(failed[i]) == efailed, (seed, i)
+            if not efailed:
+                assert bool(ent[i]) == eent, (seed, i)
+                np.testing.assert_array_equal(got[i], exp, err_msg=f"seed {seed} store {i}")
+
+
 def test_unsat_and_errors():
     tcn = frontend.Model.from_string("var 1..3: x; var 1..3: y; constraint int_lt(x,y); constraint int_lt(y,x); solve satisfy;").tcn()
     has, _, st = capi.solve(tcn, capi.make_config(timeout_ms=20000))
