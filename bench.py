@@ -175,6 +175,16 @@ def main() -> int:
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        issue = None  # what really bounds the kernel: SQ instruction-issue counters of the same command (profiles/)
+        sfile = os.path.join(ROOT, "profiles", "r01_sq_summary.json")
+        if os.path.exists(sfile) and args.workload == "wordpress7_500":
+            try:
+                k = json.load(open(sfile))["kernels"].get(args.fixpoint)
+                if k:
+                    issue = {key: k[key] for key in ("valu_busy", "salu_busy", "lds_busy", "valu_insts_per_64_propagations")}
+                    issue["source"] = "profiles/r01_sq_summary.json (rocprofv3 --pmc SQ_* passes of this command)"
+            except Exception:
+                issue = None
         out = {
             "metric": "propagations/sec (+ nodes/sec) on wordpress7_500.fzn" if args.workload == "wordpress7_500" else f"propagations/sec (+ nodes/sec) on {fzn}",
             "value": g_props / elapsed, "unit": "propagations/s",
@@ -194,6 +204,8 @@ def main() -> int:
                          "note": "algorithmic bytes = 40 B x propagations + 8 B x narrowed bounds; the store is LDS-resident on this "
                                  "workload, so the figure prices LDS+L2 traffic against the HBM peak (see DESIGN.md)"},
         }
+        if issue is not None:
+            out["roofline"]["instruction_issue"] = issue
         if event is not None:
             out["event_mode"] = event
         if world == 1 and not args.no_cpu_baseline:
