@@ -76,12 +76,14 @@ def check_batch(tcn, stores, **cfg):
 def test_root_fixpoint_bit_exact(rel, fixpoint, debug):
     tcn = load(rel)
     check_batch(tcn, tcn.store[None, :], fixpoint=fixpoint, debug=debug)
+    if fixpoint < 2:
+        check_batch(tcn, tcn.store[None, :], fixpoint=fixpoint, entailed_prop_removal=1)
 
 
 @pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pennies5.fzn",
                                  "test_data/triangular9.fzn", "test_data/bug4.fzn", "accap_a3.fzn"])
 @pytest.mark.parametrize("mode", ["wac1", "ac1", "globalmem", "t1024", "event", "event_globalmem", "event_t1024",
-                                  "event_compact", "event_compact_globalmem", "event_compact_t1024"])
+                                  "event_compact", "event_compact_globalmem", "event_compact_t1024", "wac1_rm", "ac1_rm", "globalmem_rm"])
 def test_random_nodes_bit_exact(rel, mode):
     tcn = load(rel)
     stores = random_nodes(tcn, 48, seed=zlib.crc32(rel.encode()) % 1000)
@@ -89,7 +91,9 @@ def test_random_nodes_bit_exact(rel, mode):
            "t1024": dict(fixpoint=1, threads_per_block=1024), "event": dict(fixpoint=2),
            "event_globalmem": dict(fixpoint=2, only_global_memory=1), "event_t1024": dict(fixpoint=2, threads_per_block=1024),
            "event_compact": dict(fixpoint=2, debug=COMPACT), "event_compact_globalmem": dict(fixpoint=2, only_global_memory=1, debug=COMPACT),
-           "event_compact_t1024": dict(fixpoint=2, threads_per_block=1024, debug=COMPACT)}[mode]
+           "event_compact_t1024": dict(fixpoint=2, threads_per_block=1024, debug=COMPACT),
+           "wac1_rm": dict(fixpoint=1, entailed_prop_removal=1), "ac1_rm": dict(fixpoint=0, entailed_prop_removal=1),
+           "globalmem_rm": dict(fixpoint=1, only_global_memory=1, entailed_prop_removal=1)}[mode]
     check_batch(tcn, stores, **cfg)
 
 
@@ -101,13 +105,14 @@ def test_wordpress_nodes_bit_exact():
     check_batch(tcn, stores, fixpoint=2, debug=0x80000)  # the same without it
 
 
-@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT)], ids=["wac1", "event", "event_compact"])
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT), (1, "rm"), (0, "rm")], ids=["wac1", "event", "event_compact", "wac1_rm", "ac1_rm"])
 @pytest.mark.parametrize("rel,expected", FAST)
 def test_sequential_tree_identical(rel, expected, fixpoint, debug):
+    rm, debug = (1, 0) if debug == "rm" else (0, debug)
     """One workgroup, one subproblem: the GPU explores exactly the oracle's DFS tree."""
     tcn = load(rel)
     has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=0, timeout_ms=120000)
-    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=0, timeout_ms=120000, fixpoint=fixpoint, debug=debug))
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=0, timeout_ms=120000, fixpoint=fixpoint, debug=debug, entailed_prop_removal=rm))
     assert has_g == has_o and st_g["exhaustive"] == st_o["exhaustive"] == 1
     assert tcn.objective_of(best_g) == expected
     for k in ("nodes", "fails", "solutions", "depth_max"):
@@ -117,26 +122,28 @@ def test_sequential_tree_identical(rel, expected, fixpoint, debug):
 
 @pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pat7.fzn", "test_data/sudoku_opt_p0.fzn"])
 @pytest.mark.parametrize("power", [3, 6])
-@pytest.mark.parametrize("fixpoint,levels,debug", [(1, 0, 0), (2, 0, 0), (2, 1, 0), (2, 3, 0), (2, 0, COMPACT), (2, 1, COMPACT)],
-                         ids=["wac1", "event", "event_recompute", "event_3levels", "event_compact", "event_compact_recompute"])
+@pytest.mark.parametrize("fixpoint,levels,debug", [(1, 0, 0), (2, 0, 0), (2, 1, 0), (2, 3, 0), (2, 0, COMPACT), (2, 1, COMPACT), (1, 0, "rm"), (1, 1, "rm")],
+                         ids=["wac1", "event", "event_recompute", "event_3levels", "event_compact", "event_compact_recompute", "wac1_rm", "wac1_rm_recompute"])
 def test_sequential_eps_identical(rel, power, fixpoint, levels, debug):
+    rm, debug = (1, 0) if debug == "rm" else (0, debug)
     """One workgroup walking 2^d subproblems in index order == the oracle's sequential dive-and-solve
     (snapshot_levels=1 is the reference's recompute-from-root backtracking)."""
     tcn = load(rel)
     has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power)
-    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=power, timeout_ms=120000, fixpoint=fixpoint, snapshot_levels=levels, debug=debug))
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=power, timeout_ms=120000, fixpoint=fixpoint, snapshot_levels=levels, debug=debug, entailed_prop_removal=rm))
     assert has_g == has_o
     for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
         assert st_g[k] == st_o[k], k
     np.testing.assert_array_equal(best_g, best_o)
 
 
-@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT)], ids=["wac1", "event", "event_compact"])
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT), (1, "rm")], ids=["wac1", "event", "event_compact", "wac1_rm"])
 @pytest.mark.parametrize("rel,expected", ROWS)
 def test_parallel_objective_matches_known_answer(rel, expected, fixpoint, debug):
+    rm, debug = (1, 0) if debug == "rm" else (0, debug)
     """Reference regression contract (test_turbo.sh:34-67): the objective of every instance."""
     tcn = load(rel)
-    has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=60000, fixpoint=fixpoint, debug=debug))
+    has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=60000, fixpoint=fixpoint, debug=debug, entailed_prop_removal=rm))
     assert has
     assert tcn.objective_of(best) == expected
     assert st["exhaustive"] == 1, "optimality must be proved within the reference's 60 s budget"

@@ -34,7 +34,7 @@ class TbConfig(C.Structure):
                 ("verbose", C.c_int32), ("has_eps_strategy", C.c_int32), ("threads_per_block", C.c_int32),
                 ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
                 ("use_fixed_bound", C.c_int32), ("fixed_bound", C.c_int32), ("deterministic", C.c_int32),
-                ("snapshot_levels", C.c_int32), ("stream_solutions", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("snapshot_levels", C.c_int32), ("stream_solutions", C.c_int32), ("entailed_prop_removal", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class TbStats(C.Structure):

@@ -509,7 +509,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   HIP_TRY(hipMemcpy(d_stores, slabs.data(), slabs.size(), hipMemcpyHostToDevice));
   P.n_vars = n_vars; P.n_props = n_props; P.props = d_props;
   P.fixpoint = cfg.fixpoint; P.wac1_threshold = (int)std::min<uint64_t>(cfg.wac1_threshold, 0x7fffffffu);
-  P.mem_kind = plan.mem_kind; P.debug = cfg.reserved[0];
+  P.mem_kind = plan.mem_kind; P.debug = cfg.reserved[0]; P.entailed_removal = cfg.entailed_prop_removal;
   const bool event = cfg.fixpoint == 2, compact = plan.compact != 0;
   {
     int occ = 0;
@@ -653,6 +653,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   P.wac1_threshold = (int)std::min<uint64_t>(s->cfg.wac1_threshold, 0x7fffffffu);
   P.subproblems_power = plan.subproblems_power;
   P.has_eps_strategy = s->cfg.has_eps_strategy;
+  P.entailed_removal = s->cfg.entailed_prop_removal;
   P.use_fixed_bound = s->cfg.use_fixed_bound; P.fixed_bound = s->cfg.fixed_bound;
   P.mem_kind = plan.mem_kind; P.snapshot_levels = plan.snapshot_levels; P.max_depth = plan.max_depth; P.debug = s->cfg.reserved[0];
   const unsigned long long nsub = 1ull << plan.subproblems_power;

@@ -162,11 +162,16 @@ __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store
 // Returns the number of block-level sweeps.  After the call (which ends with a barrier):
 //   sh.bot          the node failed
 //   *all_entailed   no propagator is un-entailed (only meaningful when !sh.bot)
+// `slice_unent`: one byte per 64-propagator slice behind the store ("some propagator of the slice is not entailed").
+// With P.entailed_removal a slice whose byte is 0 is skipped for the whole subtree -- entailed-propagator removal
+// (FixpointSubsetGPU::select, gpu_dive_and_solve.hpp:334, barebones:984; a build option of the reference, off by
+// default) at the granularity of a wave's slice instead of a compacted index array.
 __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
-                                        ThreadCounters& tc, bool& all_entailed) {
+                                        unsigned char* slice_unent, ThreadCounters& tc, bool& all_entailed) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
   const int n = P.n_props;
   const bool wac1 = P.fixpoint == 1 && n > P.wac1_threshold;
+  const bool rm = P.entailed_removal != 0;
   const int dbg = P.debug & 0xff, force_sweeps = (P.debug >> 8) & 0xff;  // profiling knobs, 0 in production
   if (tid == 0) { st(&sh.flag[0], 0); st(&sh.unent[0], 0); }
   __syncthreads();
@@ -185,6 +190,15 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         const int4 pr = pr_next;
         pr_next = idle_record();
         if (i + T < n) pr_next = (dbg & 8) ? make_int4(K_EQ_R | (1 << (16 + K_EQ_R)), (i + T) % P.n_vars, (i * 7) % P.n_vars, (i * 13) % P.n_vars) : props[i + T];
+        if (rm) {
+          if (slice_unent[base >> 6] == 0) continue;
+          bool ch = false, un_i = false;
+          apply<false, false>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
+          if (lane == 0) tc.deductions += 64;  // iterations x active propagators (gpu_dive_and_solve.hpp:304-306)
+          changed |= ch; un |= un_i;
+          if (!__any(ch) && !__any(un_i) && lane == 0) slice_unent[base >> 6] = 0;
+          continue;
+        }
         apply<false, false>(pr, act, store, P.n_int, &sh.bot, changed, un, tc, dbg);
       }
     } else {
@@ -196,11 +210,16 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         const int4 pr = pr_next;
         pr_next = idle_record();
         if (i + T < n) pr_next = (dbg & 8) ? make_int4(K_EQ_R | (1 << (16 + K_EQ_R)), (i + T) % P.n_vars, (i * 7) % P.n_vars, (i * 13) % P.n_vars) : props[i + T];
+        if (rm && slice_unent[base >> 6] == 0) continue;
         for (;;) {
           bool ch = false, un_i = false;
           apply<false, false>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
           if (lane == 0) tc.deductions += 64;  // barebones:958-960 counts warp iterations x warp width
-          if (!__any(ch)) { un |= un_i; break; }
+          if (!__any(ch)) {
+            un |= un_i;
+            if (rm && !__any(un_i) && lane == 0) slice_unent[base >> 6] = 0;  // 1 -> 0 only: entailment is monotone below a node
+            break;
+          }
           changed = true;
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
           if (ld(&sh.bot)) break;
@@ -223,7 +242,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     if (force_sweeps) { if (it >= force_sweeps) break; else continue; }
     if (!ld(&sh.flag[k]) || ld(&sh.bot) || ld(&sh.abort)) break;
   }
-  if (!wac1 && tid == 0) tc.deductions += (unsigned long long)it * (unsigned long long)n;  // barebones:934
+  if (!wac1 && !rm && tid == 0) tc.deductions += (unsigned long long)it * (unsigned long long)n;  // barebones:934
   all_entailed = !ld(&sh.unent[k]);
   return it;
 }
@@ -612,7 +631,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
   bool all_entailed = false;
   int iters;
   if constexpr (EVENT) iters = fixpoint_event<C>(P, sh, store, props, es, tc, all_entailed);
-  else iters = fixpoint(P, sh, store, props, tc, all_entailed);
+  else iters = fixpoint(P, sh, store, props, es.unent, tc, all_entailed);
   const bool aborted = ld(&sh.abort) != 0;
   const bool failed = !aborted && ld(&sh.bot) != 0;
   if (aborted) all_entailed = false;
@@ -744,6 +763,10 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     // C. restore the root
     copy_store(store, P.root_store, VX);  // the root slab is laid out like a workgroup slab
     if (EVENT && tid == 0) sh.ev_all = 1;  // the root store is not a fixpoint: every slice runs once
+    if (!EVENT && P.entailed_removal) {  // nothing is known to be entailed yet (the event fixpoint does this in its root pass)
+      __syncthreads();
+      for (int s = tid; s < P.n_slices; s += blockDim.x) es.unent[s] = 1;
+    }
     long long t_dive = 0;
     if (tid == 0) {
       sh.cur_strategy = 0; sh.next_unassigned = 0; sh.depth = 0; sh.bot = 0;
@@ -930,6 +953,7 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
     if (tid == 0) { sh.bot = 0; sh.abort = 0; sh.red_key[0] = 0; sh.red_key[1] = 0; }
     __syncthreads();
     if (MEM >= TB_MEM_STORE_SHARED) { copy_store(store, gstore, VX); __syncthreads(); }
+    if (!EVENT && P.entailed_removal) for (int q = tid; q < P.n_slices; q += blockDim.x) es.unent[q] = 1;
     for (int i = tid; i < V; i += blockDim.x) { const Itv d = load_dom<C>(store, P.n_int, i); if (d.lb > d.ub) st(&sh.bot, 1); }
     __syncthreads();
     bool all_entailed = false;
@@ -937,7 +961,7 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
     if (EVENT) { if (tid == 0) { sh.ev_all = 1; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; } __syncthreads(); }
     if (!ld(&sh.bot)) {
       if constexpr (EVENT) iters = fixpoint_event<C>(P, sh, store, props, es, tc, all_entailed);
-      else iters = fixpoint(P, sh, store, props, tc, all_entailed);
+      else iters = fixpoint(P, sh, store, props, es.unent, tc, all_entailed);
     }
     if (MEM >= TB_MEM_STORE_SHARED) copy_store(gstore, store, VX);
     unsigned long long w = tc.writes, d = tc.deductions;

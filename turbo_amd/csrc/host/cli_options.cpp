@@ -26,7 +26,7 @@ void usage_and_exit(const std::string& program) {
       << "usage: " << program
       << " [-t 2000] [-a] [-n 10] [-i] [-f] [-s] [-v] [-arch <gpu|barebones>] [-p 48] [-or 48] [-sub 12] [-subfactor 300]"
          " [-fp <ac1|wac1|event>] [-wac1_threshold 0] [-eps_var_order <input_order|first_fail|anti_first_fail|smallest|largest>]"
-         " [-eps_value_order <min|max|split|reverse_split>] [-seed 0] [-cutnodes 0] [-disable_simplify] [-globalmem]"
+         " [-eps_value_order <min|max|split|reverse_split>] [-seed 0] [-cutnodes 0] [-disable_simplify] [-entailed_removal] [-globalmem]"
          " [-gpus 1] [-deterministic] [-threads 0] [-version 1.0.0] [-hardware \"...\"] fzninstance.fzn\n"
       << "\t-t / -timeout <ms>: timeout in milliseconds (-timeout overrides -t).\n"
       << "\t-a: all solutions (satisfaction) / intermediate solutions (optimisation); implies -n 0 -i.\n"
@@ -114,6 +114,7 @@ Options parse_options(int argc, char** argv) {
   boolean("-s", o.print_statistics);
   boolean("-globalmem", o.only_global_memory);
   boolean("-disable_simplify", o.disable_simplify);
+  boolean("-entailed_removal", o.entailed_removal);
   boolean("-force_ternarize", o.force_ternarize);
   boolean("-disable_network_analysis", o.disable_network_analysis);
   boolean("-deterministic", o.deterministic);
@@ -159,6 +160,7 @@ std::string command_line_echo(const Options& o, const char* program) {
     s << "-arch cpu -p " << o.or_nodes << " ";
   }
   if (o.disable_simplify) s << "-disable_simplify ";
+  if (o.entailed_removal) s << "-entailed_removal ";
   if (o.force_ternarize) s << "-force_ternarize ";
   if (o.disable_network_analysis) s << "-disable_network_analysis ";
   s << "-fp " << name_of(o.fixpoint) << " ";

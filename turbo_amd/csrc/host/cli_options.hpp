@@ -22,6 +22,7 @@ struct Options {
   bool only_global_memory = false;            // -globalmem
   bool force_ternarize = false;
   bool disable_simplify = false;
+  bool entailed_removal = false;              // -entailed_removal: the reference's TURBO_NO_ENTAILED_PROP_REMOVAL=OFF build, at run time
   bool disable_network_analysis = false;
   uint64_t timeout_ms = 0;                    // -t / -timeout
   uint64_t or_nodes = 0;                      // -or / -p
