@@ -7,7 +7,8 @@ node budget per workgroup (`-cutnodes`, the reference's own fixed-work switch, c
 already resident in HBM (tb_session_create uploads them before the timed region).
 N > 1: one process per GPU (torch.distributed / RCCL); the 2^d subproblems are sharded in contiguous
 slices, the only payload exchanged during a step is the incumbent objective bound (all_reduce MIN of
-one int32).  Per-GPU work is fixed, so scaling is "weak".
+one int32).  By default the node budget of a step is fixed and divided among the GPUs ("strong" scaling, the
+north star's target); `--scaling weak` gives every GPU the full per-workgroup budget.
 
 Prints ONE JSON line on rank 0.
 """
@@ -54,6 +55,9 @@ def main() -> int:
     ap.add_argument("--cutnodes", type=int, default=0, help="node budget per workgroup and step (0 = workload default)")
     ap.add_argument("--fixpoint", default="wac1", choices=["ac1", "wac1", "event"])
     ap.add_argument("--event-steps", type=int, default=2, help="extra steps in the event-driven fixpoint mode, reported beside the headline (0 = skip)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: the node budget of one step is fixed (cutnodes x workgroups of one GPU) and divided among the GPUs; "
+                         "weak: every GPU gets the full per-workgroup budget")
     ap.add_argument("--no-simplify", action="store_true", help="skip the network simplifier (the reference's -disable_simplify)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,7 +85,8 @@ def main() -> int:
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)  # "nccl" is RCCL over xGMI
 
     fzn, default_cut = WORKLOADS[args.workload]
-    cut = args.cutnodes or default_cut
+    cut_total = args.cutnodes or default_cut      # per workgroup at N = 1
+    cut = cut_total if args.scaling == "weak" else max(1, cut_total // max(world, 1))
     if args.workload == "synthetic":
         from turbo_amd.synth import make_synthetic
         tcn = make_synthetic(100_000, 500_000, seed=42)
@@ -190,13 +195,14 @@ def main() -> int:
             "value": g_props / elapsed, "unit": "propagations/s",
             "nodes_per_sec": g_nodes / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1000.0 / steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed * 1000.0 / steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32",
             "data": "synthetic (seed 42)" if args.workload == "synthetic" else "reference instance file (no randomness)",
             "config": {"workload": f"{fzn}{'' if args.no_simplify or args.workload == 'synthetic' else ' (simplified network)'}: {tcn.n_vars} interval variables x {tcn.n_props} ternary propagators, "
                                    f"{last['num_blocks']} workgroups x {last['threads_per_block']} threads per GPU, "
                                    f"{capi.MEM_KINDS[last['mem_kind']]} ({last['shared_bytes']} B LDS per workgroup), "
-                                   f"2^{last['subproblems_power']} subproblems, cutnodes={cut} per workgroup and step, fixpoint={args.fixpoint}",
+                                   f"2^{last['subproblems_power']} subproblems, cutnodes={cut} per workgroup and step"
+                                   f"{'' if world == 1 else f' ({cut_total} at 1 GPU: fixed total node budget)' if args.scaling == 'strong' else ''}, fixpoint={args.fixpoint}",
                        "parallelism": f"eps_shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
