@@ -59,6 +59,7 @@ def main() -> int:
                     help="strong: the node budget of one step is fixed (cutnodes x workgroups of one GPU) and divided among the GPUs; "
                          "weak: every GPU gets the full per-workgroup budget")
     ap.add_argument("--no-simplify", action="store_true", help="skip the network simplifier (the reference's -disable_simplify)")
+    ap.add_argument("--debug-bits", type=lambda v: int(v, 0), default=0, help="tuning knobs of tb_config.reserved[0] (experiments only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="testing aid: gloo lets two ranks share one GPU")
@@ -98,7 +99,7 @@ def main() -> int:
         _model, tcn, _ = preprocess.load_fzn_simplified(os.path.join(ROOT, "benchmarks", fzn), device=local_rank)
     fp_code = {"ac1": 0, "wac1": 1, "event": 2}
     cfg = capi.make_config(fixpoint=fp_code[args.fixpoint], stop_after_n_nodes=cut, timeout_ms=600000,
-                           device=local_rank, rank=rank, world_size=world)
+                           device=local_rank, rank=rank, world_size=world, debug=args.debug_bits)
     session = capi.Session(tcn, cfg)  # inputs uploaded to HBM here, outside the timed region
 
     from turbo_amd.distributed import exchange_until_done
