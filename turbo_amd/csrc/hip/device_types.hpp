@@ -73,7 +73,6 @@ struct DevProblem {
   int wac1_threshold;
   int subproblems_power;
   int has_eps_strategy;
-  int entailed_removal;    // sweeping fixpoints skip the slices whose propagators are all entailed
   int use_fixed_bound, fixed_bound;
   int mem_kind;            // tb_mem_kind
   int debug;               // ablation knobs for profiling (tb_config.reserved[0]); 0 in production

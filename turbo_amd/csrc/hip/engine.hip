@@ -318,27 +318,29 @@ int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
     else if (mem == TB_MEM_STORE_SHARED) FN<TB_MEM_STORE_SHARED, TM, EV, CP> __VA_ARGS__; \
     else FN<TB_MEM_TCN_SHARED, TM, EV, CP> __VA_ARGS__;                                 \
   } while (0)
-// the COMPACT store layout exists for the event-driven kernels only (the sweeps are VALU bound: decoding 2-bit
-// Booleans would cost them more than the LDS it frees)
-#define DISPATCH_KERNEL(FN, mem, tmax, event, compact, ...)                             \
+// Fourth template flag (`opt`): the COMPACT store layout for the event-driven kernels (the sweeps are VALU bound:
+// decoding 2-bit Booleans would cost them more than the LDS it frees), entailed-slice removal for the sweeps.
+#define DISPATCH_KERNEL(FN, mem, tmax, event, opt, ...)                                 \
   do {                                                                                  \
     if (tmax == 256) {                                                                  \
-      if (event && compact) DISPATCH_MEM(FN, 256, true, true, mem, __VA_ARGS__);        \
+      if (event && opt) DISPATCH_MEM(FN, 256, true, true, mem, __VA_ARGS__);            \
       else if (event) DISPATCH_MEM(FN, 256, true, false, mem, __VA_ARGS__);             \
+      else if (opt) DISPATCH_MEM(FN, 256, false, true, mem, __VA_ARGS__);               \
       else DISPATCH_MEM(FN, 256, false, false, mem, __VA_ARGS__);                       \
     } else {                                                                            \
-      if (event && compact) DISPATCH_MEM(FN, 1024, true, true, mem, __VA_ARGS__);       \
+      if (event && opt) DISPATCH_MEM(FN, 1024, true, true, mem, __VA_ARGS__);           \
       else if (event) DISPATCH_MEM(FN, 1024, true, false, mem, __VA_ARGS__);            \
+      else if (opt) DISPATCH_MEM(FN, 1024, false, true, mem, __VA_ARGS__);              \
       else DISPATCH_MEM(FN, 1024, false, false, mem, __VA_ARGS__);                      \
     }                                                                                   \
   } while (0)
 
 // Sets the dynamic-LDS limit of the kernel that will run and returns how many of its workgroups a CU holds
 // (register / LDS limited).  A persistent kernel gains nothing from queued workgroups, so the grid is capped.
-int prepare_kernel(bool solve, int mem, int tmax, bool event, bool compact, int bytes, int threads, int* max_blocks_per_cu) {
+int prepare_kernel(bool solve, int mem, int tmax, bool event, bool opt, int bytes, int threads, int* max_blocks_per_cu) {
   int rc = TB_OK;
-  if (solve) DISPATCH_KERNEL(rc = prepare_solve, mem, tmax, event, compact, (bytes, threads, max_blocks_per_cu));
-  else DISPATCH_KERNEL(rc = prepare_prop, mem, tmax, event, compact, (bytes, threads, max_blocks_per_cu));
+  if (solve) DISPATCH_KERNEL(rc = prepare_solve, mem, tmax, event, opt, (bytes, threads, max_blocks_per_cu));
+  else DISPATCH_KERNEL(rc = prepare_prop, mem, tmax, event, opt, (bytes, threads, max_blocks_per_cu));
   return rc;
 }
 
@@ -509,8 +511,8 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   HIP_TRY(hipMemcpy(d_stores, slabs.data(), slabs.size(), hipMemcpyHostToDevice));
   P.n_vars = n_vars; P.n_props = n_props; P.props = d_props;
   P.fixpoint = cfg.fixpoint; P.wac1_threshold = (int)std::min<uint64_t>(cfg.wac1_threshold, 0x7fffffffu);
-  P.mem_kind = plan.mem_kind; P.debug = cfg.reserved[0]; P.entailed_removal = cfg.entailed_prop_removal;
-  const bool event = cfg.fixpoint == 2, compact = plan.compact != 0;
+  P.mem_kind = plan.mem_kind; P.debug = cfg.reserved[0];
+  const bool event = cfg.fixpoint == 2, compact = event ? plan.compact != 0 : cfg.entailed_prop_removal != 0;  // the kernels' fourth template flag
   {
     int occ = 0;
     if ((rc = prepare_kernel(false, plan.mem_kind, plan.tmax, event, compact, plan.shared_bytes, plan.threads, &occ)) != TB_OK) return rc;
@@ -576,12 +578,12 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     // cap the grid by what is actually resident (registers, LDS): queued workgroups of a persistent kernel only
     // add tail latency; re-plan so that the subproblem count follows the real workgroup count
     int occ = 0;
-    if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->cfg.fixpoint == 2, s->plan.compact != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
+    if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->cfg.fixpoint == 2, s->cfg.fixpoint == 2 ? s->plan.compact != 0 : s->cfg.entailed_prop_removal != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     if (occ > 0 && (long long)occ * s->caps.cus < (long long)s->plan.num_blocks) {
       tb_config capped = s->cfg;
       capped.or_nodes = (uint64_t)occ * (uint64_t)s->caps.cus;
       if ((rc = choose_layout(capped, s->caps, n_vars, 1, root_store, n_props, &s->lay, &s->plan)) != TB_OK) return rc;
-      if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->cfg.fixpoint == 2, s->plan.compact != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
+      if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->cfg.fixpoint == 2, s->cfg.fixpoint == 2 ? s->plan.compact != 0 : s->cfg.entailed_prop_removal != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     }
   }
   const LaunchPlan& plan = s->plan;
@@ -653,7 +655,6 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   P.wac1_threshold = (int)std::min<uint64_t>(s->cfg.wac1_threshold, 0x7fffffffu);
   P.subproblems_power = plan.subproblems_power;
   P.has_eps_strategy = s->cfg.has_eps_strategy;
-  P.entailed_removal = s->cfg.entailed_prop_removal;
   P.use_fixed_bound = s->cfg.use_fixed_bound; P.fixed_bound = s->cfg.fixed_bound;
   P.mem_kind = plan.mem_kind; P.snapshot_levels = plan.snapshot_levels; P.max_depth = plan.max_depth; P.debug = s->cfg.reserved[0];
   const unsigned long long nsub = 1ull << plan.subproblems_power;
@@ -720,7 +721,7 @@ int tb_session_start(tb_session* s) {
   s->t_start = std::chrono::steady_clock::now();
   HIP_TRY(hipEventRecord(s->ev_start, s->stream));
   const LaunchPlan& plan = s->plan;
-  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, s->cfg.fixpoint == 2, plan.compact != 0, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->mbox_dev));
+  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, s->cfg.fixpoint == 2, s->cfg.fixpoint == 2 ? plan.compact != 0 : s->cfg.entailed_prop_removal != 0, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->mbox_dev));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev_stop, s->stream));
   s->started = true;

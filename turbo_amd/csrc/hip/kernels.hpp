@@ -163,15 +163,16 @@ __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store
 //   sh.bot          the node failed
 //   *all_entailed   no propagator is un-entailed (only meaningful when !sh.bot)
 // `slice_unent`: one byte per 64-propagator slice behind the store ("some propagator of the slice is not entailed").
-// With P.entailed_removal a slice whose byte is 0 is skipped for the whole subtree -- entailed-propagator removal
+// With RM (tb_config.entailed_prop_removal) a slice whose byte is 0 is skipped for the whole subtree -- entailed-propagator removal
 // (FixpointSubsetGPU::select, gpu_dive_and_solve.hpp:334, barebones:984; a build option of the reference, off by
 // default) at the granularity of a wave's slice instead of a compacted index array.
+template <bool RM>
 __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
                                         unsigned char* slice_unent, ThreadCounters& tc, bool& all_entailed) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
   const int n = P.n_props;
   const bool wac1 = P.fixpoint == 1 && n > P.wac1_threshold;
-  const bool rm = P.entailed_removal != 0;
+  constexpr bool rm = RM;  // compiled in or out: the headline sweep pays nothing for the option
   const int dbg = P.debug & 0xff, force_sweeps = (P.debug >> 8) & 0xff;  // profiling knobs, 0 in production
   if (tid == 0) { st(&sh.flag[0], 0); st(&sh.unent[0], 0); }
   __syncthreads();
@@ -620,7 +621,7 @@ __device__ __forceinline__ void produce_solution(const DevProblem& P, BlockShare
 
 struct NodeTimers { long long t_last; };
 
-template <bool EVENT, bool C>
+template <bool EVENT, bool C, bool RM>
 __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
                                                int2* best_store, Mailbox* mbox, ThreadCounters& tc,
                                                long long& t_mark, long long t_start) {
@@ -631,7 +632,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
   bool all_entailed = false;
   int iters;
   if constexpr (EVENT) iters = fixpoint_event<C>(P, sh, store, props, es, tc, all_entailed);
-  else iters = fixpoint(P, sh, store, props, es.unent, tc, all_entailed);
+  else iters = fixpoint<RM>(P, sh, store, props, es.unent, tc, all_entailed);
   const bool aborted = ld(&sh.abort) != 0;
   const bool failed = !aborted && ld(&sh.bot) != 0;
   if (aborted) all_entailed = false;
@@ -714,11 +715,13 @@ constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 255) / 256 * 256);
 
 // The event-driven variant is latency bound: its 256-thread form asks the register allocator for 6 waves per
 // SIMD (<= 80 VGPRs) so that 6 workgroups are resident per CU; the sweep variants are VALU bound and keep 4.
-template <int MEM, int TMAX, bool EVENT, bool C>
+// OPT: the COMPACT store layout for the event kernels, entailed-slice removal for the sweeping ones.
+template <int MEM, int TMAX, bool EVENT, bool OPT>
 #ifndef TB_EVENT_WAVES
 #define TB_EVENT_WAVES 6
 #endif
 __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES : 4) solve_kernel(DevProblem P, Mailbox* mbox) {
+  constexpr bool C = EVENT && OPT, RM = !EVENT && OPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -763,7 +766,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     // C. restore the root
     copy_store(store, P.root_store, VX);  // the root slab is laid out like a workgroup slab
     if (EVENT && tid == 0) sh.ev_all = 1;  // the root store is not a fixpoint: every slice runs once
-    if (!EVENT && P.entailed_removal) {  // nothing is known to be entailed yet (the event fixpoint does this in its root pass)
+    if (RM) {  // nothing is known to be entailed yet (the event fixpoint does this in its root pass)
       __syncthreads();
       for (int s = tid; s < P.n_slices; s += blockDim.x) es.unent[s] = 1;
     }
@@ -777,7 +780,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     __syncthreads();
     // D. dive: no objective bound while diving (gpu_dive_and_solve.hpp:370-372)
     while (sh.remaining > 0 && !sh.leaf && !sh.stop) {
-      propagate_node<EVENT, C>(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
+      propagate_node<EVENT, C, RM>(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
       if (!sh.leaf && !sh.stop) {
         split<C>(P, sh, dec, store);
         if (tid == 0) {
@@ -823,7 +826,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
         __syncthreads();
         if (sh.stop) break;
         // II. propagate
-        propagate_node<EVENT, C>(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
+        propagate_node<EVENT, C, RM>(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
         if (sh.stop) break;
         // III. branch
         if (!sh.leaf) {
@@ -925,8 +928,9 @@ struct PropagateOut {
 };
 
 // `stores` holds n_stores slabs of P.vext intervals each (the layout of a workgroup slab, encoded by the host).
-template <int MEM, int TMAX, bool EVENT, bool C>
+template <int MEM, int TMAX, bool EVENT, bool OPT>
 __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* stores, PropagateOut* out, int n_stores) {
+  constexpr bool C = EVENT && OPT, RM = !EVENT && OPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, V = P.n_vars;
@@ -953,7 +957,7 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
     if (tid == 0) { sh.bot = 0; sh.abort = 0; sh.red_key[0] = 0; sh.red_key[1] = 0; }
     __syncthreads();
     if (MEM >= TB_MEM_STORE_SHARED) { copy_store(store, gstore, VX); __syncthreads(); }
-    if (!EVENT && P.entailed_removal) for (int q = tid; q < P.n_slices; q += blockDim.x) es.unent[q] = 1;
+    if (RM) for (int q = tid; q < P.n_slices; q += blockDim.x) es.unent[q] = 1;
     for (int i = tid; i < V; i += blockDim.x) { const Itv d = load_dom<C>(store, P.n_int, i); if (d.lb > d.ub) st(&sh.bot, 1); }
     __syncthreads();
     bool all_entailed = false;
@@ -961,7 +965,7 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
     if (EVENT) { if (tid == 0) { sh.ev_all = 1; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; } __syncthreads(); }
     if (!ld(&sh.bot)) {
       if constexpr (EVENT) iters = fixpoint_event<C>(P, sh, store, props, es, tc, all_entailed);
-      else iters = fixpoint(P, sh, store, props, es.unent, tc, all_entailed);
+      else iters = fixpoint<RM>(P, sh, store, props, es.unent, tc, all_entailed);
     }
     if (MEM >= TB_MEM_STORE_SHARED) copy_store(gstore, store, VX);
     unsigned long long w = tc.writes, d = tc.deductions;
