@@ -75,7 +75,8 @@ typedef struct {
   int32_t entailed_prop_removal;    /* AC1 / WAC1: skip, below the node that proved it, every 64-propagator slice whose propagators are
                                        all entailed (the reference's build option TURBO_NO_ENTAILED_PROP_REMOVAL=OFF, CMakeLists.txt:28;
                                        default 0 like the reference).  The event-driven fixpoint always does it. */
-  int32_t reserved[3];              /* 0 in production.  Tuning / test knobs read by the engine:
+  int32_t reserved[3];              /* 0 in production.  Tuning / test knobs read by the engine (the device-side ones -- ablations, timers,
+                                       0x20000, 0x400000 -- only in a -DTB_TUNING build: they sit in the hot loops):
                                        [0] bit mask -- 0x1/0x2/0x4/0x8 and bits 8-15: sweep ablations of scripts/ablate.py (results are
                                            not fixpoints); 0x10000 in-kernel phase timers; 0x20000 keep running entailed slices;
                                            0x40000 event mode accepts < 4 workgroups per CU in LDS; 0x80000 never / 0x100000 always

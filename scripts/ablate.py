@@ -1,3 +1,4 @@
+# needs the tuning build of the engine: make hip EXTRA_HIPFLAGS=-DTB_TUNING (the knobs are compiled out otherwise)
 """Ablation of the sweep on tb_propagate (profiling knobs in tb_config.reserved[0]); results are NOT valid fixpoints."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,3 +1,4 @@
+# needs the tuning build of the engine: make hip EXTRA_HIPFLAGS=-DTB_TUNING (the knobs are compiled out otherwise)
 """Deterministic single-workgroup latency probe: same tree for every configuration (or_nodes=1, fixed d, cutnodes)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,3 +1,4 @@
+# needs the tuning build of the engine: make hip EXTRA_HIPFLAGS=-DTB_TUNING (the knobs are compiled out otherwise)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

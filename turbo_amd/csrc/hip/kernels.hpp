@@ -52,6 +52,15 @@ struct alignas(16) BlockShared {
   BlockStats bs;  // written by thread 0 only
 };
 
+// Device-side tuning / profiling knobs (tb_config.reserved[0], see include/turbo_hip.h).  They sit in the hot loops,
+// so a production build compiles them out; build with -DTB_TUNING (make hip EXTRA_HIPFLAGS=-DTB_TUNING) for
+// scripts/ablate.py, scripts/phase_probe.py and the like.
+#ifdef TB_TUNING
+__device__ __forceinline__ int knobs(const DevProblem& P) { return P.debug; }
+#else
+__device__ __forceinline__ constexpr int knobs(const DevProblem&) { return 0; }
+#endif
+
 __device__ __forceinline__ int ld(const int* p) { return __hip_atomic_load(p, TB_RLX, TB_WG); }
 __device__ __forceinline__ void st(int* p, int v) { __hip_atomic_store(p, v, TB_RLX, TB_WG); }
 
@@ -173,7 +182,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
   const int n = P.n_props;
   const bool wac1 = P.fixpoint == 1 && n > P.wac1_threshold;
   constexpr bool rm = RM;  // compiled in or out: the headline sweep pays nothing for the option
-  const int dbg = P.debug & 0xff, force_sweeps = (P.debug >> 8) & 0xff;  // profiling knobs, 0 in production
+  const int dbg = knobs(P) & 0xff, force_sweeps = (knobs(P) >> 8) & 0xff;  // profiling knobs, 0 in production
   if (tid == 0) { st(&sh.flag[0], 0); st(&sh.unent[0], 0); }
   __syncthreads();
   int it = 0, k = 0;
@@ -329,7 +338,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                                               const EventState& es, ThreadCounters& tc, bool& all_entailed) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
   const int n = P.n_props, W = es.words, S = P.n_slices;
-  const bool prof = (P.debug & 0x10000) != 0;
+  const bool prof = (knobs(P) & 0x10000) != 0;
   long long tp0 = 0;
   if (tid == 0 && prof) tp0 = wall_clock64();
   // ---- initial dirty set: everything, or the slices of the variables changed since the last fixpoint
@@ -338,7 +347,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   // Entailed-slice removal: a slice whose 64 propagators were all entailed when it last ran stays entailed in the
   // whole subtree (domains only shrink), so it is dropped when claimed.  The bytes are undefined before the root pass.
   const bool root_pass = ld(&sh.ev_all) != 0;
-  const bool drop_entailed = !root_pass && !(P.debug & 0x20000);
+  const bool drop_entailed = !root_pass && !(knobs(P) & 0x20000);
   if (all) {
     for (int i = tid; i < W; i += T) {
       const int left = S - i * 32;
@@ -416,7 +425,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       if (ld(&sh.bot)) break;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my marks are visible before I stop being busy
-    if (lane == 0) { (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG); tc.deductions += 64ull * (unsigned)((P.debug & 0x400000) ? 1 : wave_iters); }  // 0x400000: count slice runs (profiling)
+    if (lane == 0) { (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG); tc.deductions += 64ull * (unsigned)((knobs(P) & 0x400000) ? 1 : wave_iters); }  // 0x400000: count slice runs (profiling)
   }
   if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += t - tp0; tp0 = t; }  // profiling: own work
   __syncthreads();
@@ -831,7 +840,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
         // III. branch
         if (!sh.leaf) {
           const int d0 = sh.depth;
-          const bool prof = (P.debug & 0x10000) != 0;
+          const bool prof = (knobs(P) & 0x10000) != 0;
           long long tp = 0;
           if (prof && tid == 0) tp = wall_clock64();
           if (d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * VX, store, VX);  // d0 == 0: barebones:785-791
