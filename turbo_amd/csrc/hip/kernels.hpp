@@ -186,6 +186,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
   if (tid == 0) { st(&sh.flag[0], 0); st(&sh.unent[0], 0); }
   __syncthreads();
   int it = 0, k = 0;
+  unsigned wave_evals = 0;  // wave-uniform: slice evaluations of this wave (x 64 = deduce calls, barebones:958-960)
   for (;;) {
     k = it % 3;
     bool changed = false, un = false;
@@ -204,7 +205,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
           if (slice_unent[base >> 6] == 0) continue;
           bool ch = false, un_i = false;
           apply<false, false>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
-          if (lane == 0) tc.deductions += 64;  // iterations x active propagators (gpu_dive_and_solve.hpp:304-306)
+          ++wave_evals;  // iterations x active propagators (gpu_dive_and_solve.hpp:304-306)
           changed |= ch; un |= un_i;
           if (!__any(ch) && !__any(un_i) && lane == 0) slice_unent[base >> 6] = 0;
           continue;
@@ -224,7 +225,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         for (;;) {
           bool ch = false, un_i = false;
           apply<false, false>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
-          if (lane == 0) tc.deductions += 64;  // barebones:958-960 counts warp iterations x warp width
+          ++wave_evals;
           if (!__any(ch)) {
             un |= un_i;
             if (rm && !__any(un_i) && lane == 0) slice_unent[base >> 6] = 0;  // 1 -> 0 only: entailment is monotone below a node
@@ -253,6 +254,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     if (!ld(&sh.flag[k]) || ld(&sh.bot) || ld(&sh.abort)) break;
   }
   if (!wac1 && !rm && tid == 0) tc.deductions += (unsigned long long)it * (unsigned long long)n;  // barebones:934
+  if (lane == 0) tc.deductions += 64ull * wave_evals;
   all_entailed = !ld(&sh.unent[k]);
   return it;
 }
