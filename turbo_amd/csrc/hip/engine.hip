@@ -164,7 +164,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   p.chg_cap = std::min(1024, std::max(64, n_vars / 4));
   if (cfg.reserved[1] > 0) p.chg_cap = cfg.reserved[1];  // tuning knob
   const size_t dirty_b = align16((size_t)dirty_words * 4) + align16((size_t)p.chg_cap * 4);
-  const size_t store_b = align16((size_t)vext * 8) + dirty_b, props_b = align16((size_t)n_props * 16);
+  const size_t store_b = align16((size_t)vext * 8) + dirty_b, props_b = (size_t)n_slices * 64 * 16;  // padded to whole slices
   const size_t fixed = SH_BYTES;
   int bpc_max = std::min(cfg.reserved[2] > 0 ? cfg.reserved[2] : 8, 2048 / T);  // 32 waves per CU (reserved[2]: tuning knob)
   if (bpc_max < 1) bpc_max = 1;
@@ -255,7 +255,8 @@ Adjacency build_adjacency(int32_t n_vars, int32_t n_props, const tb_prop* props,
 // "operand is read by no other slice" bits 8-10 | original op << 12 | classes present in the 64-record slice << 16.
 std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::vector<char>& is_const, const std::vector<int>& value,
                              const Adjacency& adj) {
-  std::vector<int4> out((size_t)n_props);
+  // padded to whole slices with idle records (never narrow, always entailed): the kernels may load any lane of a slice
+  std::vector<int4> out(((size_t)n_props + 63) / 64 * 64, make_int4(K_LEQ_T, 0, 0, 0));
   for (int32_t base = 0; base < n_props; base += 64) {
     const int32_t end = std::min(n_props, base + 64);
     const int s = base / 64;
@@ -485,7 +486,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   DevBuffers bufs;
   DevProblem P{};
   int4* d_props = nullptr; int2* d_stores = nullptr; PropagateOut* d_out = nullptr;
-  if ((rc = bufs.alloc(&d_props, (size_t)n_props)) != TB_OK) return rc;
+  if ((rc = bufs.alloc(&d_props, ((size_t)n_props + 63) / 64 * 64)) != TB_OK) return rc;
   if ((rc = bufs.alloc(&d_stores, (size_t)n_stores * VX)) != TB_OK) return rc;
   if ((rc = bufs.alloc(&d_out, (size_t)n_stores)) != TB_OK) return rc;
   {
@@ -496,7 +497,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     const InternalNet net = to_internal(lay, stores_inout, n_props, props);
     const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const);
     const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj);
-    if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), (size_t)n_props * sizeof(int4), hipMemcpyHostToDevice));
+    if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
     int4* d_head = nullptr; int* d_adj = nullptr;
     if ((rc = bufs.alloc(&d_head, adj.heads.size())) != TB_OK) return rc;
     if ((rc = bufs.alloc(&d_adj, adj.rest.size())) != TB_OK) return rc;
@@ -605,7 +606,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   const int32_t i_obj = obj_var >= 0 ? lay.perm[(size_t)obj_var] : -1;
 
   int4* d_props = nullptr; int2* d_root = nullptr; int *d_vo = nullptr, *d_vl = nullptr, *d_off = nullptr, *d_sv = nullptr;
-  if ((rc = s->bufs.alloc(&d_props, (size_t)n_props)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&d_props, ((size_t)n_props + 63) / 64 * 64)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_root, VX)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_vo, (size_t)n_strats)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_vl, (size_t)n_strats)) != TB_OK) return rc;
@@ -618,7 +619,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     find_constants(n_vars, 1, net.store.data(), &is_const, &value);  // constants = singleton variables of the root store
     const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const);
     const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj);
-    if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), (size_t)n_props * sizeof(int4), hipMemcpyHostToDevice));
+    if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
     int4* d_head = nullptr; int* d_adj = nullptr;
     if ((rc = s->bufs.alloc(&d_head, adj.heads.size())) != TB_OK) return rc;
     if ((rc = s->bufs.alloc(&d_adj, adj.rest.size())) != TB_OK) return rc;

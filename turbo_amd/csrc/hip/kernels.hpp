@@ -192,15 +192,17 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     bool changed = false, un = false;
     // The bytecode of the next 64-propagator slice is fetched while the current one is evaluated
     // (software prefetch: the 16-B records come from L2 unless they were staged in LDS).
+    // (the record array is padded to whole slices with idle records, and the prefetch index is clamped to the last
+    //  slice instead of being predicated: an unconditional load lets the wait sink to the first use)
+    const int last_base = ((n - 1) >> 6) << 6;
     int4 pr_next = idle_record();
-    if (tid < n) pr_next = (dbg & 8) ? make_int4(K_EQ_R | (1 << (16 + K_EQ_R)), tid % P.n_vars, (tid * 7) % P.n_vars, (tid * 13) % P.n_vars) : props[tid];
+    if (n > 0) pr_next = props[imin(tid - lane, last_base) + lane];
     if (!wac1) {
       for (int base = tid - lane; base < n; base += T) {
         const int i = base + lane;
         const bool act = i < n;
         const int4 pr = pr_next;
-        pr_next = idle_record();
-        if (i + T < n) pr_next = (dbg & 8) ? make_int4(K_EQ_R | (1 << (16 + K_EQ_R)), (i + T) % P.n_vars, (i * 7) % P.n_vars, (i * 13) % P.n_vars) : props[i + T];
+        pr_next = props[imin(base + T, last_base) + lane];
         if (rm) {
           if (slice_unent[base >> 6] == 0) continue;
           bool ch = false, un_i = false;
@@ -219,8 +221,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         const int i = base + lane;
         const bool act = i < n;
         const int4 pr = pr_next;
-        pr_next = idle_record();
-        if (i + T < n) pr_next = (dbg & 8) ? make_int4(K_EQ_R | (1 << (16 + K_EQ_R)), (i + T) % P.n_vars, (i * 7) % P.n_vars, (i * 13) % P.n_vars) : props[i + T];
+        pr_next = props[imin(base + T, last_base) + lane];
         if (rm && slice_unent[base >> 6] == 0) continue;
         for (;;) {
           bool ch = false, un_i = false;
@@ -749,7 +750,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   const int4* props = P.props;
   if (MEM == TB_MEM_TCN_SHARED) {
     int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + store_bytes + dirty_bytes);
-    for (int i = tid; i < P.n_props; i += blockDim.x) lprops[i] = P.props[i];
+    for (int i = tid; i < P.n_slices * 64; i += blockDim.x) lprops[i] = P.props[i];  // whole slices: the array is padded
     props = lprops;
   }
   for (int i = tid; i < P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
@@ -956,7 +957,7 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
   const int4* props = P.props;
   if (MEM == TB_MEM_TCN_SHARED) {
     int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + store_bytes + dirty_bytes);
-    for (int i = tid; i < P.n_props; i += blockDim.x) lprops[i] = P.props[i];
+    for (int i = tid; i < P.n_slices * 64; i += blockDim.x) lprops[i] = P.props[i];  // whole slices: the array is padded
     props = lprops;
   }
   for (int s = blockIdx.x; s < n_stores; s += gridDim.x) {
