@@ -195,10 +195,11 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     // (the record array is padded to whole slices with idle records, and the prefetch index is clamped to the last
     //  slice instead of being predicated: an unconditional load lets the wait sink to the first use)
     const int last_base = ((n - 1) >> 6) << 6;
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid - lane);  // wave-uniform: slice addressing stays in SGPRs
     int4 pr_next = idle_record();
-    if (n > 0) pr_next = props[imin(tid - lane, last_base) + lane];
+    if (n > 0) pr_next = props[imin(wave_base, last_base) + lane];
     if (!wac1) {
-      for (int base = tid - lane; base < n; base += T) {
+      for (int base = wave_base; base < n; base += T) {
         const int i = base + lane;
         const bool act = i < n;
         const int4 pr = pr_next;
@@ -217,7 +218,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     } else {
       // WAC1: a wave iterates its 64 propagators to a local fixpoint before moving on (config.cpp:26,
       // warp_fixpoint at barebones:955; the wave is 64 wide on CDNA).
-      for (int base = tid - lane; base < n; base += T) {
+      for (int base = wave_base; base < n; base += T) {
         const int i = base + lane;
         const bool act = i < n;
         const int4 pr = pr_next;
