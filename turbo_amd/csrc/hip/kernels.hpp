@@ -390,8 +390,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     if (lane == 0) (void)__hip_atomic_fetch_add(&sh.ev_busy, 1, TB_RLX, TB_WG);
     const int i = s * 64 + lane;
     const bool act = i < n;
-    int4 pr = idle_record();
-    if (act) pr = props[i];
+    const int4 pr = props[i];  // the record array is padded to whole slices with idle records
     if (drop_entailed && es.unent[s] == 0) {
       if (lane == 0) (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG);
       continue;
