@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 ROWS = known_answers()
 FAST = [r for r in ROWS if r[0] not in SLOW_FOR_ORACLE]
-HEADLINE = ["example_wordpress7_500.fzn", "accap_a3.fzn"]
+HEADLINE = ["example_wordpress7_500.fzn", "accap_a3.fzn", "trains15.fzn",
+            "unsolved_bugs_data/bigdom.fzn"]  # bigdom: objective near 2^31 (the reference lists it as an unsolved 32-bit hazard)
 COMPACT = 0x100000  # tb_config.reserved[0]: force the 2-bit Boolean store layout of the event kernels
 
 
@@ -81,7 +82,7 @@ def test_root_fixpoint_bit_exact(rel, fixpoint, debug):
 
 
 @pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pennies5.fzn",
-                                 "test_data/triangular9.fzn", "test_data/bug4.fzn", "accap_a3.fzn"])
+                                 "test_data/triangular9.fzn", "test_data/bug4.fzn", "accap_a3.fzn", "unsolved_bugs_data/bigdom.fzn"])
 @pytest.mark.parametrize("mode", ["wac1", "ac1", "globalmem", "t1024", "event", "event_globalmem", "event_t1024",
                                   "event_compact", "event_compact_globalmem", "event_compact_t1024", "wac1_rm", "ac1_rm", "globalmem_rm"])
 def test_random_nodes_bit_exact(rel, mode):
