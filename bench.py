@@ -211,6 +211,14 @@ def main() -> int:
                          "note": "algorithmic bytes = 40 B x propagations + 8 B x narrowed bounds; the store is LDS-resident on this "
                                  "workload, so the figure prices LDS+L2 traffic against the HBM peak (see DESIGN.md)"},
         }
+        if last["mem_kind"] != 0:
+            # with the store in LDS the HBM fraction says little; the 24 B of domain gathers per propagation are
+            # LDS traffic, priced against 256 B/clk/CU (ds_read_b64, MI355X_MICROARCH.md LDS section) x CUs x shader clock
+            info = capi.device_info(local_rank)
+            lds_peak = info["compute_units"] * 256.0 * info["clock_khz"] * 1e3 / 1e9
+            lds_ach = (tot["num_deductions"] * 24 / steps) / max(kernel_s, 1e-12) / 1e9
+            out["roofline"]["lds"] = {"achieved": lds_ach, "peak": lds_peak, "unit": "GB/s", "frac": lds_ach / lds_peak,
+                                      "note": "3 x 8 B domain gathers per propagation served by LDS"}
         if issue is not None:
             out["roofline"]["instruction_issue"] = issue
         if event is not None:
