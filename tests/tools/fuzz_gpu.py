@@ -1,6 +1,6 @@
 """One-off: many random models, GPU tree vs oracle tree (see tests/test_gpu_parity.py::test_random_models_tree_identical)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from fuzz_models import random_model

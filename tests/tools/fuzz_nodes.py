@@ -1,11 +1,11 @@
 """One-off: random ternary networks with wide and infinite domains, node-level parity (tb_propagate vs orc_propagate).
 
-usage: python scripts/fuzz_nodes.py <first seed> <last seed>
+usage: python tests/tools/fuzz_nodes.py <first seed> <last seed>
 Every network has 6-24 variables and 4-40 propagators over all eight operators; a batch of perturbed stores per
 network is pushed through AC1 / WAC1 / event / event+compact and compared bit for bit with the oracle.
 """
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import pyoracle

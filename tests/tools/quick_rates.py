@@ -1,6 +1,6 @@
 """Quick throughput probe (not the bench): GPU engine vs CPU oracle on the headline instances."""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from turbo_amd import frontend, capi
 from oracle import pyoracle

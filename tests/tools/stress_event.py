@@ -1,6 +1,6 @@
 """Stress: many concurrent copies of the same search nodes at full occupancy must all match the oracle."""
 import os, sys, zlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from turbo_amd import frontend, capi
