@@ -39,8 +39,19 @@ $(BINDIR)/turbo: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libturbo_front.so $(LIBDIR)/l
 	@mkdir -p $(BINDIR)
 	$(CXX) $(CXXFLAGS) -fPIE -o $@ $(HOST_SRC) -Iinclude -L$(LIBDIR) -lturbo_front -lturbo_hip -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(ROCM)/lib -lpthread
 
+# AddressSanitizer + UBSan on the CPU code (front-end and oracle) over every benchmark input; GPU sanitizers are not available
+SAN := -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer
+sanitize:
+	@mkdir -p build
+	$(CC) $(SAN) -std=c11 -c oracle/oracle.c -o build/oracle_san.o
+	$(CXX) $(SAN) -std=c++17 tests/tools/san_front.cpp $(FRONT_SRC) -o build/san_front
+	$(CXX) $(SAN) -std=c++17 tests/tools/san_oracle.cpp $(FRONT_SRC) build/oracle_san.o -o build/san_oracle
+	build/san_front benchmarks/*.fzn benchmarks/test_data/*.fzn benchmarks/test_data/*.xml benchmarks/unsolved_bugs_data/*.fzn > build/san_front.log
+	build/san_oracle benchmarks/*.fzn benchmarks/test_data/*.fzn benchmarks/unsolved_bugs_data/bigdom.fzn > build/san_oracle.log
+	@echo "sanitize: no report"
+
 clean:
 	rm -rf $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all front hip cli oracle clean
+.PHONY: all front hip cli oracle sanitize clean

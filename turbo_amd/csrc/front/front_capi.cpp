@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <random>
 #include <sstream>
 
@@ -70,10 +71,10 @@ std::string analyze_model(const Model& m) {
 tf_model* build(const std::string& text, char* err, int32_t err_len) {
   try {
     Model m = parse_flatzinc(text);
-    tf_model* out = new tf_model;
+    std::unique_ptr<tf_model> out(new tf_model);
     out->tcn = lower_to_tcn(m);
     out->fcn_stats = analyze_model(m);
-    return out;
+    return out.release();
   } catch (const std::exception& e) {
     set_err(err, err_len, e.what());
     return nullptr;
