@@ -80,7 +80,8 @@ typedef struct {
                                        [0] bit mask -- 0x1/0x2/0x4/0x8 and bits 8-15: sweep ablations of scripts/ablate.py (results are
                                            not fixpoints); 0x10000 in-kernel phase timers; 0x20000 keep running entailed slices;
                                            0x40000 event mode accepts < 4 workgroups per CU in LDS; 0x80000 never / 0x100000 always
-                                           use the compact (2-bit Boolean) store layout of the event kernels; 0x400000 count slice
+                                           use the compact (2-bit Boolean) store layout of the event kernels; 0x200000 keep the caller's
+                                           propagator order instead of sorting the records by class; 0x400000 count slice
                                            runs instead of propagator evaluations;
                                        [1] capacity of the event change list; [2] cap on workgroups per CU */
 } tb_config;

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -368,7 +369,7 @@ struct InternalNet {
   std::vector<tb_itv> store;  // first store of the batch, internal order
   std::vector<tb_prop> props;
 };
-InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, const tb_prop* props) {
+InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, const tb_prop* props, bool keep_order) {
   InternalNet n;
   n.store.resize((size_t)L.n_vars);
   for (int v = 0; v < L.n_vars; ++v) n.store[(size_t)L.perm[(size_t)v]] = store[v];
@@ -377,6 +378,18 @@ InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, c
     const tb_prop& q = props[i];
     n.props[(size_t)i] = tb_prop{q.op, L.perm[(size_t)q.x], L.perm[(size_t)q.y], L.perm[(size_t)q.z]};
   }
+  // Record order is the engine's choice (the fixpoint does not depend on it): a stable sort by pack-time class (and by
+  // operator inside the heavy class) makes almost every 64-record slice class-pure, so a slice evaluation runs one
+  // class body instead of two or three.  Measured on wordpress7_500 (583 of 718 slices mixed `b = (y = z)` with
+  // `y <= z`): WAC1 2.25e11 -> 3.3e11 propagations/s and 1.09 -> 1.5e6 nodes/s, event mode 4.9 -> 6.5e6 nodes/s.
+  // The sort is stable, so the records of one constraint stay together inside their class.
+  if (keep_order) return n;
+  auto key = [&](const tb_prop& q) {
+    const tb_itv d = n.store[(size_t)q.x];
+    const bool xc = d.lb == d.ub && d.lb != TB_NINF && d.lb != TB_PINF;
+    return class_of(q.op, xc, xc ? d.lb : 0) * 16 + q.op;
+  };
+  std::stable_sort(n.props.begin(), n.props.end(), [&](const tb_prop& a, const tb_prop& c) { return key(a) < key(c); });
   return n;
 }
 
@@ -496,7 +509,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     std::vector<int> v0, value((size_t)n_vars);
     find_constants(n_vars, n_stores, stores_inout, &c0, &v0);
     for (int v = 0; v < n_vars; ++v) { is_const[(size_t)lay.perm[(size_t)v]] = c0[(size_t)v]; value[(size_t)lay.perm[(size_t)v]] = v0[(size_t)v]; }
-    const InternalNet net = to_internal(lay, stores_inout, n_props, props);
+    const InternalNet net = to_internal(lay, stores_inout, n_props, props, (cfg.reserved[0] & 0x200000) != 0);
     const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const);
     const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -615,7 +628,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   if ((rc = s->bufs.alloc(&d_off, (size_t)n_strats + 1)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_sv, (size_t)total_svars)) != TB_OK) return rc;
   {
-    const InternalNet net = to_internal(lay, root_store, n_props, props);
+    const InternalNet net = to_internal(lay, root_store, n_props, props, (s->cfg.reserved[0] & 0x200000) != 0);
     std::vector<char> is_const;
     std::vector<int> value;
     find_constants(n_vars, 1, net.store.data(), &is_const, &value);  // constants = singleton variables of the root store
