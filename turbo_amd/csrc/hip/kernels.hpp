@@ -732,7 +732,7 @@ template <int MEM, int TMAX, bool EVENT, bool OPT>
 #ifndef TB_EVENT_WAVES
 #define TB_EVENT_WAVES 6
 #endif
-__global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES : 4) solve_kernel(DevProblem P, Mailbox* mbox) {
+__global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES : (TMAX == 256 ? 5 : 4)) solve_kernel(DevProblem P, Mailbox* mbox) {
   constexpr bool C = EVENT && OPT, RM = !EVENT && OPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);

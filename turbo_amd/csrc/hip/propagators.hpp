@@ -162,6 +162,47 @@ __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y
   const int cls = w0 & 0xff;
   const int present = __builtin_amdgcn_readfirstlane(w0) >> 16;
   bool ent = false;
+  // Class-pure slices (the records are sorted by class, engine.hip: to_internal): the commonest classes get a body
+  // without any per-lane class predicate.
+  if (present == (1 << K_LEQ_T)) {  // y <= z
+    c.yu = Z.ub; c.zl = Y.lb;
+    c.ent = Y.ub <= Z.lb;
+    return c;
+  }
+  if (present == (1 << K_EQ_R)) {  // x = (y = z), x a variable
+    const bool t = X.lb >= 1, f = X.ub <= 0, u = !t && !f;
+    const bool ys = Y.lb == Y.ub, zs = Z.lb == Z.ub;
+    const bool disjoint = Y.ub < Z.lb || Y.lb > Z.ub;
+    const bool same = ys && zs && Y.lb == Z.lb;
+    const bool fy = f && ys, fz = f && zs;
+    c.xl = sel(u && same, 1, c.xl);
+    c.xu = sel(u && disjoint, 0, c.xu);
+    c.yl = sel(t, Z.lb, sel(fz && Y.lb == Z.lb, sat_add(Z.lb, 1), c.yl));
+    c.yu = sel(t, Z.ub, sel(fz && Y.ub == Z.lb, sat_sub(Z.lb, 1), c.yu));
+    c.zl = sel(t, Y.lb, sel(fy && Z.lb == Y.lb, sat_add(Y.lb, 1), c.zl));
+    c.zu = sel(t, Y.ub, sel(fy && Z.ub == Y.lb, sat_sub(Y.lb, 1), c.zu));
+    c.ent = (t && same) || (f && disjoint);
+    return c;
+  }
+  if (present == (1 << K_LEQ_R)) {  // x = (y <= z), x a variable
+    const bool t = X.lb >= 1, f = X.ub <= 0, u = !t && !f;
+    const bool le = Y.ub <= Z.lb, gt = Y.lb > Z.ub;
+    c.xl = sel(u && le, 1, c.xl);
+    c.xu = sel(u && gt, 0, c.xu);
+    c.yu = sel(t, Z.ub, c.yu);
+    c.zl = sel(t, Y.lb, c.zl);
+    c.yl = sel(f, add_lo(Z.lb, 1), c.yl);
+    c.zu = sel(f, add_hi(Y.ub, -1), c.zu);
+    c.ent = (t && le) || (f && gt);
+    return c;
+  }
+  if (present == (1 << K_ADD)) {  // x = y + z
+    c.xl = add_lo(Y.lb, Z.lb); c.xu = add_hi(Y.ub, Z.ub);
+    c.yl = sub_lo(X.lb, Z.ub); c.yu = sub_hi(X.ub, Z.lb);
+    c.zl = sub_lo(X.lb, Y.ub); c.zu = sub_hi(X.ub, Y.lb);
+    c.ent = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub && (long long)X.lb == (long long)Y.lb + (long long)Z.lb;
+    return c;
+  }
   // predicates shared by the comparison classes
   const bool xt = X.lb >= 1, xf = X.ub <= 0;
   if (present & ((1 << K_LEQ_T) | (1 << K_LEQ_F) | (1 << K_LEQ_R))) {
