@@ -133,6 +133,28 @@ template <bool EVENT, bool C>
 __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store, const int ni, int* bot, bool& changed, bool& un, ThreadCounters& tc, const int dbg = 0,
                                       int* narrowed = nullptr) {
   const int w0 = pr.x;
+  if (dbg == 0 && (__builtin_amdgcn_readfirstlane(w0) >> 16) == (1 << K_LEQ_T)) {
+    // Class-pure slice of `y <= z` (x is the constant true; two thirds of wordpress7_500 after sorting the records by
+    // class): two gathers instead of three, no candidate bookkeeping for x, one comparison per bound.
+    const Itv Y = load_dom<C>(store, ni, pr.z), Z = load_dom<C>(store, ni, pr.w);
+    const bool ny = Z.ub < Y.ub, nz = Y.lb > Z.lb;                    // y.ub := z.ub, z.lb := y.lb
+    const bool empty_in = (Y.lb > Y.ub) | (Z.lb > Z.ub);
+    const bool touched = act & (ny | nz | empty_in);
+    if (__any(touched)) {
+      if (touched) {
+        if (empty_in | (Y.lb > Z.ub)) st(bot, 1);                     // y.lb > new y.ub, or z.ub < new z.lb
+        if (!empty_in) {
+          if (ny) lower_ub<C>(store, ni, pr.z, Z.ub);
+          if (nz) raise_lb<C>(store, ni, pr.w, Y.lb);
+          tc.writes += (unsigned)ny + (unsigned)nz;
+          changed = true;
+          if (EVENT) *narrowed = ((int)ny << 1) | ((int)nz << 2);
+        }
+      }
+    }
+    un |= act & !(Y.ub <= Z.lb);
+    return;
+  }
   // three gathers issued back to back, one s_waitcnt (the LDS is ~1 % busy: gathers are cheap, VALU is not)
   Itv X{0, 1}, Y{0, 1}, Z{0, 1};
   if (!(dbg & 2)) { X = load_dom<C>(store, ni, pr.y); Y = load_dom<C>(store, ni, pr.z); Z = load_dom<C>(store, ni, pr.w); }
