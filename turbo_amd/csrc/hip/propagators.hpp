@@ -159,7 +159,7 @@ __host__ __device__ inline int class_of(int op, bool x_const, int x_value) {
 
 __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y, const Itv Z) {
   Cand c;
-  const int cls = w0 & 0xff;
+  int cls = w0 & 0xff;
   const int present = __builtin_amdgcn_readfirstlane(w0) >> 16;
   bool ent = false;
   // Class-pure slices (the records are sorted by class, engine.hip: to_internal): the commonest classes get a body
@@ -203,6 +203,11 @@ __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y
     c.ent = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub && (long long)X.lb == (long long)Y.lb + (long long)Z.lb;
     return c;
   }
+  // Mixed slice (class boundaries only, once the records are sorted).  The per-lane class predicates below are loop
+  // invariant for the caller's wave-local loop; hoisted, they would sit in ~28 SGPRs across the whole loop and push
+  // the common class-pure paths into SGPR spills (v_readlane / v_writelane are VALU work).  The empty asm makes the
+  // class look freshly written, so they are recomputed here, where they are needed.
+  asm volatile("" : "+v"(cls));
   // predicates shared by the comparison classes
   const bool xt = X.lb >= 1, xf = X.ub <= 0;
   if (present & ((1 << K_LEQ_T) | (1 << K_LEQ_F) | (1 << K_LEQ_R))) {
