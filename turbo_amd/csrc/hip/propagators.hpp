@@ -203,6 +203,25 @@ __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y
     c.ent = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub && (long long)X.lb == (long long)Y.lb + (long long)Z.lb;
     return c;
   }
+  if (present == (1 << K_MIN) || present == (1 << K_MAX)) {  // x = min(y, z) / x = max(y, z)
+    const bool fixed = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub;
+    if (present == (1 << K_MIN)) {
+      const int mnl = imin(Y.lb, Z.lb);
+      c.xl = mnl; c.xu = imin(Y.ub, Z.ub);
+      c.yl = X.lb; c.zl = X.lb;
+      c.yu = sel(Z.lb > X.ub, X.ub, c.yu);
+      c.zu = sel(Y.lb > X.ub, X.ub, c.zu);
+      c.ent = fixed && X.lb == mnl;
+    } else {
+      const int mxl = imax(Y.lb, Z.lb);
+      c.xl = mxl; c.xu = imax(Y.ub, Z.ub);
+      c.yu = X.ub; c.zu = X.ub;
+      c.yl = sel(Z.ub < X.lb, X.lb, c.yl);
+      c.zl = sel(Y.ub < X.lb, X.lb, c.zl);
+      c.ent = fixed && X.lb == mxl;
+    }
+    return c;
+  }
   // Mixed slice (class boundaries only, once the records are sorted).  The per-lane class predicates below are loop
   // invariant for the caller's wave-local loop; hoisted, they would sit in ~28 SGPRs across the whole loop and push
   // the common class-pure paths into SGPR spills (v_readlane / v_writelane are VALU work).  The empty asm makes the
