@@ -177,8 +177,8 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     p.mem_kind = TB_MEM_TCN_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b + props_b);
   } else if ((fixed + store_b) * (size_t)bpc_max <= lds) {
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b);
-  } else if (fixed + store_b <= lds && !(event && (int)(lds / (fixed + store_b)) < 4 && !(cfg.reserved[0] & 0x40000))) {
-    // (event mode: a store that leaves fewer than 4 workgroups per CU goes to global memory instead --
+  } else if (fixed + store_b <= lds && !(event && (int)(lds / (fixed + store_b)) < 3 && !(cfg.reserved[0] & 0x40000))) {
+    // (event mode: a store that leaves fewer than 3 workgroups per CU goes to global memory instead --
     //  measured 1.2-1.5x more nodes/s on wordpress7_500 / trains15 with 6 x 256-thread workgroups per CU;
     //  choose_layout then tries the COMPACT layout, which usually brings the store back into LDS)
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / (fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
