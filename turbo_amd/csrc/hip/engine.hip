@@ -383,6 +383,9 @@ InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, c
   // class body instead of two or three.  Measured on wordpress7_500 (583 of 718 slices mixed `b = (y = z)` with
   // `y <= z`): WAC1 2.25e11 -> 3.3e11 propagations/s and 1.09 -> 1.5e6 nodes/s, event mode 4.9 -> 6.5e6 nodes/s.
   // The sort is stable, so the records of one constraint stay together inside their class.
+  // Not for stores in global memory: those runs are bound by the memory system, not by VALU work, and the caller's
+  // order carries locality (the 100k x 500k synthetic network is emitted in topological order: sorted, a node needs
+  // 20 % more sweeps and the event worklist twice the evaluations).
   if (keep_order) return n;
   auto key = [&](const tb_prop& q) {
     const tb_itv d = n.store[(size_t)q.x];
@@ -509,7 +512,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     std::vector<int> v0, value((size_t)n_vars);
     find_constants(n_vars, n_stores, stores_inout, &c0, &v0);
     for (int v = 0; v < n_vars; ++v) { is_const[(size_t)lay.perm[(size_t)v]] = c0[(size_t)v]; value[(size_t)lay.perm[(size_t)v]] = v0[(size_t)v]; }
-    const InternalNet net = to_internal(lay, stores_inout, n_props, props, (cfg.reserved[0] & 0x200000) != 0);
+    const InternalNet net = to_internal(lay, stores_inout, n_props, props, (cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL);
     const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const);
     const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -628,7 +631,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   if ((rc = s->bufs.alloc(&d_off, (size_t)n_strats + 1)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_sv, (size_t)total_svars)) != TB_OK) return rc;
   {
-    const InternalNet net = to_internal(lay, root_store, n_props, props, (s->cfg.reserved[0] & 0x200000) != 0);
+    const InternalNet net = to_internal(lay, root_store, n_props, props, (s->cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL);
     std::vector<char> is_const;
     std::vector<int> value;
     find_constants(n_vars, 1, net.store.data(), &is_const, &value);  // constants = singleton variables of the root store
