@@ -676,10 +676,8 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   P.has_eps_strategy = s->cfg.has_eps_strategy;
   P.use_fixed_bound = s->cfg.use_fixed_bound; P.fixed_bound = s->cfg.fixed_bound;
   P.mem_kind = plan.mem_kind; P.snapshot_levels = plan.snapshot_levels; P.max_depth = plan.max_depth; P.debug = s->cfg.reserved[0];
-  const unsigned long long nsub = 1ull << plan.subproblems_power;
   const unsigned long long world = (unsigned long long)std::max(1, s->cfg.world_size), rank = (unsigned long long)std::max(0, s->cfg.rank);
   // contiguous slices keep the subtree skip `((idx >> r) + 1) << r` local to a GPU (clamped at the slice end)
-  (void)nsub;
   uint64_t lo = 0, hi = 0;
   if ((rc = tb_eps_slice(plan.subproblems_power, (int32_t)rank, (int32_t)world, &lo, &hi)) != TB_OK) return rc;
   P.sub_lo = lo; P.sub_hi = hi;

@@ -48,7 +48,7 @@ void final_separator(uint64_t solutions, bool exhaustive, bool optimization) {  
   else std::printf("=====UNKNOWN=====\n");
 }
 
-void print_solve_statistics(const Printer& p, const Options& o, const tb_stats& st, int n_vars, int n_props, int64_t preprocessing_ns, int64_t overall_ns) {
+void print_solve_statistics(const Printer& p, const Options&, const tb_stats& st, int n_vars, int n_props, int64_t preprocessing_ns, int64_t overall_ns) {
   const int nb = std::max(1, st.num_blocks);
   p.i("num_blocks", st.num_blocks);
   p.u("nodes", st.nodes);
@@ -81,7 +81,6 @@ void print_solve_statistics(const Printer& p, const Options& o, const tb_stats& 
   p.d("kernel_time", (double)st.kernel_ns * 1e-9);
   p.d("propagations_per_second", st.kernel_ns > 0 ? (double)st.num_deductions / ((double)st.kernel_ns * 1e-9) : 0.0);
   p.d("nodes_per_second", st.kernel_ns > 0 ? (double)st.nodes / ((double)st.kernel_ns * 1e-9) : 0.0);
-  (void)o;
 }
 
 void merge_stats(tb_stats& a, const tb_stats& b) {  // statistics.hpp:182-196 across GPUs
