@@ -17,7 +17,9 @@ HOST_SRC := $(wildcard turbo_amd/csrc/host/*.cpp)
 HOST_HDR := $(wildcard turbo_amd/csrc/host/*.hpp)
 
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter -Wno-bitwise-instead-of-logical $(EXTRA_HIPFLAGS)
+# -amdgpu-atomic-optimizer-strategy=None: the engine's LDS atomics are issued by one lane on purpose; the optimizer's
+# wave-aggregation prologue (mbcnt/bcnt) around each of them costs the event loop 3-5 %
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter -Wno-bitwise-instead-of-logical -mllvm -amdgpu-atomic-optimizer-strategy=None $(EXTRA_HIPFLAGS)
 
 all: front hip cli oracle
 
