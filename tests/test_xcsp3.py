@@ -111,6 +111,22 @@ R5 = range(0, 6)
                           "<maximum><list> m[1][] </list><condition> (eq,2) </condition></maximum>"
                           "<group><intension> ne(%0,%1) </intension><args> m[0][0] m[0][1] </args><args> m[0][1] m[1][1] </args></group>"),
      count(lambda a, b, c, d: min(a, c) >= 1 and max(c, d) == 2 and a != b and b != d, *[range(4)] * 4)),
+    ("allequal_count", inst('<array id="a" size="[4]"> 0..2 </array><var id="k"> 0..4 </var><array id="e" size="[2]"> 1..3 </array>',
+                            "<allEqual> e[] </allEqual><count><list> a[] </list><values> 0 2 </values><condition> (eq,k) </condition></count>"
+                            "<count><list> a[] </list><values> 1 </values><condition> (le,1) </condition></count>"),
+     count(lambda a, b, c, d, k, e, f: e == f and sum(v in (0, 2) for v in (a, b, c, d)) == k and sum(v == 1 for v in (a, b, c, d)) <= 1,
+           range(3), range(3), range(3), range(3), range(5), range(1, 4), range(1, 4))),
+    ("nooverlap", inst('<array id="s" size="[3]"> 0..5 </array>',
+                       "<noOverlap><origins> s[] </origins><lengths> 2 3 1 </lengths></noOverlap>"),
+     count(lambda a, b, c: all(p + lp <= q or q + lq <= p for (p, lp), (q, lq) in (((a, 2), (b, 3)), ((a, 2), (c, 1)), ((b, 3), (c, 1)))),
+           range(6), range(6), range(6))),
+    ("channel", inst('<array id="x" size="[3]"> 0..2 </array><array id="y" size="[3]"> 0..2 </array><array id="p" size="[3]"> 1..3 </array>',
+                     "<channel><list> x[] </list><list> y[] </list></channel>"
+                     '<channel><list startIndex="1"> p[] </list></channel>'),
+     count(lambda x0, x1, x2, y0, y1, y2, p1, p2, p3:
+           all(((x0, x1, x2)[i] == j) == ((y0, y1, y2)[j] == i) for i in range(3) for j in range(3)) and
+           all(((p1, p2, p3)[i] == j + 1) == ((p1, p2, p3)[j] == i + 1) for i in range(3) for j in range(3)),
+           *([range(3)] * 6 + [range(1, 4)] * 3))),
     ("instantiation_block", inst('<array id="a" size="[3]"> 0..3 </array>',
                                  "<block><instantiation><list> a[0] </list><values> 2 </values></instantiation>"
                                  "<intension> le(add(a[0],a[1],a[2]),4) </intension></block>"),

@@ -5,6 +5,7 @@
 //   variables    <var>, <array> (uniform domain: ranges and value lists; multi-dimensional sizes)
 //   constraints  <intension>, <extension> (supports / conflicts, `*`), <allDifferent>, <sum>, <cumulative>
 //                (constant lengths and heights), <element>, <minimum>, <maximum>, <ordered>, <instantiation>,
+//                <allEqual>, <count>, <noOverlap> (one dimension), <channel> (one or two lists),
 //                <group> with %i arguments, <block>
 //   objectives   <minimize> / <maximize> of type expression, sum, minimum, maximum (optional <coeffs>)
 //
@@ -603,6 +604,49 @@ struct Translator {
         }
         if (!lits.empty()) post_linear(coef, lits, c);
       }
+      return;
+    }
+    if (k == "allEqual") {
+      std::vector<Val> xs = val_list(n.child("list") ? n.child("list")->text : n.text);
+      for (size_t i = 0; i + 1 < xs.size(); ++i) cons << "constraint int_eq(" << xs[i].str() << ", " << xs[i + 1].str() << ");\n";
+      return;
+    }
+    if (k == "count") {  // number of list cells whose value is one of <values>, compared by the condition
+      std::vector<Val> xs = val_list(text_of(n, "list")), vals = val_list(text_of(n, "values"));
+      if (vals.empty()) fail("count without values");
+      std::vector<Val> hits;
+      for (auto& x : xs) {
+        std::vector<Val> any;
+        for (auto& v : vals) any.push_back(cmp("int_eq", x, v));
+        hits.push_back(as_int(any.size() == 1 ? any[0] : apply("or", any)));
+      }
+      post_linear(std::vector<int64_t>(hits.size(), 1), hits, condition(text_of(n, "condition")));
+      return;
+    }
+    if (k == "noOverlap") {  // one dimension, constant or variable lengths: s_i + l_i <= s_j  or  s_j + l_j <= s_i
+      std::vector<Val> o = val_list(text_of(n, "origins")), len = val_list(text_of(n, "lengths"));
+      if (o.size() != len.size()) fail("noOverlap: origins and lengths differ in length");
+      if (text_of(n, "origins").find('(') != std::string::npos) fail("noOverlap in several dimensions is not supported");
+      for (size_t i = 0; i < o.size(); ++i)
+        for (size_t j = i + 1; j < o.size(); ++j) {
+          Val a = cmp("int_le", apply("add", {o[i], len[i]}), o[j]), b = cmp("int_le", apply("add", {o[j], len[j]}), o[i]);
+          cons << "constraint bool_clause([" << lit(a) << ", " << lit(b) << "], []);\n";
+        }
+      return;
+    }
+    if (k == "channel") {  // one list: x[i] = j  <=>  x[j] = i ; two lists: x[i] = j  <=>  y[j] = i
+      std::vector<const Xml*> lists;
+      for (auto& c : n.kids) if (c->name == "list") lists.push_back(c.get());
+      if (lists.empty() || lists.size() > 2 || n.child("value")) fail("this form of channel is not supported");
+      std::vector<Val> x = val_list(lists[0]->text), y = lists.size() == 2 ? val_list(lists[1]->text) : x;
+      const int64_t sx = lists[0]->get("startIndex").empty() ? 0 : std::stoll(lists[0]->get("startIndex"));
+      const int64_t sy = lists.size() == 2 && !lists[1]->get("startIndex").empty() ? std::stoll(lists[1]->get("startIndex")) : (lists.size() == 2 ? 0 : sx);
+      if (x.size() != y.size()) fail("channel: lists differ in length");
+      for (size_t i = 0; i < x.size(); ++i)
+        for (size_t j = 0; j < y.size(); ++j) {
+          Val a = cmp("int_eq", x[i], konst((int64_t)j + sy)), b = cmp("int_eq", y[j], konst((int64_t)i + sx));
+          cons << "constraint bool_eq(" << lit(a) << ", " << lit(b) << ");\n";
+        }
       return;
     }
     fail("unsupported constraint <" + k + ">");
