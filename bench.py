@@ -108,7 +108,7 @@ def main() -> int:
         sess = sess or session
         sess.start()
         # incumbent exchange (all_reduce MIN of one int32 over RCCL) until every rank's kernel is done
-        exchange_until_done(sess, dist if world > 1 else None, tensor_device=tdev)
+        exchange_until_done(sess, dist if world > 1 else None, tensor_device=tdev, period_s=0.0002)
         _, _, st = sess.finish()
         return st
 
