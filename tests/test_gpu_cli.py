@@ -11,12 +11,13 @@ pytestmark = pytest.mark.gpu
 TURBO = os.path.join(ROOT, "turbo_amd", "bin", "turbo")
 
 
+@pytest.mark.parametrize("fp", ["wac1", "event"])
 @pytest.mark.parametrize("simplify_flag", ["", "-disable_simplify"], ids=["simplify", "disable_simplify"])  # test_turbo.sh:8
 @pytest.mark.parametrize("rel,expected", known_answers())
-def test_regression_script_contract(rel, expected, simplify_flag):
+def test_regression_script_contract(rel, expected, simplify_flag, fp):
     # test_turbo.sh:34-44: -eps_var_order input_order -eps_value_order min -arch barebones [-disable_simplify] -s -t 60000
     r = subprocess.run([TURBO, "-eps_var_order", "input_order", "-eps_value_order", "min", "-arch", "barebones", *([simplify_flag] if simplify_flag else []),
-                        "-s", "-t", "60000", os.path.join(BENCH, rel)], capture_output=True, text=True, timeout=180)
+                        "-fp", fp, "-s", "-t", "60000", os.path.join(BENCH, rel)], capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stderr
     m = re.search(r"objective=(-?\d+)", r.stdout)            # test_turbo.sh:47
     t = re.search(r"solveTime=([0-9.]+)", r.stdout)          # test_turbo.sh:48
