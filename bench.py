@@ -2,13 +2,18 @@
 """Benchmark of the dive-and-solve hot path (BASELINE.json metric: propagations/sec + nodes/sec on
 wordpress7_500.fzn at 1/2/4/8 MI355X).
 
-A "step" is one launch of the persistent search kernel over the whole EPS index space with a fixed
-node budget per workgroup (`-cutnodes`, the reference's own fixed-work switch, config.cpp:155), inputs
-already resident in HBM (tb_session_create uploads them before the timed region).
-N > 1: one process per GPU (torch.distributed / RCCL); the 2^d subproblems are sharded in contiguous
-slices, the only payload exchanged during a step is the incumbent objective bound (all_reduce MIN of
-one int32).  By default the node budget of a step is fixed and divided among the GPUs ("strong" scaling, the
-north star's target); `--scaling weak` gives every GPU the full per-workgroup budget.
+A "step" is one launch of the persistent search kernel(s) over the EPS index space with a fixed node budget for the
+WHOLE search (all workgroups of all GPUs together, `stop_after_n_nodes_total`), inputs already resident in HBM
+(tb_session_create uploads them before the timed region).  The budget does not depend on the number of GPUs, so
+`--gpus N` measures strong scaling: the same amount of search in less time.  (`--scaling weak` multiplies it by N.)
+
+N > 1: one process per GPU (torch.distributed; backend "nccl" is RCCL).  The 2^d subproblems are dealt block-cyclically,
+every rank's session is linked to the others' (IPC handles exchanged with an all_gather), and during a step the KERNELS
+exchange the incumbent bound and steal work from each other over xGMI; the processes only meet at the barriers around a
+step.  `--exchange host` uses the fallback instead (all_reduce MIN of one int32 relayed by the hosts, static shares).
+
+Default fixpoint is the engine's event-driven one (same tree as WAC1, fewest propagator evaluations per node); the
+reference-compatible WAC1 sweep is timed beside it (`--side-steps`).
 
 Prints ONE JSON line on rank 0.
 """
@@ -18,32 +23,94 @@ import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# instance, node budget of one step for the event / sweeping fixpoints (about one second of one MI355X each)
 WORKLOADS = {
-    "wordpress7_500": ("example_wordpress7_500.fzn", 3000),
-    "accap_a3": ("accap_a3.fzn", 4000),
-    "trains15": ("trains15.fzn", 2000),
-    "synthetic": ("synthetic 100k x 500k (seed 42)", 40),
+    "wordpress7_500": ("example_wordpress7_500.fzn", 6_000_000, 1_500_000),
+    "accap_a3": ("accap_a3.fzn", 12_000_000, 12_000_000),
+    "trains15": ("trains15.fzn", 12_000_000, 4_000_000),
+    "synthetic": ("synthetic 100k x 500k (seed 42)", 8_000, 8_000),
 }
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BYTES_PER_PROPAGATION = 40  # 16 B bytecode + 3 x 8 B domains; + 8 B per narrowed bound written
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBPS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth (8 XCDs)
+LDS_BYTES_PER_CLK_CU = 256  # MI355X_MICROARCH.md: ds_read_b64 / b128
+RECORD_BYTES = 16           # one bytecode per propagation ...
+DOMAIN_BYTES = 24           # ... and three 8-byte domains; + 8 B per narrowed bound written
+FP_CODE = {"ac1": 0, "wac1": 1, "event": 2}
 
 
-def cpu_baseline(tcn, seconds: float) -> dict:
-    """The oracle (CPU restatement of cpu_solving.hpp) on a bounded sample of the same workload, 1 core."""
+def pinned_core() -> int | None:
+    """Pin this process to one core for the CPU leg (1 core, pinned); returns the core or None."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        core = cores[len(cores) // 2]
+        os.sched_setaffinity(0, {core})
+        return core
+    except Exception:
+        return None
+
+
+def cpu_baseline(tcn, subproblems_power: int, seconds: float) -> dict:
+    """The oracle (CPU restatement of cpu_solving.hpp) on a bounded sample of the SAME node population the GPU step
+    explores: the same 2^d EPS decomposition walked in index order (dive nodes + solve nodes of the first subproblems),
+    1 core, pinned, built -O3 -march=native on this machine.  The plain DFS (the reference's own `-arch cpu` order) is a
+    second row."""
     from oracle import pyoracle
-    has, best, st = pyoracle.solve(tcn, subproblems_power=0, timeout_ms=int(seconds * 1000))
-    secs = max(st["solve_seconds"], 1e-9)
+    before = None
+    try:
+        before = os.sched_getaffinity(0)
+    except Exception:
+        pass
+    native = pyoracle.build_native(tempfile.gettempdir())
+    if native:
+        pyoracle.use_library(native)
+    core = pinned_core()
+    try:
+        _, _, st = pyoracle.solve(tcn, subproblems_power=subproblems_power, timeout_ms=int(seconds * 1000))
+        _, _, dfs = pyoracle.solve(tcn, subproblems_power=0, timeout_ms=int(seconds * 300))
+    finally:
+        if before is not None:
+            try:
+                os.sched_setaffinity(0, before)
+            except Exception:
+                pass
+    secs, dsecs = max(st["solve_seconds"], 1e-9), max(dfs["solve_seconds"], 1e-9)
+    model = ""
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
     return {"value": st["num_deductions"] / secs, "unit": "propagations/s", "cores": 1, "kind": "port",
             "nodes_per_sec": st["nodes"] / secs,
-            "sample": f"first {secs:.1f} s of the sequential DFS branch-and-bound (AC1 Gauss-Seidel) on the same instance: "
-                      f"{st['nodes']} nodes, {st['num_deductions']} propagations",
-            "host_cpus": os.cpu_count()}
+            "sample": f"first {secs:.1f} s of the sequential walk over the same 2^{subproblems_power} EPS subproblems the GPU step explores "
+                      f"(dive + solve nodes, AC1 Gauss-Seidel): {st['nodes']} nodes, {st['num_deductions']} propagations, "
+                      f"{st['eps_solved_subproblems'] + st['eps_skipped_subproblems']} subproblems done",
+            "build": "gcc -O3 -march=native (built on this host)" if native else "gcc -O3 (prebuilt, portable)",
+            "pinned_core": core, "host_cpus": os.cpu_count(), "cpu_model": model,
+            "dfs_sample": {"value": dfs["num_deductions"] / dsecs, "nodes_per_sec": dfs["nodes"] / dsecs,
+                           "sample": f"first {dsecs:.1f} s of the plain DFS branch-and-bound (no EPS; deep nodes only): {dfs['nodes']} nodes"}}
+
+
+def profile_figures(workload: str, fixpoint: str) -> dict | None:
+    """Counter-derived figures of the same command, collected by scripts/profile_round.sh in separate rocprofv3 --pmc
+    passes and committed under profiles/ (they are NOT measured in this run: the source file is named)."""
+    for name in ("r02_counters.json",):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            rec = json.load(open(path)).get(f"{workload}/{fixpoint}")
+        except Exception:
+            rec = None
+        if rec:
+            return dict(rec, source=f"profiles/{name}")
+    return None
 
 
 def main() -> int:
@@ -52,12 +119,15 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="wordpress7_500", choices=sorted(WORKLOADS))
-    ap.add_argument("--cutnodes", type=int, default=0, help="node budget per workgroup and step (0 = workload default)")
-    ap.add_argument("--fixpoint", default="wac1", choices=["ac1", "wac1", "event"])
-    ap.add_argument("--event-steps", type=int, default=2, help="extra steps in the event-driven fixpoint mode, reported beside the headline (0 = skip)")
+    ap.add_argument("--fixpoint", default="event", choices=["ac1", "wac1", "event"])
+    ap.add_argument("--nodes-total", type=int, default=0, help="node budget of one step, all GPUs together (0 = workload default)")
+    ap.add_argument("--cutnodes", type=int, default=0, help="additionally cap every workgroup at this many nodes (the reference's -cutnodes)")
+    ap.add_argument("--or-nodes", type=int, default=0, help="workgroups per GPU (0 = fill the GPU)")
+    ap.add_argument("--side-steps", type=int, default=2, help="steps of the other fixpoint (wac1 <-> event) timed beside the headline (0 = skip)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
-                    help="strong: the node budget of one step is fixed (cutnodes x workgroups of one GPU) and divided among the GPUs; "
-                         "weak: every GPU gets the full per-workgroup budget")
+                    help="strong: the node budget of a step does not depend on the number of GPUs; weak: it is multiplied by it")
+    ap.add_argument("--exchange", default="peer", choices=["peer", "host"],
+                    help="peer: the kernels exchange bound and work through their cells over xGMI; host: all_reduce(MIN) relay, static shares")
     ap.add_argument("--no-simplify", action="store_true", help="skip the network simplifier (the reference's -disable_simplify)")
     ap.add_argument("--debug-bits", type=lambda v: int(v, 0), default=0, help="tuning knobs of tb_config.reserved[0] (experiments only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -73,6 +143,7 @@ def main() -> int:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     import torch
     from turbo_amd import capi, frontend
+    from turbo_amd import distributed as tdist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible and the engine has no CPU fallback")
@@ -84,10 +155,9 @@ def main() -> int:
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)  # "nccl" is RCCL over xGMI
+        dist.barrier()  # communicator set-up happens here, outside every timed region
 
-    fzn, default_cut = WORKLOADS[args.workload]
-    cut_total = args.cutnodes or default_cut      # per workgroup at N = 1
-    cut = cut_total if args.scaling == "weak" else max(1, cut_total // max(world, 1))
+    fzn, budget_event, budget_sweep = WORKLOADS[args.workload]
     if args.workload == "synthetic":
         from turbo_amd.synth import make_synthetic
         tcn = make_synthetic(100_000, 500_000, seed=42)
@@ -97,19 +167,35 @@ def main() -> int:
         # the reference's default pipeline: root fixpoint (tb_propagate on this GPU) + network simplifier, outside the timed region
         from turbo_amd import preprocess
         _model, tcn, _ = preprocess.load_fzn_simplified(os.path.join(ROOT, "benchmarks", fzn), device=local_rank)
-    fp_code = {"ac1": 0, "wac1": 1, "event": 2}
-    cfg = capi.make_config(fixpoint=fp_code[args.fixpoint], stop_after_n_nodes=cut, timeout_ms=600000,
-                           device=local_rank, rank=rank, world_size=world, debug=args.debug_bits)
-    session = capi.Session(tcn, cfg)  # inputs uploaded to HBM here, outside the timed region
 
-    from turbo_amd.distributed import exchange_until_done
+    def make_session(fixpoint: str, budget: int):
+        """Session + whether its cell is linked to every other rank's."""
+        linked = world > 1 and args.exchange == "peer"
+        per_rank_budget = budget if (world == 1 or linked) else max(1, budget // world)  # unlinked ranks count on their own
+        cfg = capi.make_config(fixpoint=FP_CODE[fixpoint], stop_after_n_nodes_total=per_rank_budget, stop_after_n_nodes=args.cutnodes,
+                               or_nodes=args.or_nodes, timeout_ms=600000, device=local_rank, rank=rank, world_size=world, debug=args.debug_bits)
+        sess = capi.Session(tcn, cfg)  # inputs uploaded to HBM here, outside the timed region
+        tdist.agree_on_plan(sess, dist, tdev)
+        if linked:
+            linked = tdist.link_group(sess, dist, tdev)
+            if not linked and rank == 0:
+                print("bench.py: the sessions' cells could not be mapped across processes; using the host relay", file=sys.stderr)
+        if world > 1 and not linked and per_rank_budget == budget:  # fell back after planning for a shared counter
+            sess.close()
+            cfg.stop_after_n_nodes_total = max(1, budget // world)
+            sess = capi.Session(tcn, cfg)
+        return sess, linked
 
-    def one_step(sess=None) -> dict:
-        sess = sess or session
+    def one_step(sess, linked: bool) -> dict:
+        if world == 1 or linked:
+            _, _, st = tdist.run_linked(sess, dist if world > 1 else None)
+            return st
+        sess.arm()
+        dist.barrier()
         sess.start()
-        # incumbent exchange (all_reduce MIN of one int32 over RCCL) until every rank's kernel is done
-        exchange_until_done(sess, dist if world > 1 else None, tensor_device=tdev, period_s=0.0002)
+        tdist.exchange_until_done(sess, dist, tensor_device=tdev, period_s=0.0002)
         _, _, st = sess.finish()
+        dist.barrier()
         return st
 
     def sync():
@@ -117,84 +203,93 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    sync()
-    t0 = time.perf_counter()
-    tot = {"nodes": 0, "num_deductions": 0, "store_writes": 0, "kernel_ns": 0, "fixpoint_iterations": 0}
-    last = None
-    for _ in range(args.steps):
-        last = one_step()
-        for k in tot:
-            tot[k] += last[k]
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        agg = torch.tensor([tot["nodes"], tot["num_deductions"], tot["store_writes"]], dtype=torch.int64, device=tdev)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        g_nodes, g_props, g_writes = (int(x) for x in agg.tolist())
-    else:
-        g_nodes, g_props, g_writes = tot["nodes"], tot["num_deductions"], tot["store_writes"]
-
-    # the same workload in the engine's event-driven fixpoint (same tree, fewer propagator evaluations per node)
-    event = None
-    if args.event_steps > 0 and args.fixpoint != "event":
-        cfg_e = capi.make_config(fixpoint=2, stop_after_n_nodes=cut * 2, timeout_ms=600000, device=local_rank, rank=rank, world_size=world)
-        sess_e = capi.Session(tcn, cfg_e)
-        one_step(sess_e)
+    def timed(sess, linked, steps, warmup):
+        for _ in range(warmup):
+            one_step(sess, linked)
         sync()
-        te = time.perf_counter()
-        acc = {"nodes": 0, "num_deductions": 0}
-        for _ in range(args.event_steps):
-            st_e = one_step(sess_e)
-            for k in acc:
-                acc[k] += st_e[k]
+        t0 = time.perf_counter()
+        keys = ("nodes", "num_deductions", "store_writes", "kernel_ns", "fixpoint_iterations", "wait_time_ns", "eps_stolen_subproblems",
+                "num_blocks_done", "cumulative_time_block_ns", "eps_solved_subproblems", "eps_skipped_subproblems")
+        tot = {k: 0 for k in keys}
+        last = None
+        for _ in range(steps):
+            last = one_step(sess, linked)
+            for k in keys:
+                tot[k] += last[k]
         sync()
-        te = time.perf_counter() - te
+        elapsed = time.perf_counter() - t0
+        g = dict(tot)
         if world > 1:
-            t = torch.tensor([te], dtype=torch.float64, device=tdev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            te = float(t.item())
-            agg = torch.tensor([acc["nodes"], acc["num_deductions"]], dtype=torch.int64, device=tdev)
+            elapsed = float(t.item())
+            agg = torch.tensor([tot["nodes"], tot["num_deductions"], tot["store_writes"]], dtype=torch.int64, device=tdev)
             dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-            acc["nodes"], acc["num_deductions"] = (int(x) for x in agg.tolist())
-        event = {"fixpoint": "event", "steps": args.event_steps, "cutnodes": cut * 2, "nodes_per_sec": acc["nodes"] / te,
-                 "propagations_per_sec": acc["num_deductions"] / te,
-                 "note": "same search tree, propagators re-evaluated only when one of their variables was narrowed"}
-        sess_e.close()
+            g["nodes"], g["num_deductions"], g["store_writes"] = (int(x) for x in agg.tolist())
+        return elapsed, tot, g, last
+
+    scale = world if args.scaling == "weak" else 1
+    budget = (args.nodes_total or (budget_event if args.fixpoint == "event" else budget_sweep)) * scale
+    session, linked = make_session(args.fixpoint, budget)
+    plan = session.plan()
+    elapsed, tot, glob, last = timed(session, linked, args.steps, args.warmup)
+    steps = max(args.steps, 1)
+
+    # per-rank balance: kernel time, share of workgroup-time spent without a subproblem, stolen work
+    blocks = max(1, last["num_blocks"])
+    row = {"kernel_ms": tot["kernel_ns"] * 1e-6 / steps, "nodes": tot["nodes"] / steps, "propagations": tot["num_deductions"] / steps,
+           "wait_share": tot["wait_time_ns"] / max(1, tot["cumulative_time_block_ns"]),
+           "stolen_subproblems": tot["eps_stolen_subproblems"] / steps, "blocks_done": tot["num_blocks_done"] / steps,
+           "first_block_idle_ms": last["min_block_ns"] * 1e-6, "last_block_ms": last["max_block_ns"] * 1e-6, "workgroups": blocks}
+    per_rank = tdist.gather_rank_rows(row, dist if world > 1 else None, tdev)
+
+    # the other fixpoint on the same workload, beside the headline
+    side = None
+    if args.side_steps > 0 and args.fixpoint in ("event", "wac1"):
+        other = "wac1" if args.fixpoint == "event" else "event"
+        b2 = (args.nodes_total or (budget_event if other == "event" else budget_sweep)) * scale
+        sess2, linked2 = make_session(other, b2)
+        e2, _, g2, l2 = timed(sess2, linked2, args.side_steps, 1)
+        side = {"fixpoint": other, "steps": args.side_steps, "nodes_total": b2, "nodes_per_sec": g2["nodes"] / e2,
+                "propagations_per_sec": g2["num_deductions"] / e2, "workgroups_per_gpu": l2["num_blocks"], "threads": l2["threads_per_block"],
+                "memory": capi.MEM_KINDS[l2["mem_kind"]],
+                "note": ("the reference's own GPU default (-fp wac1): every propagator is evaluated in every sweep" if other == "wac1" else
+                         "the engine's event-driven fixpoint: propagators re-evaluated only when one of their variables was narrowed") + "; same search tree"}
+        sess2.close()
 
     if rank == 0:
-        steps = max(args.steps, 1)
-        kernel_s = tot["kernel_ns"] * 1e-9 / steps                 # average launch duration of solve_kernel (HIP events, rank 0)
-        alg_bytes = (tot["num_deductions"] * BYTES_PER_PROPAGATION + tot["store_writes"] * 8) / steps  # per launch, rank 0
-        achieved = alg_bytes / max(kernel_s, 1e-12) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                rec = json.load(open(tfile))
-                if (rec.get("workload") == args.workload and rec.get("cutnodes") == cut and rec.get("fixpoint") == args.fixpoint
-                        and bool(rec.get("simplified", False)) == (not args.no_simplify and args.workload != "synthetic")):
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        issue = None  # what really bounds the kernel: SQ instruction-issue counters of the same command (profiles/)
-        sfile = os.path.join(ROOT, "profiles", "r01_sq_summary.json")
-        if os.path.exists(sfile) and args.workload == "wordpress7_500":
-            try:
-                k = json.load(open(sfile))["kernels"].get(args.fixpoint)
-                if k:
-                    issue = {key: k[key] for key in ("valu_busy", "salu_busy", "lds_busy", "valu_insts_per_64_propagations")}
-                    issue["source"] = "profiles/r01_sq_summary.json (rocprofv3 --pmc SQ_* passes of this command)"
-            except Exception:
-                issue = None
+        kernel_s = tot["kernel_ns"] * 1e-9 / steps                 # average launch duration of solve_kernel (HIP events on its stream, rank 0)
+        props = tot["num_deductions"] / steps                     # propagations of one launch, rank 0
+        writes = tot["store_writes"] / steps
+        info = capi.device_info(local_rank)
+        lds_peak = info["compute_units"] * LDS_BYTES_PER_CLK_CU * info["clock_khz"] * 1e3 / 1e9
+        in_lds = last["mem_kind"] != 0
+        # algorithmic bytes per propagation = 16 B record + 3 x 8 B domains (+ 8 B per narrowed bound).  The level
+        # that serves the domains bounds the kernel's memory side: LDS when the store is LDS resident (records from L2), HBM when
+        # the store lives in global memory.  Every fraction is achieved / peak of THAT level, so it cannot exceed 1.
+        dom_gbps = (props * DOMAIN_BYTES + writes * 8) / max(kernel_s, 1e-12) / 1e9
+        rec_gbps = props * RECORD_BYTES / max(kernel_s, 1e-12) / 1e9
+        if in_lds:
+            roof = {"bound": "lds", "achieved": dom_gbps, "peak": lds_peak, "unit": "GB/s", "frac": dom_gbps / lds_peak,
+                    "records_from_l2": {"achieved": rec_gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": rec_gbps / L2_PEAK_GBPS}}
+        else:
+            alg = dom_gbps + rec_gbps
+            roof = {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBPS}
+        roof.update({"traffic": None, "kernel": "tb::solve_kernel", "avg_launch_ms": kernel_s * 1000.0,
+                     "algorithmic_bytes_per_launch": props * (RECORD_BYTES + DOMAIN_BYTES) + writes * 8,
+                     "note": "integer propagation: no MFMA.  achieved = algorithmic bytes of the level named in `bound` / average launch duration "
+                             "(HIP events around the launch, this run).  The kernel is instruction-issue bound, not memory bound: see `issue`."})
+        prof = profile_figures(args.workload, args.fixpoint)
+        if prof:
+            roof["traffic_source"] = prof.get("source")
+            roof["hbm_counters"] = {k: prof[k] for k in ("hbm_bytes_per_launch", "hbm_gbps", "hbm_frac_of_peak", "launch_ms") if k in prof}
+            roof["issue"] = {k: prof[k] for k in ("valu_busy", "salu_busy", "lds_busy", "wait_any_share", "wait_inst_any_share",
+                                                  "valu_per_64_propagations", "salu_per_64_propagations") if k in prof}
+            roof["issue"]["note"] = "binding resource; rocprofv3 --pmc SQ_* passes of this command, not measured in this run"
         out = {
             "metric": "propagations/sec (+ nodes/sec) on wordpress7_500.fzn" if args.workload == "wordpress7_500" else f"propagations/sec (+ nodes/sec) on {fzn}",
-            "value": g_props / elapsed, "unit": "propagations/s",
-            "nodes_per_sec": g_nodes / elapsed,
+            "value": glob["num_deductions"] / elapsed, "unit": "propagations/s",
+            "nodes_per_sec": glob["nodes"] / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1000.0 / steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32",
@@ -202,30 +297,24 @@ def main() -> int:
             "config": {"workload": f"{fzn}{'' if args.no_simplify or args.workload == 'synthetic' else ' (simplified network)'}: {tcn.n_vars} interval variables x {tcn.n_props} ternary propagators, "
                                    f"{last['num_blocks']} workgroups x {last['threads_per_block']} threads per GPU, "
                                    f"{capi.MEM_KINDS[last['mem_kind']]} ({last['shared_bytes']} B LDS per workgroup), "
-                                   f"2^{last['subproblems_power']} subproblems, cutnodes={cut} per workgroup and step"
-                                   f"{'' if world == 1 else f' ({cut_total} at 1 GPU: fixed total node budget)' if args.scaling == 'strong' else ''}, fixpoint={args.fixpoint}",
-                       "parallelism": f"eps_shard{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "tb::solve_kernel", "avg_launch_ms": kernel_s * 1000.0,
-                         "note": "algorithmic bytes = 40 B x propagations + 8 B x narrowed bounds; the store is LDS-resident on this "
-                                 "workload, so the figure prices LDS+L2 traffic against the HBM peak (see DESIGN.md)"},
+                                   f"2^{plan['subproblems_power']} subproblems, one step = {budget} nodes of the search by all GPUs together"
+                                   f"{'' if not args.cutnodes else f', at most {args.cutnodes} per workgroup'}, fixpoint={args.fixpoint}",
+                       "parallelism": f"eps_block_cyclic{world}" + ("" if world == 1 else ("+xgmi_steal" if linked else "+host_relay"))},
+            "roofline": roof,
         }
-        if last["mem_kind"] != 0:
-            # with the store in LDS the HBM fraction says little; the 24 B of domain gathers per propagation are
-            # LDS traffic, priced against 256 B/clk/CU (ds_read_b64, MI355X_MICROARCH.md LDS section) x CUs x shader clock
-            info = capi.device_info(local_rank)
-            lds_peak = info["compute_units"] * 256.0 * info["clock_khz"] * 1e3 / 1e9
-            lds_ach = (tot["num_deductions"] * 24 / steps) / max(kernel_s, 1e-12) / 1e9
-            out["roofline"]["lds"] = {"achieved": lds_ach, "peak": lds_peak, "unit": "GB/s", "frac": lds_ach / lds_peak,
-                                      "note": "3 x 8 B domain gathers per propagation served by LDS"}
-        if issue is not None:
-            out["roofline"]["instruction_issue"] = issue
-        if event is not None:
-            out["event_mode"] = event
+        if world > 1:
+            ks = [r["kernel_ms"] for r in per_rank]
+            out["multi_gpu"] = {"exchange": "peer cells over xGMI" if linked else "host relay", "per_rank": per_rank,
+                                "kernel_ms_max_over_mean": max(ks) / max(1e-9, sum(ks) / len(ks)),
+                                "note": "fixed node budget for all GPUs together (counted in rank 0's cell); wait_share = workgroup-time without a subproblem"}
+        else:
+            out["balance"] = per_rank[0]
+        if side is not None:
+            out[f"{side['fixpoint']}_mode"] = side
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tcn, args.cpu_seconds)
-            out["speedup_vs_cpu_baseline"] = out["value"] / max(out["cpu_baseline"]["value"], 1e-9)
+            out["cpu_baseline"] = cpu_baseline(tcn, plan["subproblems_power"], args.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = {"propagations": out["value"] / max(out["cpu_baseline"]["value"], 1e-9),
+                                              "nodes": out["nodes_per_sec"] / max(out["cpu_baseline"]["nodes_per_sec"], 1e-9)}
         print(json.dumps(out), flush=True)
     session.close()
     if world > 1:

@@ -44,7 +44,8 @@ enum tb_error {
   TB_ERR_NO_DEVICE = -2, /* no gfx950 device / HIP runtime failure at init */
   TB_ERR_HIP = -3,       /* HIP runtime error while running (see tb_last_error) */
   TB_ERR_OOM = -4,
-  TB_ERR_STATE = -5      /* session used out of order */
+  TB_ERR_STATE = -5,     /* session used out of order */
+  TB_ERR_DEPTH = -6      /* the search went deeper than the decision stack (tb_config.decision_stack_depth) */
 };
 
 typedef struct { int32_t lb, ub; } tb_itv;          /* VStore element: 8 B */
@@ -58,6 +59,8 @@ typedef struct {
   uint64_t stop_after_n_nodes;      /* -cutnodes, per workgroup (barebones:1024); 0 = no limit */
   uint64_t stop_after_n_solutions;  /* -n, satisfaction problems only; 0 = all */
   uint64_t wac1_threshold;          /* -wac1_threshold (barebones:939) */
+  uint64_t stop_after_n_nodes_total;/* node budget of the whole search, all workgroups of all linked GPUs together (0 = none): fixed total
+                                       work for strong-scaling measurements.  Counted in rank 0's cell in batches of 32 nodes per workgroup */
   int32_t subproblems_power;        /* -sub; -1 = auto */
   int32_t fixpoint;                 /* 0 = AC1, 1 = WAC1 (config.hpp:22-25), 2 = event-driven WAC1 (this engine) */
   int32_t only_global_memory;       /* -globalmem */
@@ -65,7 +68,7 @@ typedef struct {
   int32_t has_eps_strategy;         /* strategy 0 is the EPS strategy (barebones:434,747-750) */
   int32_t threads_per_block;        /* 0 = auto (reference: CMakeLists.txt:93 fixes 256) */
   int32_t device;                   /* HIP device ordinal */
-  int32_t rank, world_size;         /* EPS index space sharding across GPUs; 0/1 = single GPU */
+  int32_t rank, world_size;         /* EPS index space sharding across GPUs (block-cyclic, see tb_eps_global_index); 0/1 = single GPU */
   int32_t use_fixed_bound;          /* 1: first-solution search under obj <= fixed_bound, lowest subproblem wins (canonical pass) */
   int32_t fixed_bound;
   int32_t deterministic;            /* tb_solve only: after B&B, run the canonical pass so the returned solution is the
@@ -75,6 +78,11 @@ typedef struct {
   int32_t entailed_prop_removal;    /* AC1 / WAC1: skip, below the node that proved it, every 64-propagator slice whose propagators are
                                        all entailed (the reference's build option TURBO_NO_ENTAILED_PROP_REMOVAL=OFF, CMakeLists.txt:28;
                                        default 0 like the reference).  The event-driven fixpoint always does it. */
+  int32_t eps_chunk_log2;           /* multi-GPU: the 2^d subproblems are dealt to the GPUs in chunks of 2^k consecutive indices, k = this
+                                       value (0 = one by one, the default: best balance; clamped to subproblems_power) */
+  int32_t decision_stack_depth;     /* capacity of a workgroup's decision stack; 0 = auto (16384; the reference grows its stack on demand,
+                                       barebones:401-403 -- here tb_solve retries with a deeper one when TB_ERR_DEPTH comes back) */
+  int32_t poll_period_us;           /* wall-clock period at which the kernel looks at the host mailbox and at the peers' words; 0 = 100 us */
   int32_t reserved[3];              /* 0 in production.  Tuning / test knobs read by the engine (the device-side ones -- ablations, timers,
                                        0x20000, 0x400000 -- only in a -DTB_TUNING build: they sit in the hot loops):
                                        [0] bit mask -- 0x1/0x2/0x4/0x8 and bits 8-15: sweep ablations of scripts/ablate.py (results are
@@ -82,7 +90,8 @@ typedef struct {
                                            0x40000 event mode accepts < 4 workgroups per CU in LDS; 0x80000 never / 0x100000 always
                                            use the compact (2-bit Boolean) store layout of the event kernels; 0x200000 keep the caller's
                                            propagator order instead of sorting the records by class; 0x400000 count slice
-                                           runs instead of propagator evaluations;
+                                           runs instead of propagator evaluations; 0x800000 test aid: keep the store every workgroup stopped
+                                           on (tb_session_debug_last_store); 0x1000000 no work stealing between linked GPUs (A/B runs, tests);
                                        [1] capacity of the event change list; [2] cap on workgroups per CU */
 } tb_config;
 
@@ -98,6 +107,11 @@ typedef struct {
   int32_t mem_kind, shared_bytes, subproblems_power, best_bound;
   int32_t best_subproblem, interrupted;
   int32_t reserved[2];
+  /* multi-GPU balance (this rank): */
+  uint64_t eps_local_subproblems;   /* size of this rank's block-cyclic share of the 2^d subproblems */
+  uint64_t eps_stolen_subproblems;  /* subproblems this GPU took over from other GPUs' queues (xGMI work stealing) */
+  int64_t wait_time_ns;             /* summed over workgroups: time without a subproblem (looking / waiting for work on other GPUs) */
+  int64_t min_block_ns, max_block_ns; /* first and last workgroup to leave the kernel (the reference's first_block_idle_time is the min) */
 } tb_stats;
 
 enum tb_timer { /* enum class Timer, statistics.hpp:13-29 (same order, 11 timers) */
@@ -119,9 +133,14 @@ const char* tb_last_error(void);
 int tb_device_count(void);
 int tb_get_device_info(int device, tb_device_info* out);
 
-/* Slice [lo, hi) of the 2^d EPS subproblems owned by `rank` of `world_size` GPUs (host arithmetic only,
- * usable without a device).  Contiguous slices keep the subtree skip of barebones:732 local to a GPU. */
-int tb_eps_slice(int32_t subproblems_power, int32_t rank, int32_t world_size, uint64_t* lo_out, uint64_t* hi_out);
+/* How the 2^d EPS subproblems (barebones:413-418) are dealt to the GPUs of a node -- host arithmetic only, usable
+ * without a device.  Block-cyclic: chunk c (2^k consecutive indices) belongs to rank c % world_size; a rank numbers its own
+ * subproblems j = 0, 1, ... in index order.  Static and balanced; on top of it an idle GPU takes over the upper half of
+ * the fullest peer queue (work stealing over xGMI), so every GPU pulls from what is in effect one node-wide queue, like
+ * every block of the reference pulls from one grid-wide counter (barebones:877-884).
+ * tb_eps_local_count: number of subproblems of `rank`; tb_eps_global_index: global index of its j-th one. */
+int tb_eps_local_count(int32_t subproblems_power, int32_t chunk_log2, int32_t rank, int32_t world_size, uint64_t* count_out);
+int tb_eps_global_index(int32_t subproblems_power, int32_t chunk_log2, int32_t rank, int32_t world_size, uint64_t j, uint64_t* index_out);
 
 /*
  * One search node for a batch of independent stores: block-parallel fixpoint of all propagators
@@ -166,6 +185,37 @@ int tb_session_create(const tb_config* cfg, int32_t n_vars, const tb_itv* root_s
                       const int32_t* strat_off, const int32_t* strat_vars,
                       int32_t obj_var, tb_session** out);
 int tb_session_start(tb_session* s);
+/* What create decided (replaces the printouts of configure_gpu_barebones, barebones:527-606): grid, memory kind, 2^d.
+ * Ranks of one search compare subproblems_power before they link: the shares only tile the index space if d agrees. */
+typedef struct {
+  int32_t num_blocks, threads_per_block, mem_kind, shared_bytes, subproblems_power, eps_chunk_log2, snapshot_levels, decision_stack_depth;
+  uint64_t eps_local_subproblems;
+} tb_plan;
+int tb_session_plan(tb_session* s, tb_plan* plan_out);
+/*
+ * Multi-GPU wiring, between create and start.  Every session owns one 256-byte cell in fine-grained device memory: its
+ * work-queue word and the incumbent bound imported from the other GPUs -- the only state another GPU touches
+ * (barebones GridData::next_subproblem / appx_best_bound, :418,426).  Once the sessions of a node are linked, their
+ * kernels exchange the bound (atomicMin of one int32 into every peer's cell) and rebalance work (CAS on a peer's queue
+ * word) directly over xGMI; the host is not involved.  A session that is not linked to some rank still works: it then
+ * relies on tb_session_poll / tb_session_push_bound (host relay) for the bound and on its static share for the work.
+ *   same process:     tb_session_link_peer(a, b) in both directions (enables peer access between the two devices);
+ *   other process:    tb_session_export_peer -> 64-byte handle (hipIpcMemHandle_t), sent by whatever means the processes
+ *                     share (bench.py: torch.distributed all_gather over RCCL), tb_session_import_peer on the other side.
+ * tb_session_arm resets the device-side state of a search (queue, bounds, counters); start does it itself when the
+ * caller has not.  With linked sessions every rank arms, then all ranks synchronise, then every rank starts -- and all
+ * ranks synchronise again after finish before the next arm: a peer must not touch a cell that is being reset.
+ */
+typedef struct { unsigned char bytes[64]; } tb_peer_handle;
+int tb_session_export_peer(tb_session* s, tb_peer_handle* handle_out);
+int tb_session_import_peer(tb_session* s, int32_t peer_rank, const tb_peer_handle* handle);
+int tb_session_link_peer(tb_session* s, tb_session* peer);
+int tb_session_arm(tb_session* s);
+/* Remaining work of this GPU as of the kernel's last poll: subproblems not yet handed to a workgroup (its own share and
+ * what it took from others), and how many it has taken from / lost to other GPUs so far. */
+int tb_session_progress(tb_session* s, uint64_t* remaining_out, uint64_t* stolen_in_out, uint64_t* stolen_out_out);
+/* Test aid (tb_config.reserved[0] & 0x800000): the store workgroup `workgroup` was working on when it left the kernel. */
+int tb_session_debug_last_store(tb_session* s, int32_t workgroup, tb_itv* store_out);
 int tb_session_poll(tb_session* s, int32_t* local_best_out, int32_t* done_out);
 int tb_session_push_bound(tb_session* s, int32_t bound);
 int tb_session_stop(tb_session* s);

@@ -28,6 +28,14 @@ static int64_t g_sink_cap = 0, g_sink_count = 0;
 void orc_set_solution_sink(orc_itv* buf, int64_t capacity) { g_sink = buf; g_sink_cap = capacity; g_sink_count = 0; }
 int64_t orc_solution_sink_count(void) { return g_sink_count; }
 
+/* Optional per-node trace (tests pick a node budget whose last node did not fail) and copy of the store the search
+ * stopped on (tests compare it with the engine's, tb_session_debug_last_store); not thread safe. */
+static unsigned char* g_trace = NULL;
+static int64_t g_trace_cap = 0;
+static orc_itv* g_last_store = NULL;
+void orc_set_node_trace(unsigned char* failed_flags, int64_t capacity) { g_trace = failed_flags; g_trace_cap = capacity; }
+void orc_set_last_store_sink(orc_itv* buf) { g_last_store = buf; }
+
 #define NINF ORC_NINF
 #define PINF ORC_PINF
 
@@ -396,6 +404,7 @@ static int propagate(engine_t* e, int is_dive) {
   (void)is_dive;
   e->st.fixpoint_iterations += it;
   e->st.num_deductions += de;
+  if (g_trace && (int64_t)e->st.nodes < g_trace_cap) g_trace[e->st.nodes] = (unsigned char)(failed ? 1 : 0);
   e->st.nodes++;
   e->st.fails += failed ? 1 : 0;
   if (e->depth > e->st.depth_max) e->st.depth_max = e->depth;
@@ -494,6 +503,7 @@ int orc_solve(const orc_config* cfg, int32_t n_vars, const orc_itv* root_store,
   }
   e->st.best_bound = e->best_bound;
   e->st.solve_seconds = elapsed_s(e);
+  if (g_last_store) memcpy(g_last_store, e->store, sizeof(orc_itv) * (size_t)n_vars);
   if (has_solution_out) *has_solution_out = e->st.solutions > 0 ? 1 : 0;
   if (best_store_out && e->st.solutions > 0) memcpy(best_store_out, e->best_store, sizeof(orc_itv) * (size_t)n_vars);
   if (stats_out) *stats_out = e->st;

@@ -99,6 +99,11 @@ int orc_solve(const orc_config* cfg, int32_t n_vars, const orc_itv* root_store,
 void orc_set_solution_sink(orc_itv* buf, int64_t capacity);
 int64_t orc_solution_sink_count(void);
 
+/* Test aids: failed flag of every node of the next orc_solve calls (node i -> failed_flags[i]); a copy of the store the
+ * search was working on when it returned.  NULL switches them off. */
+void orc_set_node_trace(unsigned char* failed_flags, int64_t capacity);
+void orc_set_last_store_sink(orc_itv* buf);
+
 #ifdef __cplusplus
 }
 #endif

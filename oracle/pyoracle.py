@@ -47,10 +47,29 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def build_native(out_dir: str) -> str | None:
+    """bench.py's cpu_baseline leg: the same oracle.c compiled `-O3 -march=native` ON THE MACHINE THAT TIMES IT
+    (cpu-release flags; the prebuilt liboracle.so is portable -O3).  Returns the path, or None if gcc fails."""
+    out = os.path.join(out_dir, "liboracle_native.so")
+    try:
+        subprocess.run(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-shared", "-o", out, os.path.join(_HERE, "oracle.c")],
+                       check=True, capture_output=True, timeout=120)
+        return out
+    except Exception:
+        return None
+
+
+def use_library(path: str) -> None:
+    """Load the oracle from another build of oracle.c (see build_native)."""
+    global _lib, _LIB_PATH
+    _LIB_PATH, _lib = path, None
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        build()
+        if _LIB_PATH == os.path.join(_HERE, "liboracle.so"):
+            build()
         L = C.CDLL(_LIB_PATH)
         L.orc_deduce.restype = C.c_int
         L.orc_deduce.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -117,3 +136,21 @@ def enumerate_solutions(tcn, capacity: int = 100000):
     if k > capacity:
         raise RuntimeError(f"{k} solutions exceed the capacity {capacity}")
     return buf[:k, :n], st
+
+
+def solve_traced(tcn, cutnodes: int, subproblems_power: int = 0):
+    """solve() with a node budget, plus the failed flag of every node and the store the search stopped on."""
+    L = lib()
+    L.orc_set_node_trace.argtypes = [C.c_void_p, C.c_int64]
+    L.orc_set_last_store_sink.argtypes = [C.c_void_p]
+    n = int(np.asarray(tcn.store).shape[0])
+    trace = np.zeros(cutnodes + 1, dtype=np.uint8)
+    last = np.zeros(max(n, 1), dtype=ITV)
+    L.orc_set_node_trace(trace.ctypes.data, trace.shape[0])
+    L.orc_set_last_store_sink(last.ctypes.data)
+    try:
+        has, best, st = solve(tcn, subproblems_power=subproblems_power, cutnodes=cutnodes)
+    finally:
+        L.orc_set_node_trace(None, 0)
+        L.orc_set_last_store_sink(None)
+    return has, best, st, trace[:st["nodes"]], last[:n]

@@ -37,9 +37,10 @@ def test_front_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    # sizes computed from include/turbo_hip.h by hand: tb_config = 6*8 + 18*4 = 120, tb_stats = 9*8 + 11*8 + 3*8 + 12*4 = 232
-    assert ctypes.sizeof(capi.TbConfig) == 120
-    assert ctypes.sizeof(capi.TbStats) == 232
+    # sizes computed from include/turbo_hip.h by hand: tb_config = 7*8 + 21*4 = 140 -> 144 (8-byte alignment),
+    # tb_stats = 9*8 + 11*8 + 3*8 + 12*4 + 5*8 = 272
+    assert ctypes.sizeof(capi.TbConfig) == 144
+    assert ctypes.sizeof(capi.TbStats) == 272
 
 
 def test_no_device_is_a_loud_error():
@@ -53,14 +54,25 @@ def test_no_device_is_a_loud_error():
         capi.propagate(tcn.props, tcn.store[None, :])
 
 
-@pytest.mark.parametrize("d,world", [(0, 1), (3, 2), (10, 8), (17, 3), (40, 7)])
-def test_eps_slices_partition_the_index_space(d, world):
-    edges = [capi.eps_slice(d, r, world) for r in range(world)]
-    assert edges[0][0] == 0 and edges[-1][1] == 2 ** d
-    for (lo, hi), (lo2, _) in zip(edges, edges[1:]):
-        assert hi == lo2 and lo <= hi
-    sizes = [hi - lo for lo, hi in edges]
-    assert max(sizes) - min(sizes) <= 1
+@pytest.mark.parametrize("d,k,world", [(0, 0, 1), (3, 0, 2), (10, 0, 8), (10, 3, 8), (11, 2, 3), (13, 5, 7), (6, 9, 4), (17, 0, 3)])
+def test_block_cyclic_shares_partition_the_index_space(d, k, world):
+    """Every subproblem index belongs to exactly one rank; a rank's local numbering is in increasing global order;
+    chunk c of 2^k consecutive indices belongs to rank c % world (include/turbo_hip.h: tb_eps_global_index)."""
+    kk = min(k, d)
+    seen = np.full(2 ** d, -1, dtype=np.int64)
+    counts = []
+    for r in range(world):
+        n = capi.eps_local_count(d, k, r, world)
+        counts.append(n)
+        idx = [capi.eps_global_index(d, k, r, world, j) for j in range(n)]
+        assert idx == sorted(idx)
+        for g in idx:
+            assert seen[g] == -1 and (g >> kk) % world == r
+            seen[g] = r
+        with pytest.raises(capi.TurboHipError):
+            capi.eps_global_index(d, k, r, world, n)
+    assert (seen >= 0).all() and sum(counts) == 2 ** d
+    assert max(counts) - min(counts) <= 2 ** kk
 
 
 def test_frontend_lowering_conventions():

@@ -116,3 +116,43 @@ def test_bench_contract_line():
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and "sample" in cpu
     assert d["value"] > 10 * cpu["value"]  # north star: >= 10x the CPU propagation rate
+
+
+@pytest.mark.parametrize("fp", ["wac1", "event"])
+@pytest.mark.parametrize("simplify_flag", [[], ["-disable_simplify"]], ids=["simplify", "disable_simplify"])
+def test_unsatisfiable_root_is_reported(tmp_path, fp, simplify_flag):
+    """An inconsistent root (found by the GPU root fixpoint, not by the parser): the CLI takes `failed` from tb_propagate
+    explicitly (turbo_main.cpp: simplify_network) and prints the reference's separator (statistics.hpp:394-412)."""
+    f = tmp_path / "unsat_root.fzn"
+    f.write_text("var 1..5: x;\nvar 1..5: y;\nvar 1..5: z;\nconstraint int_lt(x,y);\nconstraint int_lt(y,z);\nconstraint int_lt(z,x);\nsolve satisfy;\n")
+    r = subprocess.run([TURBO, "-arch", "gpu", "-fp", fp, "-s", "-t", "30000", *simplify_flag, str(f)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "=====UNSATISFIABLE=====" in r.stdout and "----------" not in r.stdout
+
+
+def test_two_gpus_flag_runs_two_linked_sessions():
+    """`-gpus 2` on a one-GPU box is refused cleanly (device ordinal out of range), never a crash or a silent single-GPU run."""
+    r = subprocess.run([TURBO, "-arch", "gpu", "-gpus", "2", "-s", "-t", "30000", os.path.join(BENCH, "test_data", "sudoku_opt2.fzn")],
+                       capture_output=True, text=True, timeout=120)
+    from turbo_amd import capi
+    if capi.lib().tb_device_count() >= 2:
+        assert r.returncode == 0 and "objective = -2;" in r.stdout
+        assert "%%%mzn-stat: eps_stolen_subproblems=" in r.stdout
+    else:
+        assert r.returncode != 0 and "device ordinal out of range" in r.stderr
+
+
+@pytest.mark.parametrize("rel,expected", [r for r in known_answers() if r[0].split("/")[-1] in ("pat7.fzn", "sudoku_opt4.fzn", "pennies5.fzn", "bug4.fzn")])
+@pytest.mark.parametrize("fp", ["wac1", "event"])
+def test_two_ranks_on_one_device_through_the_cli(rel, expected, fp):
+    """`turbo -devices 0,0`: the C++ host's multi-GPU path (solve_sessions: link, arm, start, relay, merge) with both ranks on
+    the only GPU of the box."""
+    r = subprocess.run([TURBO, "-arch", "gpu", "-devices", "0,0", "-or", "64", "-sub", "10", "-fp", fp, "-s", "-t", "60000", os.path.join(BENCH, rel)],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    assert int(re.search(r"objective=(-?\d+)", r.stdout).group(1)) == expected
+    assert "==========" in r.stdout
+    solved = int(re.search(r"eps_solved_subproblems=(\d+)", r.stdout).group(1))
+    skipped = int(re.search(r"eps_skipped_subproblems=(\d+)", r.stdout).group(1))
+    assert solved + skipped == 1024
+    assert int(re.search(r"mzn-stat: num_blocks=(\d+)", r.stdout).group(1)) == 128

@@ -1,0 +1,237 @@
+"""Multi-GPU path on ONE GPU: two ranks (two sessions of the real engine) sharing device 0.
+
+The pool has 1-GPU boxes only, so the N > 1 path is exercised by letting both ranks of a world_size-2 search run on the
+same device -- in one process (tb_session_link_peer: the peers' cells are plain pointers) and in two processes
+(bench.py --share-device: the cells travel as IPC handles through torch.distributed/gloo).  Everything except the xGMI
+hop itself is the code that runs on 8 GPUs: block-cyclic shares, queue words, work stealing, bound import,
+stop propagation, winner selection.  Reference: barebones_dive_and_solve.hpp:409-453,718-741,877-884.
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from conftest import BENCH, ROOT, known_answers
+from oracle import pyoracle
+from turbo_amd import capi, frontend
+
+pytestmark = pytest.mark.gpu
+
+ANSWERS = dict(known_answers())
+NO_STEAL = 0x1000000
+
+
+def load(rel):
+    return frontend.load_fzn(os.path.join(BENCH, rel))
+
+
+def run_group(tcn, world=2, link=True, power=8, relay=False, per_rank=None, **kw):
+    """Create `world` sessions on device 0, wire them, run them concurrently; returns [(has, best, stats)] per rank."""
+    per_rank = per_rank or [{}] * world
+    ss = []
+    for r in range(world):
+        cfg = dict(rank=r, world_size=world, subproblems_power=power, timeout_ms=60000, or_nodes=32, snapshot_levels=4)
+        cfg.update(kw)
+        cfg.update(per_rank[r])
+        ss.append(capi.Session(tcn, capi.make_config(**cfg)))
+    if link:
+        for a in ss:
+            for b in ss:
+                if a is not b:
+                    a.link_peer(b)
+    for s in ss:
+        s.arm()
+    for s in ss:
+        s.start()
+    done = [False] * world
+    gbest = capi.TB_PINF
+    while not all(done):
+        for r, s in enumerate(ss):
+            best, done[r] = s.poll()
+            gbest = min(gbest, best)
+        if relay and gbest != capi.TB_PINF:
+            for s in ss:
+                s.push_bound(gbest)
+        time.sleep(0.0005)
+    out = [s.finish() for s in ss]
+    for s in ss:
+        s.close()
+    return out
+
+
+def merged(out, tcn):
+    """reduce_blocks across ranks: best bound, ties to the lowest subproblem index."""
+    win = None
+    for has, best, st in out:
+        if has and (win is None or (st["best_bound"], st["best_subproblem"]) < (win[1]["best_bound"], win[1]["best_subproblem"])):
+            win = (best, st)
+    tot = {k: sum(st[k] for _, _, st in out) for k in ("nodes", "eps_solved_subproblems", "eps_skipped_subproblems", "eps_stolen_subproblems", "eps_local_subproblems")}
+    return win, tot
+
+
+@pytest.mark.parametrize("fixpoint", [1, 2], ids=["wac1", "event"])
+@pytest.mark.parametrize("mode", ["linked", "linked_no_steal", "host_relay", "chunk3"])
+@pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pat7.fzn", "test_data/pennies5.fzn", "test_data/bug4.fzn"])
+def test_two_ranks_on_one_gpu_cover_the_index_space_and_find_the_optimum(rel, mode, fixpoint):
+    tcn = load(rel)
+    power = 8
+    kw = dict(fixpoint=fixpoint)
+    if mode == "linked_no_steal":
+        kw["debug"] = NO_STEAL
+    if mode == "chunk3":
+        kw["eps_chunk_log2"] = 3
+    out = run_group(tcn, link=mode != "host_relay", relay=mode == "host_relay", power=power, **kw)
+    win, tot = merged(out, tcn)
+    assert all(st["exhaustive"] == 1 for _, _, st in out)
+    # every subproblem is accounted for exactly once, solved or skipped, whichever GPU ended up with it
+    assert tot["eps_solved_subproblems"] + tot["eps_skipped_subproblems"] == 2 ** power
+    assert tot["eps_local_subproblems"] == 2 ** power
+    assert win is not None and tcn.objective_of(win[0]) == ANSWERS[rel]
+    if mode in ("linked_no_steal", "host_relay"):
+        assert tot["eps_stolen_subproblems"] == 0
+        for _, _, st in out:  # without stealing a rank handles exactly its own share
+            assert st["eps_solved_subproblems"] + st["eps_skipped_subproblems"] == st["eps_local_subproblems"]
+
+
+@pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat7.fzn", "test_data/pennies5.fzn"])
+def test_two_ranks_canonical_solution_is_the_oracles(rel):
+    """Optimum by the two-rank search, then the canonical pass (first solution under obj <= optimum, lowest subproblem wins)
+    on both ranks: the merged answer is bit-identical to the sequential oracle's."""
+    tcn = load(rel)
+    power = 8
+    win, _ = merged(run_group(tcn, power=power), tcn)
+    opt = win[1]["best_bound"]
+    out = run_group(tcn, power=power, use_fixed_bound=1, fixed_bound=opt)
+    win2, _ = merged(out, tcn)
+    _, _, st_b = pyoracle.solve(tcn, subproblems_power=power)
+    assert st_b["best_bound"] == opt
+    has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power, fixed_bound=opt)
+    assert has_o and win2 is not None
+    assert win2[1]["best_subproblem"] == st_o["best_subproblem"]
+    np.testing.assert_array_equal(win2[0], best_o)
+
+
+def test_an_idle_gpu_takes_work_from_the_busy_one():
+    """Rank 0 has one workgroup, rank 1 has 64: rank 1 finishes its share and takes over most of rank 0's."""
+    tcn = load("test_data/pat7.fzn")
+    power = 10
+    out = run_group(tcn, power=power, per_rank=[dict(or_nodes=1), dict(or_nodes=64)])
+    win, tot = merged(out, tcn)
+    assert tcn.objective_of(win[0]) == ANSWERS["test_data/pat7.fzn"]
+    assert tot["eps_solved_subproblems"] + tot["eps_skipped_subproblems"] == 2 ** power
+    st0, st1 = out[0][2], out[1][2]
+    assert st1["eps_stolen_subproblems"] > 0 and st0["eps_stolen_subproblems"] <= st1["eps_stolen_subproblems"]
+    assert st1["eps_solved_subproblems"] + st1["eps_skipped_subproblems"] > st1["eps_local_subproblems"]
+
+
+def test_a_foreign_incumbent_prunes_the_search():
+    """Host relay: rank 0 of 2 alone, with and without the optimum pushed as a foreign bound before the kernel starts.
+    The import goes Mailbox -> first poll -> Ctrl::foreign_bound -> `obj <= bound - 1` at every node."""
+    rel = "test_data/pat7.fzn"
+    tcn = load(rel)
+    nodes = []
+    for push in (False, True):
+        s = capi.Session(tcn, capi.make_config(rank=0, world_size=2, subproblems_power=6, or_nodes=8, timeout_ms=60000, snapshot_levels=4, debug=NO_STEAL))
+        s.arm()
+        if push:
+            s.push_bound(ANSWERS[rel])
+        s.start()
+        while not s.poll()[1]:
+            time.sleep(0.001)
+        has, best, st = s.finish()
+        s.close()
+        assert st["exhaustive"] == 1
+        if push:
+            assert not has or tcn.objective_of(best) > ANSWERS[rel] or st["best_bound"] >= ANSWERS[rel]
+        nodes.append(st["nodes"])
+    assert nodes[1] < nodes[0], nodes
+
+
+def test_a_peer_incumbent_arrives_through_the_cell():
+    """Linked sessions, no stealing: rank 1 runs first and leaves its incumbent in rank 0's cell (the xGMI atomicMin);
+    rank 0, started afterwards without re-arming, explores fewer nodes than when it runs unlinked."""
+    rel = "test_data/pat7.fzn"
+    tcn = load(rel)
+
+    def make(rank):
+        return capi.Session(tcn, capi.make_config(rank=rank, world_size=2, subproblems_power=6, or_nodes=8, timeout_ms=60000, snapshot_levels=4, debug=NO_STEAL))
+
+    def run(s):
+        s.start()
+        while not s.poll()[1]:
+            time.sleep(0.001)
+        return s.finish()
+
+    alone = make(0)
+    _, _, st_alone = run(alone)
+    alone.close()
+    a, b = make(0), make(1)
+    a.link_peer(b); b.link_peer(a)
+    a.arm(); b.arm()
+    has_b, best_b, st_b = run(b)
+    has_a, best_a, st_a = run(a)  # armed above: the cell still holds what rank 1 wrote into it
+    a.close(); b.close()
+    assert st_a["exhaustive"] == 1 and st_b["exhaustive"] == 1
+    bounds = [st["best_bound"] for has, st in ((has_a, st_a), (has_b, st_b)) if has]
+    assert min(bounds) == ANSWERS[rel]
+    assert has_b, "rank 1's share of pat7 holds solutions (otherwise this test checks nothing)"
+    assert st_a["nodes"] < st_alone["nodes"], (st_a["nodes"], st_alone["nodes"])
+
+
+def test_solution_limit_stops_every_gpu():
+    """-n k on a satisfaction problem: the workgroup that reaches the limit stops its own device and raises the peers' stop word."""
+    tcn = frontend.Model.from_string(
+        "var 1..9: a; var 1..9: b; var 1..9: c; var 1..9: d; constraint int_lin_le([1,1,1,1],[a,b,c,d],30); solve satisfy;").tcn()
+    out = run_group(tcn, power=6, stop_after_n_solutions=5, per_rank=[dict(or_nodes=4), dict(or_nodes=4)])
+    total = sum(st["solutions"] for _, _, st in out)
+    assert total >= 5
+    assert any(st["exhaustive"] == 0 for _, _, st in out)
+    assert total < 6000  # 9^4 = 6561 assignments, all but a few are solutions: the search was cut short on both ranks
+
+
+def test_trains15_sharded_with_a_node_budget():
+    """BASELINE.json configs[3] in its 2-rank-on-1-GPU form: trains15 dealt to two ranks, a node budget for the whole node
+    (counted in rank 0's cell), the incumbent shared through the cells."""
+    from turbo_amd import preprocess
+    _, tcn, _ = preprocess.load_fzn_simplified(os.path.join(BENCH, "trains15.fzn"))
+    budget = 40000
+    out = run_group(tcn, power=12, fixpoint=2, stop_after_n_nodes_total=budget, per_rank=[dict(or_nodes=128), dict(or_nodes=128)], snapshot_levels=8)
+    nodes = sum(st["nodes"] for _, _, st in out)
+    assert budget <= nodes <= budget + 2 * 128 * 64 + 256 * 40  # batches of 32 per workgroup + the nodes in flight when the stop lands
+    assert all(st["exhaustive"] == 0 for _, _, st in out)
+    for has, best, st in out:
+        assert st["nodes"] > 0
+        if has:  # whatever was found satisfies the network
+            _, failed, ent, _, _ = pyoracle.propagate(best, tcn.props)
+            assert not failed and ent
+
+
+def test_linking_sessions_with_different_plans_is_refused():
+    tcn = load("test_data/pat2.fzn")
+    a = capi.Session(tcn, capi.make_config(rank=0, world_size=2, subproblems_power=6, or_nodes=4, snapshot_levels=2))
+    b = capi.Session(tcn, capi.make_config(rank=1, world_size=2, subproblems_power=7, or_nodes=4, snapshot_levels=2))
+    with pytest.raises(capi.TurboHipError):
+        a.link_peer(b)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("exchange", ["peer", "host"])
+def test_two_processes_share_one_gpu_through_bench(exchange, tmp_path):
+    """bench.py as the driver launches it for N = 2, with both ranks on cuda:0 and gloo as the rendezvous: the cells are
+    exchanged as IPC handles between the two processes."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--share-device", "--dist-backend", "gloo",
+           "--workload", "accap_a3", "--or-nodes", "256", "--nodes-total", "200000", "--no-cpu-baseline", "--exchange", exchange, "--side-steps", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["value"] > 0
+    assert rec["multi_gpu"]["exchange"] == ("peer cells over xGMI" if exchange == "peer" else "host relay")
+    assert len(rec["multi_gpu"]["per_rank"]) == 2
+    assert all(r["nodes"] > 0 for r in rec["multi_gpu"]["per_rank"])

@@ -21,20 +21,25 @@ MEM_KINDS = ["global", "store_shared", "tcn_shared"]
 TIMERS = ["OVERALL", "PREPROCESSING", "SEARCH", "FIXPOINT", "TRANSFER_CPU2GPU", "TRANSFER_GPU2CPU",
           "SELECT_FP_FUNCTIONS", "WAIT_CPU", "DIVE", "LATEST_BEST_OBJ_FOUND", "FIRST_BLOCK_IDLE"]
 
-EXPORTS = ["tb_version", "tb_last_error", "tb_device_count", "tb_get_device_info", "tb_eps_slice", "tb_propagate", "tb_solve",
+EXPORTS = ["tb_version", "tb_last_error", "tb_device_count", "tb_get_device_info", "tb_eps_local_count", "tb_eps_global_index",
+           "tb_propagate", "tb_solve",
            "tb_session_create", "tb_session_start", "tb_session_poll", "tb_session_push_bound",
-           "tb_session_stop", "tb_session_next_solution", "tb_session_finish", "tb_session_destroy"]
+           "tb_session_stop", "tb_session_next_solution", "tb_session_finish", "tb_session_destroy",
+           "tb_session_export_peer", "tb_session_import_peer", "tb_session_link_peer", "tb_session_arm",
+           "tb_session_progress", "tb_session_debug_last_store", "tb_session_plan"]
 
 
 class TbConfig(C.Structure):
     _fields_ = [("timeout_ms", C.c_uint64), ("or_nodes", C.c_uint64), ("subproblems_factor", C.c_uint64),
                 ("stop_after_n_nodes", C.c_uint64), ("stop_after_n_solutions", C.c_uint64),
-                ("wac1_threshold", C.c_uint64),
+                ("wac1_threshold", C.c_uint64), ("stop_after_n_nodes_total", C.c_uint64),
                 ("subproblems_power", C.c_int32), ("fixpoint", C.c_int32), ("only_global_memory", C.c_int32),
                 ("verbose", C.c_int32), ("has_eps_strategy", C.c_int32), ("threads_per_block", C.c_int32),
                 ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
                 ("use_fixed_bound", C.c_int32), ("fixed_bound", C.c_int32), ("deterministic", C.c_int32),
-                ("snapshot_levels", C.c_int32), ("stream_solutions", C.c_int32), ("entailed_prop_removal", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("snapshot_levels", C.c_int32), ("stream_solutions", C.c_int32), ("entailed_prop_removal", C.c_int32),
+                ("eps_chunk_log2", C.c_int32), ("decision_stack_depth", C.c_int32), ("poll_period_us", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 class TbStats(C.Structure):
@@ -47,7 +52,9 @@ class TbStats(C.Structure):
                 ("depth_max", C.c_int32), ("num_blocks", C.c_int32), ("threads_per_block", C.c_int32),
                 ("exhaustive", C.c_int32), ("mem_kind", C.c_int32), ("shared_bytes", C.c_int32),
                 ("subproblems_power", C.c_int32), ("best_bound", C.c_int32), ("best_subproblem", C.c_int32),
-                ("interrupted", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("interrupted", C.c_int32), ("reserved", C.c_int32 * 2),
+                ("eps_local_subproblems", C.c_uint64), ("eps_stolen_subproblems", C.c_uint64), ("wait_time_ns", C.c_int64),
+                ("min_block_ns", C.c_int64), ("max_block_ns", C.c_int64)]
 
     def as_dict(self) -> dict:
         d = {}
@@ -58,6 +65,12 @@ class TbStats(C.Structure):
             v = getattr(self, k)
             d[k] = list(v) if hasattr(v, "__len__") else v
         return d
+
+
+class TbPlan(C.Structure):
+    _fields_ = [("num_blocks", C.c_int32), ("threads_per_block", C.c_int32), ("mem_kind", C.c_int32), ("shared_bytes", C.c_int32),
+                ("subproblems_power", C.c_int32), ("eps_chunk_log2", C.c_int32), ("snapshot_levels", C.c_int32),
+                ("decision_stack_depth", C.c_int32), ("eps_local_subproblems", C.c_uint64)]
 
 
 class TbDeviceInfo(C.Structure):
@@ -87,8 +100,10 @@ def lib() -> C.CDLL:
         L.tb_device_count.restype = C.c_int
         L.tb_get_device_info.restype = C.c_int
         L.tb_get_device_info.argtypes = [C.c_int, C.POINTER(TbDeviceInfo)]
-        L.tb_eps_slice.restype = C.c_int
-        L.tb_eps_slice.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.tb_eps_local_count.restype = C.c_int
+        L.tb_eps_local_count.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
+        L.tb_eps_global_index.restype = C.c_int
+        L.tb_eps_global_index.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64)]
         L.tb_propagate.restype = C.c_int
         L.tb_propagate.argtypes = [C.POINTER(TbConfig), C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
@@ -98,7 +113,19 @@ def lib() -> C.CDLL:
         L.tb_solve.argtypes = net + [C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32), C.POINTER(TbStats)]
         L.tb_session_create.restype = C.c_int
         L.tb_session_create.argtypes = net + [C.POINTER(C.c_void_p)]
-        for name in ("tb_session_start", "tb_session_stop"):
+        L.tb_session_plan.restype = C.c_int
+        L.tb_session_plan.argtypes = [C.c_void_p, C.POINTER(TbPlan)]
+        L.tb_session_export_peer.restype = C.c_int
+        L.tb_session_export_peer.argtypes = [C.c_void_p, C.c_void_p]
+        L.tb_session_import_peer.restype = C.c_int
+        L.tb_session_import_peer.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.tb_session_link_peer.restype = C.c_int
+        L.tb_session_link_peer.argtypes = [C.c_void_p, C.c_void_p]
+        L.tb_session_progress.restype = C.c_int
+        L.tb_session_progress.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.tb_session_debug_last_store.restype = C.c_int
+        L.tb_session_debug_last_store.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        for name in ("tb_session_start", "tb_session_stop", "tb_session_arm"):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [C.c_void_p]
         L.tb_session_poll.restype = C.c_int
@@ -143,10 +170,18 @@ def device_info(device: int = 0) -> dict:
     return {k: (getattr(info, k).decode() if k == "name" else getattr(info, k)) for k, _ in info._fields_}
 
 
-def eps_slice(subproblems_power: int, rank: int, world_size: int):
-    lo, hi = C.c_uint64(0), C.c_uint64(0)
-    check(lib().tb_eps_slice(subproblems_power, rank, world_size, C.byref(lo), C.byref(hi)))
-    return lo.value, hi.value
+def eps_local_count(subproblems_power: int, chunk_log2: int, rank: int, world_size: int) -> int:
+    """Size of `rank`'s block-cyclic share of the 2^d subproblems."""
+    n = C.c_uint64(0)
+    check(lib().tb_eps_local_count(subproblems_power, chunk_log2, rank, world_size, C.byref(n)))
+    return n.value
+
+
+def eps_global_index(subproblems_power: int, chunk_log2: int, rank: int, world_size: int, j: int) -> int:
+    """Global index of the j-th subproblem of `rank`."""
+    g = C.c_uint64(0)
+    check(lib().tb_eps_global_index(subproblems_power, chunk_log2, rank, world_size, j, C.byref(g)))
+    return g.value
 
 
 def _net_args(tcn):
@@ -207,6 +242,41 @@ class Session:
 
     def start(self) -> None:
         check(lib().tb_session_start(self._h))
+
+    def plan(self) -> dict:
+        """Grid, memory kind and 2^d chosen by tb_session_create."""
+        pl = TbPlan()
+        check(lib().tb_session_plan(self._h, C.byref(pl)))
+        return {k: getattr(pl, k) for k, _ in pl._fields_}
+
+    def arm(self) -> None:
+        """Reset the device-side state of a search (linked sessions: every rank arms, all synchronise, every rank starts)."""
+        check(lib().tb_session_arm(self._h))
+
+    def export_peer(self) -> bytes:
+        """64-byte IPC handle of this session's cell (for tb_session_import_peer in another process)."""
+        buf = C.create_string_buffer(64)
+        check(lib().tb_session_export_peer(self._h, buf))
+        return buf.raw
+
+    def import_peer(self, peer_rank: int, handle: bytes) -> None:
+        buf = C.create_string_buffer(bytes(handle), 64)
+        check(lib().tb_session_import_peer(self._h, int(peer_rank), buf))
+
+    def link_peer(self, other: "Session") -> None:
+        """Same process: let this session's kernel reach `other`'s cell (call it in both directions)."""
+        check(lib().tb_session_link_peer(self._h, other._h))
+
+    def progress(self, counters: bool = False):
+        """Remaining subproblems of this GPU as of the kernel's last poll (and, with counters, stolen in / out so far)."""
+        rem, si, so = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib().tb_session_progress(self._h, C.byref(rem), C.byref(si) if counters else None, C.byref(so) if counters else None))
+        return (rem.value, si.value, so.value) if counters else rem.value
+
+    def debug_last_store(self, workgroup: int = 0):
+        out = np.zeros(max(self._n_vars, 1), dtype=ITV_DTYPE)
+        check(lib().tb_session_debug_last_store(self._h, workgroup, out.ctypes.data))
+        return out[:self._n_vars]
 
     def poll(self):
         best, done = C.c_int32(0), C.c_int32(0)

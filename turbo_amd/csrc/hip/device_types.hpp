@@ -16,19 +16,73 @@ struct Decision {
   int rope[2];    // O(1) backtracking: depth to jump to after each child (barebones:388-393)
 };
 
-// Grid-level words shared by every workgroup (barebones GridData, :409-453): the only inter-workgroup state.
-struct Ctrl {
-  unsigned long long next_subproblem;  // work queue over the EPS index space (barebones:418)
-  unsigned long long first_sol_idx;    // canonical pass: lowest subproblem index holding a solution
+// Grid-level words shared by every workgroup of ONE device (barebones GridData, :409-453), plain device memory touched
+// with agent-scope atomics only.  The first 16 bytes are what thread 0 of every workgroup reads at every node: one load.
+struct alignas(16) Ctrl {
   int best_bound;                      // appx_best_bound (barebones:426), monotone min
-  int foreign_bound;                   // incumbent imported from other GPUs (host writes it)
-  int stop;                            // host stop request (UnifiedData::stop, barebones:64)
-  int gpu_stop;                        // raised by a workgroup (solution limit reached / unbounded objective)
-  int blocks_done;                     // number of workgroups that left the kernel
-  int error;                           // device-side error code (decision stack overflow ...)
+  int foreign_bound;                   // incumbent imported from other GPUs (peers' cells / the host mailbox)
+  int stop;                            // bit 0: host stop request (UnifiedData::stop, barebones:64); bit 1: raised by a workgroup
+                                       // (solution limit reached / unbounded objective), on this or on a peer device
+  unsigned next_poll;                  // low 32 bits of the wall-clock tick at which the mailbox / peer cell is polled next
+  unsigned long long first_sol_idx;    // canonical pass: lowest subproblem index holding a solution
   unsigned long long solutions;        // satisfaction: global solution counter for -n
   unsigned long long sol_ticket;       // streaming: next sequence number of the solution ring
+  int blocks_done;                     // number of workgroups that left the kernel
+  int error;                           // device-side error code (1: decision stack overflow)
 };
+constexpr int STOP_HOST = 1, STOP_GPU = 2;
+
+// One contiguous run of LOCAL subproblem indices of rank `owner` (see eps_global_index below).
+struct QueueDesc {
+  unsigned long long j_base;
+  int owner, pad;
+};
+
+// The only state another GPU touches (barebones GridData::next_subproblem + appx_best_bound, :418,426, made
+// multi-device): one cell per session in FINE-GRAINED device memory, mapped by every peer of the node (same process:
+// hipDeviceEnablePeerAccess; other processes: hipIpcOpenMemHandle), accessed with system-scope atomics over xGMI.
+//   queue  = gen:8 | next:28 | hi:28 -- the work queue over desc[gen & 7]: a fetch is one atomicAdd of 1 << 28, a thief
+//            lowers `hi` with a CAS, the owner installs a new range (stolen from a peer) by bumping gen.
+//   bound  = incumbent found by the peers: they atomicMin into it; the local poller folds it into Ctrl::foreign_bound.
+struct alignas(64) PeerCell {
+  unsigned long long queue;
+  int bound;
+  int stealing;   // 1 while a workgroup of this device moves a range from a peer into `queue`
+  int stop;       // a peer reached the solution limit / proved the objective unbounded
+  int waiting;    // workgroups of this device currently waiting for work (diagnostic)
+  unsigned long long stolen_in, stolen_out;  // subproblems moved into / out of this device (diagnostic)
+  unsigned long long nodes_total;            // rank 0's cell only: nodes explored by all GPUs (tb_config.stop_after_n_nodes_total)
+  unsigned long long pad[2];
+  QueueDesc desc[8];
+};
+constexpr int Q_BITS = 28;
+constexpr unsigned long long Q_MASK = (1ull << Q_BITS) - 1ull;
+__host__ __device__ inline unsigned long long q_pack(unsigned gen, unsigned long long next, unsigned long long hi) {
+  return ((unsigned long long)(gen & 0xffu) << (2 * Q_BITS)) | ((next & Q_MASK) << Q_BITS) | (hi & Q_MASK);
+}
+__host__ __device__ inline unsigned q_gen(unsigned long long w) { return (unsigned)(w >> (2 * Q_BITS)) & 0xffu; }
+__host__ __device__ inline unsigned long long q_next(unsigned long long w) { return (w >> Q_BITS) & Q_MASK; }
+__host__ __device__ inline unsigned long long q_hi(unsigned long long w) { return w & Q_MASK; }
+
+// EPS index space across GPUs: block-cyclic.  The 2^d subproblems are cut into chunks of 2^k consecutive indices;
+// rank g of G owns the chunks c with c % G == g and numbers its own subproblems j = 0, 1, ... in index order.
+// (G = 1: j is the global index.)  Static, needs no communication, and statistically balanced because neighbouring
+// subproblems -- which share most of their dive path and tend to be equally hard -- go to different GPUs.
+__host__ __device__ inline unsigned long long eps_global_index(unsigned long long j, int k, int g, int G) {
+  return G == 1 ? j : ((((j >> k) * (unsigned long long)G + (unsigned long long)g) << k) | (j & ((1ull << k) - 1ull)));
+}
+// smallest local index of rank g whose global index is >= t
+__host__ __device__ inline unsigned long long eps_local_lower_bound(unsigned long long t, int k, int g, int G) {
+  if (G == 1) return t;
+  const unsigned long long c = t >> k, m = c % (unsigned long long)G;
+  const unsigned long long d = ((unsigned long long)g + (unsigned long long)G - m) % (unsigned long long)G;
+  if (d == 0) return (((c / (unsigned long long)G)) << k) | (t & ((1ull << k) - 1ull));
+  return ((c + d) / (unsigned long long)G) << k;
+}
+// number of subproblems of rank g (d = subproblems_power)
+__host__ __device__ inline unsigned long long eps_local_count(int d, int k, int g, int G) {
+  return eps_local_lower_bound(1ull << d, k, g, G);
+}
 
 // Solution ring in pinned host memory (streaming, gpu_dive_and_solve.hpp:100-132 re-done without a print lock):
 // a producer takes a ticket, waits until `ticket - consumed < slots`, copies its store into slot ticket % slots and
@@ -44,8 +98,10 @@ struct SolutionRing {
 struct BlockStats {
   unsigned long long nodes, fails, solutions, fixpoint_iterations, num_deductions;
   unsigned long long eps_solved, eps_skipped, store_writes;
+  unsigned long long stolen;        // subproblems this workgroup took from other GPUs' queues
   long long timers[TB_NUM_TIMERS];  // wall-clock ticks
   long long best_time;              // tick at which the best solution was found
+  long long wait_ticks;             // time spent without a subproblem (waiting for / looking for work on other GPUs)
   int depth_max, exhaustive, num_blocks_done, best_bound;
   long long best_sub;               // subproblem index that produced best_store (-1: none)
   int why, pad_why;                 // debugging: reasons that cleared `exhaustive` (bit mask)
@@ -78,17 +134,24 @@ struct DevProblem {
   int debug;               // ablation knobs for profiling (tb_config.reserved[0]); 0 in production
   int snapshot_levels;     // >= 1
   int max_depth;           // capacity of the decision stack
-  unsigned long long sub_lo, sub_hi;  // this device's slice of the EPS index space
+  int rank, world;         // this device among the GPUs of the search
+  int chunk_log2;          // k of the block-cyclic partition
+  int poll_ticks;          // wall-clock ticks between two polls of the mailbox / peer cell
+  int steal;               // 1: a device whose queue is empty takes work from its peers (0: tb_config.reserved[0] & 0x1000000, A/B runs and tests)
   unsigned long long cut_nodes;       // 0 = none
+  unsigned long long cut_nodes_total; // 0 = none: budget of all workgroups of all GPUs together
   unsigned long long stop_after_n_solutions;
   long long deadline_ticks;           // watchdog (wall_clock64 units); 0 = none
   // per-workgroup buffers in HBM
   int2* g_store;     // [B][V]  working store (GLOBAL mode only)
   int2* g_snap;      // [B][L][V] snapshot stack
   int2* g_best;      // [B][V]
+  int2* g_last;      // [B][V] test aid (tb_config.reserved[0] & 0x800000): the store of each workgroup when it left the kernel
   Decision* g_dec;   // [B][max_depth]
   BlockStats* g_stats;
   Ctrl* ctrl;
+  PeerCell* cell;            // this device's cell
+  PeerCell* const* peers;    // [world] cells of every rank (peers[rank] == cell; nullptr = not reachable), device array
   SolutionRing ring;
 };
 

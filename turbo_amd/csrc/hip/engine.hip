@@ -205,14 +205,19 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     while (d < 40 && (1ull << d) < target) ++d;
     p.subproblems_power = d;
   }
-  if (p.subproblems_power > 62) return fail(TB_ERR_INVALID, "subproblems_power must be <= 62");
+  {
+    // a GPU's share of the index space is served through a 28-bit queue word (device_types.hpp: PeerCell::queue)
+    const int world = std::max(1, cfg.world_size);
+    if (p.subproblems_power > 40 || eps_local_count(p.subproblems_power, 0, 0, world) > Q_MASK - (1ull << 16))
+      return fail(TB_ERR_INVALID, "subproblems_power is too large: at most 2^28 - 65536 subproblems per GPU");
+  }
   // snapshot stack: as deep as 1/4 of the free HBM allows (288 GB per GPU makes copying cheaper than
   // recomputing from the subproblem root)
-  p.max_depth = 16384;
+  p.max_depth = cfg.decision_stack_depth > 0 ? std::max(16, cfg.decision_stack_depth) : 16384;
   int L = cfg.snapshot_levels;
   if (L <= 0) {
     const size_t per_level = (size_t)p.num_blocks * (size_t)std::max(1, vext) * 8;
-    size_t budget = caps.free_mem / 4;
+    size_t budget = caps.free_mem / 4;  // of what is free NOW: a second session on the same device sizes itself on what the first left
     L = (int)std::min<size_t>(256, std::max<size_t>(1, budget / std::max<size_t>(1, per_level)));
   }
   p.snapshot_levels = std::max(1, std::min(L, p.max_depth));
@@ -417,6 +422,15 @@ struct DevBuffers {
   }
 };
 
+// device wall clock "now" (the in-kernel watchdogs compare against it)
+int device_now(hipStream_t stream, long long* d_now, long long* now_out) {
+  clock_kernel<<<1, 1, 0, stream>>>(d_now);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(stream));
+  HIP_TRY(hipMemcpy(now_out, d_now, sizeof(long long), hipMemcpyDeviceToHost));
+  return TB_OK;
+}
+
 }  // namespace
 
 // ---- session -------------------------------------------------------------------------------------
@@ -437,7 +451,14 @@ struct tb_session {
   hipStream_t stream = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int32_t n_vars = 0, obj_var = -1;
-  bool started = false, finished = false;
+  bool started = false, finished = false, armed = false;
+  // multi-GPU: this session's cell (fine-grained device memory) and the cells of the other ranks as this device sees them
+  PeerCell* cell = nullptr;
+  bool cell_fine_grained = false;
+  std::vector<PeerCell*> peer_cells;   // [world]; [rank] = cell; nullptr = not linked
+  std::vector<void*> ipc_mapped;       // hipIpcOpenMemHandle mappings to close
+  PeerCell** d_peers = nullptr;        // device copy of peer_cells
+  unsigned long long local_count = 0;  // size of this rank's share of the index space
   int host_best = TB_PINF;
   long long* d_now = nullptr;
   std::chrono::steady_clock::time_point t_start;
@@ -445,6 +466,8 @@ struct tb_session {
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (ev_stop) (void)hipEventDestroy(ev_stop);
     if (stream) (void)hipStreamDestroy(stream);
+    for (void* m : ipc_mapped) (void)hipIpcCloseMemHandle(m);
+    if (cell) (void)hipFree(cell);
     if (mbox_host) (void)hipHostFree(mbox_host);
     if (ring_host) (void)hipHostFree(ring_host);
   }
@@ -483,12 +506,19 @@ int tb_get_device_info(int device, tb_device_info* out) {
   return TB_OK;
 }
 
-int tb_eps_slice(int32_t subproblems_power, int32_t rank, int32_t world_size, uint64_t* lo_out, uint64_t* hi_out) {
-  if (subproblems_power < 0 || subproblems_power > 62 || world_size < 1 || rank < 0 || rank >= world_size || !lo_out || !hi_out)
-    return fail(TB_ERR_INVALID, "bad slice arguments");
-  const unsigned long long nsub = 1ull << subproblems_power;
-  *lo_out = (uint64_t)(((unsigned __int128)nsub * (unsigned long long)rank) / (unsigned long long)world_size);
-  *hi_out = (uint64_t)(((unsigned __int128)nsub * ((unsigned long long)rank + 1)) / (unsigned long long)world_size);
+int tb_eps_local_count(int32_t subproblems_power, int32_t chunk_log2, int32_t rank, int32_t world_size, uint64_t* count_out) {
+  if (subproblems_power < 0 || subproblems_power > 62 || chunk_log2 < 0 || world_size < 1 || rank < 0 || rank >= world_size || !count_out)
+    return fail(TB_ERR_INVALID, "bad partition arguments");
+  *count_out = eps_local_count(subproblems_power, std::min(chunk_log2, subproblems_power), rank, world_size);
+  return TB_OK;
+}
+
+int tb_eps_global_index(int32_t subproblems_power, int32_t chunk_log2, int32_t rank, int32_t world_size, uint64_t j, uint64_t* index_out) {
+  uint64_t n = 0;
+  int rc = tb_eps_local_count(subproblems_power, chunk_log2, rank, world_size, &n);
+  if (rc != TB_OK) return rc;
+  if (!index_out || j >= n) return fail(TB_ERR_INVALID, "local subproblem index out of range");
+  *index_out = eps_global_index(j, std::min(chunk_log2, subproblems_power), rank, world_size);
   return TB_OK;
 }
 
@@ -550,6 +580,13 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   P.deadline_ticks = 0;
+  if (cfg.timeout_ms != 0) {  // same watchdog as the search kernel: a slowly converging network must not outlive -t
+    long long* d_now = nullptr;
+    long long now = 0;
+    if ((rc = bufs.alloc(&d_now, 1)) != TB_OK) return rc;
+    if ((rc = device_now(stream, d_now, &now)) != TB_OK) return rc;
+    P.deadline_ticks = now + (long long)cfg.timeout_ms * (long long)caps.wall_khz;
+  }
   const int grid = std::min(n_stores, plan.num_blocks);
   HIP_TRY(hipEventRecord(e0, stream));
   DISPATCH_KERNEL(propagate_kernel, plan.mem_kind, plan.tmax, event, compact, <<<dim3(grid), dim3(plan.threads), plan.shared_bytes, stream>>>(P, d_stores, d_out, n_stores));
@@ -683,16 +720,37 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   P.has_eps_strategy = s->cfg.has_eps_strategy;
   P.use_fixed_bound = s->cfg.use_fixed_bound; P.fixed_bound = s->cfg.fixed_bound;
   P.mem_kind = plan.mem_kind; P.snapshot_levels = plan.snapshot_levels; P.max_depth = plan.max_depth; P.debug = s->cfg.reserved[0];
-  const unsigned long long world = (unsigned long long)std::max(1, s->cfg.world_size), rank = (unsigned long long)std::max(0, s->cfg.rank);
-  // contiguous slices keep the subtree skip `((idx >> r) + 1) << r` local to a GPU (clamped at the slice end)
-  uint64_t lo = 0, hi = 0;
-  if ((rc = tb_eps_slice(plan.subproblems_power, (int32_t)rank, (int32_t)world, &lo, &hi)) != TB_OK) return rc;
-  P.sub_lo = lo; P.sub_hi = hi;
+  // this rank's block-cyclic share of the 2^d subproblems (device_types.hpp: eps_global_index)
+  P.world = std::max(1, s->cfg.world_size); P.rank = P.world > 1 ? s->cfg.rank : 0;
+  P.chunk_log2 = std::max(0, std::min(s->cfg.eps_chunk_log2, plan.subproblems_power));
+  s->local_count = eps_local_count(plan.subproblems_power, P.chunk_log2, P.rank, P.world);
+  P.poll_ticks = (int)std::min<long long>(0x3fffffff, (long long)(s->cfg.poll_period_us > 0 ? s->cfg.poll_period_us : 100) * (long long)s->caps.wall_khz / 1000);
+  if (P.poll_ticks < 1) P.poll_ticks = 1;
+  P.steal = (s->cfg.reserved[0] & 0x1000000) ? 0 : 1;
+  // the cell other GPUs reach over xGMI: fine-grained device memory (coherent at system scope while kernels run)
+  {
+    void* c = nullptr;
+    if (hipExtMallocWithFlags(&c, sizeof(PeerCell), hipDeviceMallocFinegrained) == hipSuccess) s->cell_fine_grained = true;
+    else {
+      (void)hipGetLastError();
+      if (P.world > 1 && s->cfg.verbose) std::fprintf(stderr, "%% fine-grained device memory is not available: GPUs exchange through the host only\n");
+      HIP_TRY(hipMalloc(&c, sizeof(PeerCell)));
+    }
+    s->cell = static_cast<PeerCell*>(c);
+    HIP_TRY(hipMemset(s->cell, 0, sizeof(PeerCell)));
+    s->peer_cells.assign((size_t)P.world, nullptr);
+    s->peer_cells[(size_t)P.rank] = s->cell;
+    if ((rc = s->bufs.alloc(&s->d_peers, (size_t)P.world)) != TB_OK) return rc;
+    P.cell = s->cell; P.peers = nullptr;  // set at arm time, when some peer is linked
+  }
+  if (s->cfg.reserved[0] & 0x800000) { if ((rc = s->bufs.alloc(&P.g_last, B * VX)) != TB_OK) return rc; }
   P.cut_nodes = s->cfg.stop_after_n_nodes;
+  P.cut_nodes_total = s->cfg.stop_after_n_nodes_total;
   P.stop_after_n_solutions = s->cfg.stop_after_n_solutions;
 
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->mbox_host), sizeof(Mailbox), hipHostMallocMapped));
-  s->mbox_host->stop = 0; s->mbox_host->foreign_bound = TB_PINF; s->mbox_host->local_best = TB_PINF; s->mbox_host->pad = 0;
+  std::memset(s->mbox_host, 0, sizeof(Mailbox));
+  s->mbox_host->foreign_bound = TB_PINF; s->mbox_host->local_best = TB_PINF;
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->mbox_dev), s->mbox_host, 0));
   if (s->cfg.stream_solutions && !s->cfg.use_fixed_bound) {
     s->ring_slots = 8;
@@ -713,33 +771,109 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   return TB_OK;
 }
 
-int tb_session_start(tb_session* s) {
+int tb_session_plan(tb_session* s, tb_plan* plan_out) {
+  if (!s || !plan_out) return fail(TB_ERR_INVALID, "null argument");
+  plan_out->num_blocks = s->plan.num_blocks; plan_out->threads_per_block = s->plan.threads;
+  plan_out->mem_kind = s->plan.mem_kind; plan_out->shared_bytes = s->plan.shared_bytes;
+  plan_out->subproblems_power = s->plan.subproblems_power; plan_out->eps_chunk_log2 = s->P.chunk_log2;
+  plan_out->snapshot_levels = s->plan.snapshot_levels; plan_out->decision_stack_depth = s->plan.max_depth;
+  plan_out->eps_local_subproblems = s->local_count;
+  return TB_OK;
+}
+
+int tb_session_export_peer(tb_session* s, tb_peer_handle* handle_out) {
+  if (!s || !handle_out) return fail(TB_ERR_INVALID, "null argument");
+  static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(tb_peer_handle), "tb_peer_handle is too small for hipIpcMemHandle_t");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, s->cell));
+  std::memset(handle_out, 0, sizeof(*handle_out));
+  std::memcpy(handle_out->bytes, &h, sizeof(h));
+  return TB_OK;
+}
+
+int tb_session_import_peer(tb_session* s, int32_t peer_rank, const tb_peer_handle* handle) {
+  if (!s || !handle) return fail(TB_ERR_INVALID, "null argument");
+  if (s->started && !s->finished) return fail(TB_ERR_STATE, "session is running");
+  if (peer_rank < 0 || peer_rank >= s->P.world || peer_rank == s->P.rank) return fail(TB_ERR_INVALID, "peer rank out of range");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle->bytes, sizeof(h));
+  void* p = nullptr;
+  HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  s->ipc_mapped.push_back(p);
+  s->peer_cells[(size_t)peer_rank] = static_cast<PeerCell*>(p);
+  s->armed = false;
+  return TB_OK;
+}
+
+int tb_session_link_peer(tb_session* s, tb_session* peer) {
+  if (!s || !peer || s == peer) return fail(TB_ERR_INVALID, "null or identical sessions");
+  if (s->started && !s->finished) return fail(TB_ERR_STATE, "session is running");
+  if (peer->P.world != s->P.world || peer->P.rank == s->P.rank) return fail(TB_ERR_INVALID, "the sessions do not belong to the same group");
+  if (peer->plan.subproblems_power != s->plan.subproblems_power || peer->P.chunk_log2 != s->P.chunk_log2)
+    return fail(TB_ERR_INVALID, "the sessions were planned with different subproblem counts: pass the same subproblems_power to every rank");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  if (peer->cfg.device != s->cfg.device) {
+    int can = 0;
+    HIP_TRY(hipDeviceCanAccessPeer(&can, s->cfg.device, peer->cfg.device));
+    if (!can) return fail(TB_ERR_HIP, "device " + std::to_string(s->cfg.device) + " cannot access device " + std::to_string(peer->cfg.device) + " (no xGMI / PCIe peer path)");
+    const hipError_t e = hipDeviceEnablePeerAccess(peer->cfg.device, 0);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(TB_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+    (void)hipGetLastError();
+  }
+  s->peer_cells[(size_t)peer->P.rank] = peer->cell;
+  s->armed = false;
+  return TB_OK;
+}
+
+// Device-side state of one search: queue = this rank's whole share, no incumbent, counters at zero.
+int tb_session_arm(tb_session* s) {
   if (!s) return fail(TB_ERR_INVALID, "null session");
   if (s->started && !s->finished) return fail(TB_ERR_STATE, "session is running");
   HIP_TRY(hipSetDevice(s->cfg.device));
-  // (re)start: a finished session can be started again on the same resident inputs
-  s->finished = false;
   s->host_best = TB_PINF;
-  s->mbox_host->stop = 0; s->mbox_host->foreign_bound = TB_PINF; s->mbox_host->local_best = TB_PINF;
+  std::memset(s->mbox_host, 0, sizeof(Mailbox));
+  s->mbox_host->foreign_bound = TB_PINF; s->mbox_host->local_best = TB_PINF;
   if (s->ring_host) {
     std::memset(s->ring_host, 0, 64 + align16((size_t)s->ring_slots * 8));
     s->ring_next = 0;
   }
   Ctrl c{};
-  c.next_subproblem = s->P.sub_lo;
   c.first_sol_idx = ~0ull;
   c.best_bound = TB_PINF; c.foreign_bound = TB_PINF;
   HIP_TRY(hipMemcpy(s->P.ctrl, &c, sizeof(c), hipMemcpyHostToDevice));
+  PeerCell pc;
+  std::memset(&pc, 0, sizeof(pc));
+  pc.queue = q_pack(0, 0, s->local_count);
+  pc.bound = TB_PINF;
+  pc.desc[0].j_base = 0; pc.desc[0].owner = s->P.rank;
+  HIP_TRY(hipMemcpy(s->cell, &pc, sizeof(pc), hipMemcpyHostToDevice));
+  bool linked = false;
+  for (int r = 0; r < s->P.world; ++r) linked |= r != s->P.rank && s->peer_cells[(size_t)r] != nullptr;
+  if (linked) {
+    HIP_TRY(hipMemcpy(s->d_peers, s->peer_cells.data(), sizeof(PeerCell*) * (size_t)s->P.world, hipMemcpyHostToDevice));
+    s->P.peers = s->d_peers;
+  } else s->P.peers = nullptr;
   HIP_TRY(hipMemset(s->P.g_stats, 0, sizeof(BlockStats) * (size_t)s->plan.num_blocks));
+  s->armed = true;
+  return TB_OK;
+}
+
+int tb_session_start(tb_session* s) {
+  if (!s) return fail(TB_ERR_INVALID, "null session");
+  if (s->started && !s->finished) return fail(TB_ERR_STATE, "session is running");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  // (re)start: a finished session can be started again on the same resident inputs
+  int rc;
+  if (!s->armed && (rc = tb_session_arm(s)) != TB_OK) return rc;
+  s->armed = false;
+  s->finished = false;
   // in-kernel watchdog: device wall clock "now" + timeout + 2 s of margin
   s->P.deadline_ticks = 0;
   if (s->cfg.timeout_ms != 0) {
-    long long* d_now = s->d_now;
-    clock_kernel<<<1, 1, 0, s->stream>>>(d_now);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s->stream));
     long long now = 0;
-    HIP_TRY(hipMemcpy(&now, d_now, sizeof(now), hipMemcpyDeviceToHost));
+    if ((rc = device_now(s->stream, s->d_now, &now)) != TB_OK) return rc;
     s->P.deadline_ticks = now + (long long)(s->cfg.timeout_ms + 2000) * (long long)s->caps.wall_khz;
   }
   s->t_start = std::chrono::steady_clock::now();
@@ -749,6 +883,35 @@ int tb_session_start(tb_session* s) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev_stop, s->stream));
   s->started = true;
+  return TB_OK;
+}
+
+int tb_session_progress(tb_session* s, uint64_t* remaining_out, uint64_t* stolen_in_out, uint64_t* stolen_out_out) {
+  if (!s || !s->started) return fail(TB_ERR_STATE, "session not started");
+  const unsigned long long w = __atomic_load_n(&s->mbox_host->progress, __ATOMIC_RELAXED);
+  if (remaining_out) *remaining_out = q_hi(w) > q_next(w) ? q_hi(w) - q_next(w) : 0;
+  if (stolen_in_out || stolen_out_out) {
+    PeerCell pc;
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    // a side copy while the kernel runs: the cell is fine-grained memory, and this is a diagnostic
+    hipError_t e = hipMemcpy(&pc, s->cell, sizeof(pc), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(TB_ERR_HIP, std::string("hipMemcpy(cell): ") + hipGetErrorString(e));
+    if (stolen_in_out) *stolen_in_out = pc.stolen_in;
+    if (stolen_out_out) *stolen_out_out = pc.stolen_out;
+  }
+  return TB_OK;
+}
+
+int tb_session_debug_last_store(tb_session* s, int32_t workgroup, tb_itv* store_out) {
+  if (!s || !store_out) return fail(TB_ERR_INVALID, "null argument");
+  if (!s->finished) return fail(TB_ERR_STATE, "session not finished");
+  if (!s->P.g_last) return fail(TB_ERR_STATE, "the session was not created with the 0x800000 test knob");
+  if (workgroup < 0 || workgroup >= s->plan.num_blocks) return fail(TB_ERR_INVALID, "workgroup out of range");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  const size_t VX = (size_t)s->plan.vext;
+  std::vector<unsigned char> slab(std::max<size_t>(16, VX * 8));
+  HIP_TRY(hipMemcpy(slab.data(), s->P.g_last + (size_t)workgroup * VX, VX * 8, hipMemcpyDeviceToHost));
+  decode_slab(s->lay, slab.data(), store_out);
   return TB_OK;
 }
 
@@ -784,9 +947,21 @@ int tb_session_next_solution(tb_session* s, tb_itv* store_out, int32_t* objectiv
   *has_out = 0;
   if (!s->started) return fail(TB_ERR_STATE, "session not started");
   if (!s->ring_host) return TB_OK;  // streaming is off: there is never anything to take
-  const int slot = (int)(s->ring_next % (unsigned long long)s->ring_slots);
-  const unsigned long long seq = __atomic_load_n(&s->ring_seq()[slot], __ATOMIC_ACQUIRE);
-  if (seq != s->ring_next + 1) return TB_OK;
+  int slot = (int)(s->ring_next % (unsigned long long)s->ring_slots);
+  unsigned long long seq = __atomic_load_n(&s->ring_seq()[slot], __ATOMIC_ACQUIRE);
+  if (seq != s->ring_next + 1) {
+    // A producer that gave up on a stop request leaves a hole in the ticket sequence: once the kernel has ended nobody
+    // will fill it, so deliver what later tickets left in the ring, oldest first.
+    if (hipEventQuery(s->ev_stop) != hipSuccess) { (void)hipGetLastError(); return TB_OK; }
+    unsigned long long best_seq = 0;
+    for (int k = 0; k < s->ring_slots; ++k) {
+      const unsigned long long q = __atomic_load_n(&s->ring_seq()[k], __ATOMIC_ACQUIRE);
+      if (q > s->ring_next + 1 && (best_seq == 0 || q < best_seq)) { best_seq = q; slot = k; }
+    }
+    if (best_seq == 0) return TB_OK;
+    seq = best_seq;
+    s->ring_next = seq - 1;
+  }
   std::vector<tb_itv> sol((size_t)std::max(1, s->n_vars));
   decode_slab(s->lay, s->ring_data() + (size_t)slot * (size_t)s->plan.vext * 8, sol.data());
   if (store_out && s->n_vars) std::memcpy(store_out, sol.data(), (size_t)s->n_vars * sizeof(tb_itv));
@@ -809,7 +984,7 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
   HIP_TRY(hipMemcpy(bst.data(), s->P.g_stats, B * sizeof(BlockStats), hipMemcpyDeviceToHost));
   Ctrl c{};
   HIP_TRY(hipMemcpy(&c, s->P.ctrl, sizeof(c), hipMemcpyDeviceToHost));
-  if (c.error != 0) return fail(TB_ERR_HIP, "device error: decision stack overflow (search deeper than " + std::to_string(s->plan.max_depth) + ")");
+  if (c.error != 0) return fail(TB_ERR_DEPTH, "decision stack overflow: the search went deeper than " + std::to_string(s->plan.max_depth) + " decisions (tb_config.decision_stack_depth)");
 
   // reduce_blocks (barebones:1033-1067): sum the statistics, pick the winning workgroup.
   tb_stats st;
@@ -817,7 +992,7 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
   st.exhaustive = 1;
   const double ns_per_tick = 1e6 / (double)s->caps.wall_khz;
   long long best_block = -1;
-  long long first_idle = -1;
+  long long first_idle = -1, last_idle = 0, wait_ticks = 0;
   for (size_t b = 0; b < B; ++b) {
     const BlockStats& x = bst[b];
     st.nodes += x.nodes; st.fails += x.fails; st.solutions += x.solutions;
@@ -825,6 +1000,9 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
     st.eps_solved_subproblems += x.eps_solved; st.eps_skipped_subproblems += x.eps_skipped;
     st.num_blocks_done += (uint64_t)x.num_blocks_done;
     st.store_writes += x.store_writes;
+    st.eps_stolen_subproblems += x.stolen;
+    wait_ticks += x.wait_ticks;
+    last_idle = std::max(last_idle, x.timers[TB_T_FIRST_BLOCK_IDLE]);
     st.depth_max = std::max(st.depth_max, x.depth_max);
     st.exhaustive = st.exhaustive && x.exhaustive;
     st.reserved[0] |= x.why;
@@ -844,6 +1022,10 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
     }
   }
   st.timers_ns[TB_T_FIRST_BLOCK_IDLE] = first_idle < 0 ? 0 : (int64_t)((double)first_idle * ns_per_tick);
+  st.min_block_ns = st.timers_ns[TB_T_FIRST_BLOCK_IDLE];
+  st.max_block_ns = (int64_t)((double)last_idle * ns_per_tick);
+  st.wait_time_ns = (int64_t)((double)wait_ticks * ns_per_tick);
+  st.eps_local_subproblems = s->local_count;
   st.best_bound = TB_PINF; st.best_subproblem = -1;
   if (best_block >= 0) {
     const BlockStats& w = bst[(size_t)best_block];
@@ -862,7 +1044,7 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
   st.kernel_ns = (int64_t)((double)ms * 1e6);
   st.num_blocks = s->plan.num_blocks; st.threads_per_block = s->plan.threads;
   st.mem_kind = s->plan.mem_kind; st.shared_bytes = s->plan.shared_bytes; st.subproblems_power = s->plan.subproblems_power;
-  st.interrupted = (c.stop != 0) ? 1 : 0;
+  st.interrupted = (c.stop & STOP_HOST) ? 1 : 0;
   if (st.interrupted) st.exhaustive = 0;
   // a slice that was not fully consumed is not exhaustive either (stop raised by a workgroup)
   if (stats_out) *stats_out = st;
@@ -914,6 +1096,13 @@ int tb_solve(const tb_config* cfg_in, int32_t n_vars, const tb_itv* root_store,
   tb_stats st;
   int32_t has = 0;
   int rc = run(cfg, best_store_out, &has, &st);
+  // The reference grows a workgroup's decision stack on demand (barebones:401-403); the stacks here are sized on the
+  // host, so a search that outgrows them is run again with deeper ones.
+  for (int depth = cfg.decision_stack_depth > 0 ? cfg.decision_stack_depth : 16384; rc == TB_ERR_DEPTH && depth < (1 << 22);) {
+    depth *= 8;
+    cfg.decision_stack_depth = depth;
+    rc = run(cfg, best_store_out, &has, &st);
+  }
   if (rc != TB_OK) return rc;
   // Canonical pass: the B&B above proved `best_bound` optimal; the DFS-first solution under the constant
   // constraint obj <= best_bound is unique, so the answer no longer depends on the race between workgroups.

@@ -24,15 +24,21 @@ namespace tb {
 #define TB_SYS __HIP_MEMORY_SCOPE_SYSTEM
 
 constexpr int MAX_WAVES = 16;          // 1024 threads
-constexpr int MAILBOX_PERIOD = 64;     // nodes between two polls of the host mailbox
+constexpr int NODE_BATCH = 32;         // nodes a workgroup explores between two updates of the node-wide node counter
+constexpr int WAVE_WATCHDOG_PERIOD = 1024;  // wave-local iterations between two looks at the deadline / abort flag
 
 // Host-pinned page shared with the host thread (replaces the managed-memory flags of
 // barebones UnifiedData::stop, barebones:64, and the 100 ms wait loop of memory_gpu.hpp:174-196).
+// One workgroup per poll period (DevProblem::poll_ticks of wall clock, elected through Ctrl::next_poll) reads the
+// host -> device words and refreshes the device -> host ones: the traffic over PCIe does not depend on the grid size
+// nor on how long a node takes.
 struct Mailbox {
   int stop;           // host -> device
-  int foreign_bound;  // host -> device: incumbent found by another GPU
-  int local_best;     // device -> host: incumbent found on this GPU
-  int pad;
+  int foreign_bound;  // host -> device: incumbent found by another GPU (host relay; peers normally write PeerCell::bound directly)
+  int local_best;     // device -> host: incumbent found on this GPU (written on improvement, refreshed by every poll)
+  int polls;          // device -> host: number of polls so far (liveness)
+  unsigned long long progress;  // device -> host: PeerCell::queue at the last poll (remaining work of this GPU)
+  unsigned long long pad;
 };
 
 // Workgroup control block, first bytes of the dynamic LDS segment.
@@ -45,7 +51,10 @@ struct alignas(16) BlockShared {
   int best_bound;  // best objective found by this workgroup (BlockData::best_bound, barebones:116)
   int found, sol, skip, abort;
   int new_depth, ev_all, chg_count[2], ev_busy;  // event mode: "run every slice" request, change-list fill, waves running a slice
-  unsigned long long sub_idx;
+  unsigned long long sub_idx;  // global index of the current subproblem
+  unsigned long long sub_j;    // its index in the local numbering of rank sub_owner (eps_global_index)
+  int sub_owner, sub_gen;      // rank whose share it belongs to; generation of the queue range it was fetched from
+  int has_work, pad_work;
   long long ticket;  // streaming: sequence number of the solution being handed to the host, -1 if none
   unsigned long long red_key[MAX_WAVES];
   int red_first[MAX_WAVES];
@@ -246,7 +255,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         const int4 pr = pr_next;
         pr_next = props[imin(base + T, last_base) + lane];
         if (rm && slice_unent[base >> 6] == 0) continue;
-        for (;;) {
+        for (unsigned local_iters = 1;; ++local_iters) {
           bool ch = false, un_i = false;
           apply<false, false>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
           ++wave_evals;
@@ -258,6 +267,12 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
           changed = true;
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
           if (ld(&sh.bot)) break;
+          // watchdog inside the wave-local loop: a slowly converging pair in one slice (x < y < x over 2^31 values) never
+          // reaches the block-level check below (wave-uniform counter: scalar work, once per 1024 iterations)
+          if ((local_iters % WAVE_WATCHDOG_PERIOD) == 0) {
+            if (lane == 0 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
+            if (ld(&sh.abort)) break;
+          }
         }
       }
     }
@@ -448,6 +463,10 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       if (my) mark_rest(P, es.dirty, my, hy, s);
       if (mz) mark_rest(P, es.dirty, mz, hz, s);
       if (ld(&sh.bot)) break;
+      if ((wave_iters % WAVE_WATCHDOG_PERIOD) == 0) {  // watchdog inside the wave-local loop (see fixpoint)
+        if (lane == 0 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
+        if (ld(&sh.abort)) break;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my marks are visible before I stop being busy
     if (lane == 0) { (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG); tc.deductions += 64ull * (unsigned)((knobs(P) & 0x400000) ? 1 : wave_iters); }  // 0x400000: count slice runs (profiling)
@@ -651,6 +670,185 @@ __device__ __forceinline__ void produce_solution(const DevProblem& P, BlockShare
   __syncthreads();
 }
 
+// ---- device <-> host / device <-> device words (thread 0 only) ---------------------------------------
+
+struct Hot { int best, foreign, stop; unsigned next_poll; };
+// The 16 hot bytes of Ctrl: two 8-byte agent-scope loads (they bypass the non-coherent vector L1), one wait.
+__device__ __forceinline__ Hot load_hot(const Ctrl* c) {
+  const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&c->best_bound), TB_RLX, TB_AGENT);
+  const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&c->stop), TB_RLX, TB_AGENT);
+  Hot h;
+  h.best = (int)(a & 0xffffffffull); h.foreign = (int)(a >> 32);
+  h.stop = (int)(b & 0xffffffffull); h.next_poll = (unsigned)(b >> 32);
+  return h;
+}
+
+// One poll of everything that lives outside this device: the host mailbox (stop request, relayed incumbent) and this
+// device's peer cell (incumbent and stop raised by the other GPUs over xGMI).  Time based: whoever notices that the
+// poll is due and wins the CAS on Ctrl::next_poll does it, every other workgroup goes on.
+__device__ __forceinline__ void poll_outside(const DevProblem& P, Mailbox* mbox, long long now) {
+  Ctrl* c = P.ctrl;
+  PeerCell* me = P.cell;
+  int stop = __hip_atomic_load(&mbox->stop, TB_RLX, TB_SYS) != 0 ? STOP_HOST : 0;
+  int fb = __hip_atomic_load(&mbox->foreign_bound, TB_RLX, TB_SYS);
+  const int cb = __hip_atomic_load(&me->bound, TB_RLX, TB_SYS);
+  fb = cb < fb ? cb : fb;
+  if (__hip_atomic_load(&me->stop, TB_RLX, TB_SYS) != 0) stop |= STOP_GPU;
+  if (P.deadline_ticks != 0 && now > P.deadline_ticks) stop |= STOP_HOST;
+  if (fb != PINF) (void)__hip_atomic_fetch_min(&c->foreign_bound, fb, TB_RLX, TB_AGENT);
+  if (stop) (void)__hip_atomic_fetch_or(&c->stop, stop, TB_RLX, TB_AGENT);
+  // device -> host: the incumbent (two improvements may reach the host out of order; the refresh repairs it within
+  // one period) and the remaining work
+  __hip_atomic_store(&mbox->local_best, __hip_atomic_load(&c->best_bound, TB_RLX, TB_AGENT), TB_RLX, TB_SYS);
+  __hip_atomic_store(&mbox->progress, __hip_atomic_load(&me->queue, TB_RLX, TB_SYS), TB_RLX, TB_SYS);
+  __hip_atomic_store(&mbox->polls, __hip_atomic_load(&mbox->polls, TB_RLX, TB_SYS) + 1, TB_RLX, TB_SYS);
+}
+__device__ __forceinline__ void maybe_poll(const DevProblem& P, Mailbox* mbox, const Hot& h, long long now) {
+  if ((int)((unsigned)now - h.next_poll) >= 0) {
+    unsigned expect = h.next_poll;
+    if (__hip_atomic_compare_exchange_strong(&P.ctrl->next_poll, &expect, (unsigned)now + (unsigned)P.poll_ticks, TB_RLX, TB_RLX, TB_AGENT))
+      poll_outside(P, mbox, now);
+  }
+}
+
+// A better incumbent was found on this device: tell the host and every other GPU (4 bytes per peer over xGMI -- the
+// only payload the GPUs exchange during the search, barebones:426 made multi-device).
+__device__ __forceinline__ void publish_bound(const DevProblem& P, Mailbox* mbox, int obj) {
+  __hip_atomic_store(&mbox->local_best, obj, TB_RLX, TB_SYS);
+  if (P.peers != nullptr)
+    for (int r = 0; r < P.world; ++r) {
+      PeerCell* pc = P.peers[r];
+      if (r != P.rank && pc != nullptr) (void)__hip_atomic_fetch_min(&pc->bound, obj, TB_RLX, TB_SYS);
+    }
+}
+// Solution limit reached / objective unbounded: every GPU stops.
+__device__ __forceinline__ void raise_gpu_stop(const DevProblem& P) {
+  (void)__hip_atomic_fetch_or(&P.ctrl->stop, STOP_GPU, TB_RLX, TB_AGENT);
+  if (P.peers != nullptr)
+    for (int r = 0; r < P.world; ++r) {
+      PeerCell* pc = P.peers[r];
+      if (r != P.rank && pc != nullptr) __hip_atomic_store(&pc->stop, 1, TB_RLX, TB_SYS);
+    }
+}
+
+// ---- work queue over the EPS index space (barebones:718-741,877-884 made multi-device; thread 0 only) -----------------
+//
+// Each device owns a block-cyclic share of the 2^d subproblems (eps_global_index) and serves it through its cell's
+// `queue` word.  A device whose queue runs dry takes the upper half of the fullest peer queue with one CAS over xGMI
+// and installs it as its own next range: dynamic balance without the host, like the single grid-wide counter of the
+// reference but hierarchical.  Every subproblem index is, at any time, in exactly one queue range or in the hands of
+// exactly one workgroup.
+
+// Take the upper half of the fullest peer queue.  1: a range was installed, 0: nothing now (try again), -1: every
+// queue of the node is empty and nobody is moving work -- the search is over for this workgroup.
+__device__ __forceinline__ int steal_work(const DevProblem& P, BlockStats& bs) {
+  PeerCell* me = P.cell;
+  int zero = 0;
+  if (!__hip_atomic_compare_exchange_strong(&me->stealing, &zero, 1, __ATOMIC_ACQUIRE, TB_RLX, TB_SYS)) return 0;  // a sibling is at it
+  const unsigned long long mine = __hip_atomic_load(&me->queue, __ATOMIC_ACQUIRE, TB_SYS);
+  if (q_next(mine) < q_hi(mine)) { __hip_atomic_store(&me->stealing, 0, __ATOMIC_RELEASE, TB_SYS); return 1; }  // refilled meanwhile
+  int best = -1;
+  unsigned long long best_av = 0;
+  bool busy = false;
+  for (int r = 0; r < P.world; ++r) {
+    PeerCell* pc = P.peers[r];
+    if (r == P.rank || pc == nullptr) continue;
+    const unsigned long long w = __hip_atomic_load(&pc->queue, TB_RLX, TB_SYS);
+    const unsigned long long av = q_hi(w) > q_next(w) ? q_hi(w) - q_next(w) : 0ull;
+    if (av > best_av) { best = r; best_av = av; }
+    if (av > 0 || __hip_atomic_load(&pc->stealing, TB_RLX, TB_SYS) != 0) busy = true;
+  }
+  int result = busy ? 0 : -1;
+  if (best >= 0) {
+    PeerCell* v = P.peers[best];
+    result = 0;
+    for (int tries = 0; tries < 8; ++tries) {
+      unsigned long long w = __hip_atomic_load(&v->queue, __ATOMIC_ACQUIRE, TB_SYS);
+      const unsigned long long nx = q_next(w), hi = q_hi(w);
+      if (hi <= nx) break;
+      const unsigned long long take = (hi - nx + 1) / 2;  // the last one too: the victim's kernel may not be running (yet, or any more)
+      const unsigned g = q_gen(w);
+      // the descriptor of generation g is stable while its range is not exhausted, and the CAS only succeeds on that range
+      const unsigned long long vbase = __hip_atomic_load(&v->desc[g & 7].j_base, TB_RLX, TB_SYS);
+      const int vowner = __hip_atomic_load(&v->desc[g & 7].owner, TB_RLX, TB_SYS);
+      if (!__hip_atomic_compare_exchange_strong(&v->queue, &w, q_pack(g, nx, hi - take), __ATOMIC_ACQ_REL, TB_RLX, TB_SYS)) continue;
+      // [hi - take, hi) of the victim's range is mine now
+      const unsigned g2 = (q_gen(mine) + 1u) & 0xffu;
+      __hip_atomic_store(&me->desc[g2 & 7].j_base, vbase + (hi - take), TB_RLX, TB_SYS);
+      __hip_atomic_store(&me->desc[g2 & 7].owner, vowner, TB_RLX, TB_SYS);
+      __hip_atomic_store(&me->queue, q_pack(g2, 0, take), __ATOMIC_RELEASE, TB_SYS);
+      (void)__hip_atomic_fetch_add(&me->stolen_in, take, TB_RLX, TB_SYS);
+      (void)__hip_atomic_fetch_add(&v->stolen_out, take, TB_RLX, TB_SYS);
+      bs.stolen += take;
+      result = 1;
+      break;
+    }
+  }
+  __hip_atomic_store(&me->stealing, 0, __ATOMIC_RELEASE, TB_SYS);
+  return result;
+}
+
+// Fetch the next subproblem of this device (sh.sub_idx / sub_j / sub_owner / sub_gen).  False: there is no work left
+// anywhere (or a stop was requested while waiting for some).
+__device__ __forceinline__ bool next_subproblem(const DevProblem& P, BlockShared& sh, Mailbox* mbox) {
+  PeerCell* me = P.cell;
+  long long t_wait = 0;
+  bool got = false;
+  for (;;) {
+    // (look before adding: a waiting workgroup must not push `next` towards the end of its 28-bit field)
+    const unsigned long long seen = __hip_atomic_load(&me->queue, TB_RLX, TB_SYS);
+    if (q_next(seen) < q_hi(seen)) {
+      const unsigned long long old = __hip_atomic_fetch_add(&me->queue, 1ull << Q_BITS, __ATOMIC_ACQUIRE, TB_SYS);
+      const unsigned long long nx = q_next(old), hi = q_hi(old);
+      if (nx < hi) {
+        const unsigned g = q_gen(old);
+        const unsigned long long base = __hip_atomic_load(&me->desc[g & 7].j_base, TB_RLX, TB_SYS);
+        const int owner = __hip_atomic_load(&me->desc[g & 7].owner, TB_RLX, TB_SYS);
+        sh.sub_j = base + nx; sh.sub_owner = owner; sh.sub_gen = (int)g;
+        sh.sub_idx = eps_global_index(base + nx, P.chunk_log2, owner, P.world);
+        got = true;
+        break;
+      }
+    }
+    if (P.world <= 1 || P.peers == nullptr || !P.steal) break;
+    const long long now = wall_clock64();
+    if (t_wait == 0) { t_wait = now; (void)__hip_atomic_fetch_add(&me->waiting, 1, TB_RLX, TB_SYS); }
+    const int r = steal_work(P, sh.bs);
+    if (r < 0) break;
+    if (r > 0) continue;
+    const Hot h = load_hot(P.ctrl);
+    if (h.stop != 0) break;
+    maybe_poll(P, mbox, h, now);
+    __builtin_amdgcn_s_sleep(127);
+  }
+  if (t_wait != 0) { sh.bs.wait_ticks += wall_clock64() - t_wait; (void)__hip_atomic_fetch_add(&me->waiting, -1, TB_RLX, TB_SYS); }
+  return got;
+}
+
+// A leaf was met `remaining` levels above the subproblem: every index of its subtree [s, s + 2^remaining) shares it
+// (barebones:718-741).  Jump this device's queue over the part of the subtree that belongs to the range the index came
+// from.  Accounting: the index itself counts as skipped, and so does every index the jump removes from the queue --
+// each subproblem is counted exactly once (solved or skipped) however the ranges were cut and moved between the GPUs;
+// with one workgroup this is the reference's `next_idx - idx`.
+__device__ __forceinline__ void skip_subtree(const DevProblem& P, BlockShared& sh) {
+  PeerCell* me = P.cell;
+  const int r = sh.remaining;
+  const unsigned long long e = ((sh.sub_idx >> r) + 1ull) << r;  // first global index behind the subtree
+  const unsigned long long je = eps_local_lower_bound(e, P.chunk_log2, sh.sub_owner, P.world);
+  unsigned long long jumped = 0;
+  for (;;) {
+    unsigned long long w = __hip_atomic_load(&me->queue, __ATOMIC_ACQUIRE, TB_SYS);
+    if ((int)q_gen(w) != sh.sub_gen) break;  // that range is exhausted: nothing left to jump over
+    const unsigned long long base = __hip_atomic_load(&me->desc[sh.sub_gen & 7].j_base, TB_RLX, TB_SYS);
+    const unsigned long long nx = q_next(w), hi = q_hi(w);
+    unsigned long long target = je - base;
+    target = target < hi ? target : hi;
+    if (nx >= target) break;
+    if (__hip_atomic_compare_exchange_strong(&me->queue, &w, q_pack((unsigned)sh.sub_gen, target, hi), __ATOMIC_ACQ_REL, TB_RLX, TB_SYS)) { jumped = target - nx; break; }
+  }
+  sh.bs.eps_skipped += 1ull + jumped;
+}
+
 // ---- one search node (barebones:903-1031) ---------------------------------------------------------
 
 struct NodeTimers { long long t_last; };
@@ -686,7 +884,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
           if (!P.use_fixed_bound) {
             const int old = __hip_atomic_fetch_min(&P.ctrl->best_bound, obj, TB_RLX, TB_AGENT);  // appx_best_bound.meet
             if (obj < old) {
-              __hip_atomic_store(&mbox->local_best, obj, TB_RLX, TB_SYS);
+              publish_bound(P, mbox, obj);
               stream = P.ring.slots != 0;  // best_has_changed && is_printing_intermediate_sol (gpu_dive_and_solve.hpp:341-344)
             }
           }
@@ -709,7 +907,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
           if (P.stop_after_n_solutions != 0 && nsol >= P.stop_after_n_solutions) {  // common_solving.hpp:858-867
             bs.exhaustive = 0;
             sh.stop = 1;
-            __hip_atomic_store(&P.ctrl->gpu_stop, 1, TB_RLX, TB_AGENT);
+            raise_gpu_stop(P);
           }
         }
       }
@@ -721,18 +919,18 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
     bs.nodes++;
     bs.fails += failed ? 1 : 0;
     bs.depth_max = sh.depth > bs.depth_max ? sh.depth : bs.depth_max;
-    // stopping conditions (barebones:1024-1029)
+    // stopping conditions (barebones:1024-1029): one 16-byte look at the grid words per node; the mailbox and the peer
+    // cell are polled on a wall-clock period by whichever workgroup notices that the poll is due
     bool must_stop = (P.cut_nodes != 0 && bs.nodes >= P.cut_nodes);
-    must_stop |= __hip_atomic_load(&P.ctrl->gpu_stop, TB_RLX, TB_AGENT) != 0;
-    if ((bs.nodes % MAILBOX_PERIOD) == 0) {
-      if (__hip_atomic_load(&mbox->stop, TB_RLX, TB_SYS) != 0) { __hip_atomic_store(&P.ctrl->stop, 1, TB_RLX, TB_AGENT); }
-      const int fb = __hip_atomic_load(&mbox->foreign_bound, TB_RLX, TB_SYS);
-      if (fb != PINF) __hip_atomic_fetch_min(&P.ctrl->foreign_bound, fb, TB_RLX, TB_AGENT);
-      if (P.deadline_ticks != 0 && t1 > P.deadline_ticks) __hip_atomic_store(&P.ctrl->stop, 1, TB_RLX, TB_AGENT);
+    if (P.cut_nodes_total != 0 && (bs.nodes % NODE_BATCH) == 0) {  // the budget of the whole node, counted in rank 0's cell
+      PeerCell* root = (P.peers != nullptr && P.peers[0] != nullptr) ? P.peers[0] : P.cell;
+      if (__hip_atomic_fetch_add(&root->nodes_total, (unsigned long long)NODE_BATCH, TB_RLX, TB_SYS) + NODE_BATCH >= P.cut_nodes_total) raise_gpu_stop(P);
     }
-    if (__hip_atomic_load(&P.ctrl->stop, TB_RLX, TB_AGENT) != 0) must_stop = true;
+    const Hot hot = load_hot(P.ctrl);
+    maybe_poll(P, mbox, hot, t1);
+    if (hot.stop != 0) must_stop = true;
     if (P.use_fixed_bound && __hip_atomic_load(&P.ctrl->first_sol_idx, TB_RLX, TB_AGENT) < sh.sub_idx) { sh.stop = 1; }
-    if (aborted) { must_stop = true; __hip_atomic_store(&P.ctrl->stop, 1, TB_RLX, TB_AGENT); }
+    if (aborted) { must_stop = true; (void)__hip_atomic_fetch_or(&P.ctrl->stop, STOP_HOST, TB_RLX, TB_AGENT); }
     if (must_stop) { bs.exhaustive = 0; sh.stop = 1; bs.why |= 4 | (aborted ? 8 : 0) | ((P.cut_nodes != 0 && bs.nodes >= P.cut_nodes) ? 16 : 0); }
   }
   __syncthreads();
@@ -785,18 +983,19 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   if (tid == 0) {
     for (int i = 0; i < TB_NUM_TIMERS; ++i) bs.timers[i] = 0;
     bs.nodes = bs.fails = bs.solutions = bs.fixpoint_iterations = bs.num_deductions = 0;
-    bs.eps_solved = bs.eps_skipped = bs.store_writes = 0;
+    bs.eps_solved = bs.eps_skipped = bs.store_writes = bs.stolen = 0;
+    bs.wait_ticks = 0;
     bs.why = 0; bs.pad_why = 0;
     bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
     sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0;
     sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0;
-    sh.sub_idx = __hip_atomic_fetch_add(&P.ctrl->next_subproblem, 1ull, TB_RLX, TB_AGENT);
     t_start = t_mark = wall_clock64();
+    sh.has_work = next_subproblem(P, sh, mbox) ? 1 : 0;
   }
   __syncthreads();
 
   // B. dive-and-solve loop (barebones:656-886)
-  while (sh.sub_idx < P.sub_hi && !sh.stop) {
+  while (sh.has_work && !sh.stop) {
     // C. restore the root
     copy_store(store, P.root_store, VX);  // the root slab is laid out like a workgroup slab
     if (EVENT && tid == 0) sh.ev_all = 1;  // the root store is not a fixpoint: every slice runs once
@@ -832,12 +1031,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     if (tid == 0) bs.timers[TB_T_DIVE] += wall_clock64() - t_dive;
     if (sh.leaf && !sh.stop) {
       // E. a leaf above the subproblem: skip the whole subtree (barebones:718-741)
-      if (tid == 0) {
-        unsigned long long next_idx = ((sh.sub_idx >> sh.remaining) + 1ull) << sh.remaining;
-        if (next_idx > P.sub_hi) next_idx = P.sub_hi;
-        __hip_atomic_fetch_max(&P.ctrl->next_subproblem, next_idx, TB_RLX, TB_AGENT);
-        if ((sh.sub_idx & ((1ull << sh.remaining) - 1ull)) == 0ull) bs.eps_skipped += next_idx - sh.sub_idx;
-      }
+      if (tid == 0) skip_subtree(P, sh);
     } else if (!sh.stop) {
       // F. solve the subproblem (barebones:742-871)
       if (tid == 0 && P.has_eps_strategy) { sh.cur_strategy = sh.cur_strategy > 1 ? sh.cur_strategy : 1; sh.next_unassigned = 0; }
@@ -847,12 +1041,13 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
         if (tid == 0 && P.obj_var >= 0) {
           if (P.use_fixed_bound) embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, P.obj_var, NINF, P.fixed_bound);
           else {
-            int g = __hip_atomic_load(&P.ctrl->best_bound, TB_RLX, TB_AGENT);
-            const int f = __hip_atomic_load(&P.ctrl->foreign_bound, TB_RLX, TB_AGENT);
+            const unsigned long long bf = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&P.ctrl->best_bound), TB_RLX, TB_AGENT);
+            int g = (int)(bf & 0xffffffffull);
+            const int f = (int)(bf >> 32);  // Ctrl::foreign_bound
             g = f < g ? f : g;
             g = sh.best_bound < g ? sh.best_bound : g;
             if (g != PINF) {
-              if (g == NINF) { sh.stop = 1; __hip_atomic_store(&P.ctrl->gpu_stop, 1, TB_RLX, TB_AGENT); }  // unbounded objective
+              if (g == NINF) { sh.stop = 1; raise_gpu_stop(P); }  // unbounded objective
               else embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, P.obj_var, NINF, g - 1);
             }
           }
@@ -920,9 +1115,15 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
       if (tid == 0 && !sh.stop) bs.eps_solved += 1;
     }
     // G. next subproblem (barebones:877-884)
-    if (tid == 0 && !sh.stop) sh.sub_idx = __hip_atomic_fetch_add(&P.ctrl->next_subproblem, 1ull, TB_RLX, TB_AGENT);
+    if (tid == 0 && !sh.stop) {
+      const long long t = wall_clock64();
+      bs.timers[TB_T_SEARCH] += t - t_mark;
+      sh.has_work = next_subproblem(P, sh, mbox) ? 1 : 0;
+      t_mark = wall_clock64();  // time spent waiting for work is not search time (BlockStats::wait_ticks)
+    }
     __syncthreads();
   }
+  if (P.g_last != nullptr) copy_store(P.g_last + (size_t)b * VX, store, VX);  // test aid: the store this workgroup stopped on
 
   // reduce the per-thread counters (once per kernel)
   __syncthreads();
@@ -941,7 +1142,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     bs.store_writes = sh.red_key[0];
     bs.num_deductions = sh.red_key[1];
     bs.best_bound = sh.best_bound;
-    const int stopped = __hip_atomic_load(&P.ctrl->stop, TB_RLX, TB_AGENT);
+    const int stopped = __hip_atomic_load(&P.ctrl->stop, TB_RLX, TB_AGENT) & STOP_HOST;
     if (!(P.cut_nodes != 0 && bs.nodes >= P.cut_nodes) && !stopped) bs.num_blocks_done = 1;  // barebones:889-891
     const long long t_end = wall_clock64();
     bs.timers[TB_T_FIRST_BLOCK_IDLE] = t_end - t_start;

@@ -39,7 +39,7 @@ void usage_and_exit(const std::string& program) {
       << "\t-or / -p <n>: number of workgroups (default 0: automatic).\n"
       << "\t-sub <d>: 2^d subproblems (default -1: at least subfactor x workgroups).  -subfactor <f>: default 300.\n"
       << "\t-cutnodes <n>: stop a workgroup after n nodes (0: no limit).  -globalmem: keep the store in global memory.\n"
-      << "\t-gpus <n>: shard the subproblems over n GPUs of the node.  -deterministic: return the DFS-first optimal solution.\n";
+      << "\t-gpus <n>: shard the subproblems over n GPUs of the node (-devices a,b,..: which ones).  -deterministic: return the DFS-first optimal solution.\n";
   std::exit(EXIT_FAILURE);
 }
 
@@ -119,6 +119,17 @@ Options parse_options(int argc, char** argv) {
   boolean("-disable_network_analysis", o.disable_network_analysis);
   boolean("-deterministic", o.deterministic);
   i32("-gpus", o.gpus);
+  {
+    std::string list;
+    if (str("-devices", list)) {
+      for (size_t b = 0; b <= list.size();) {
+        const size_t e = std::min(list.find(',', b), list.size());
+        try { o.devices.push_back(std::stoi(list.substr(b, e - b))); } catch (...) { std::cerr << "Bad device list -devices " << list << std::endl; std::exit(EXIT_FAILURE); }
+        b = e + 1;
+      }
+      o.gpus = (int)o.devices.size();
+    }
+  }
   i32("-threads", o.threads_per_block);
   std::string s;
   if (str("-arch", s)) {
@@ -145,6 +156,7 @@ Options parse_options(int argc, char** argv) {
   if (a.tok.size() <= a.consumed) usage_and_exit(program);  // the input file is the last token
   o.problem_path = a.tok.back();
   if (o.gpus < 1) o.gpus = 1;
+  if (o.devices.empty()) for (int g = 0; g < o.gpus; ++g) o.devices.push_back(g);
   return o;
 }
 

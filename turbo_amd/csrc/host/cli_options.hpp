@@ -37,6 +37,7 @@ struct Options {
   std::string problem_path, version, hardware;
   // extensions of this engine (not reference flags)
   int gpus = 1;                               // -gpus N: shard the EPS index space over N devices of the node
+  std::vector<int> devices;                   // -devices a,b,..: the HIP device of each rank (default 0..N-1; an ordinal may repeat)
   bool deterministic = false;                 // -deterministic: canonical (DFS-first) optimal solution
   int threads_per_block = 0;                  // -threads
 };

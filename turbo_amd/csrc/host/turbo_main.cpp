@@ -63,6 +63,8 @@ void print_solve_statistics(const Printer& p, const Options&, const tb_stats& st
   p.u("eps_solved_subproblems", st.eps_solved_subproblems);
   p.u("eps_skipped_subproblems", st.eps_skipped_subproblems);
   p.u("num_blocks_done", st.num_blocks_done);
+  p.u("eps_stolen_subproblems", st.eps_stolen_subproblems);  // engine-specific: work moved between GPUs
+  p.d("wait_for_work_time", to_sec(st.wait_time_ns / nb));
   p.u("fixpoint_iterations", st.fixpoint_iterations);
   p.u("num_deductions", st.num_deductions);
   p.d("cumulative_time_block_sec", to_sec(st.cumulative_time_block_ns));
@@ -97,6 +99,9 @@ void merge_stats(tb_stats& a, const tb_stats& b) {  // statistics.hpp:182-196 ac
   a.timers_ns[TB_T_FIRST_BLOCK_IDLE] = std::min(a.timers_ns[TB_T_FIRST_BLOCK_IDLE], b.timers_ns[TB_T_FIRST_BLOCK_IDLE]);
   a.cumulative_time_block_ns += b.cumulative_time_block_ns;
   a.kernel_ns = std::max(a.kernel_ns, b.kernel_ns);
+  a.eps_local_subproblems += b.eps_local_subproblems; a.eps_stolen_subproblems += b.eps_stolen_subproblems;
+  a.wait_time_ns += b.wait_time_ns;
+  a.min_block_ns = std::min(a.min_block_ns, b.min_block_ns); a.max_block_ns = std::max(a.max_block_ns, b.max_block_ns);
 }
 
 tb_config make_config(const Options& o, bool has_eps) {
@@ -177,8 +182,14 @@ bool simplify_network(const Options& o, const Printer& p, tf_model* m, std::stri
     std::vector<tb_itv> root(tf_store(m), tf_store(m) + n_vars);
     if (n_props > 0) {
       int32_t failed = 0;
+      c.timeout_ms = o.timeout_ms;  // the root fixpoint obeys -t like the search does
       const int rc = tb_propagate(&c, n_vars, n_props, tf_props(m), 1, root.data(), &failed, nullptr, nullptr, nullptr, nullptr);
       if (rc != TB_OK) { err = tb_last_error(); return false; }
+      // failed = 1: the root is inconsistent -- say so explicitly instead of relying on the kernel having left an empty
+      // interval behind (variable 0 is the constant 0: [1, 0] is the empty interval the simplifier looks for);
+      // failed = -1: the watchdog cut the fixpoint short; what was narrowed so far is still sound, go on with it
+      if (failed == 1) { root[0].lb = 1; root[0].ub = 0; }
+      if (failed == -1 && o.verbose) std::printf("%% The root fixpoint was interrupted by the timeout.\n");
     }
     int32_t st[9];
     if (tf_simplify(m, root.data(), st) != 0) { err = "the network simplifier failed"; return false; }
@@ -229,11 +240,18 @@ int solve_sessions(const Options& o, const tb_config& base, const tf_model* m, s
   int rc = TB_OK;
   for (int g = 0; g < G && rc == TB_OK; ++g) {
     tb_config c = base;
-    c.device = g; c.rank = g; c.world_size = G; c.deterministic = 0;
+    c.device = o.devices[(size_t)g]; c.rank = g; c.world_size = G; c.deterministic = 0;
     c.stream_solutions = printer ? 1 : 0;
     rc = tb_session_create(&c, tf_num_vars(m), tf_store(m), tf_num_props(m), tf_props(m), tf_num_strategies(m), tf_strat_var_order(m),
                            tf_strat_val_order(m), tf_strat_off(m), tf_strat_vars(m), tf_obj_var(m), &ss[(size_t)g]);
   }
+  // The kernels exchange the incumbent bound and rebalance work among themselves over xGMI (include/turbo_hip.h:
+  // tb_session_link_peer); without a peer path between two devices the relay below (poll / push_bound) carries the bound.
+  for (int a = 0; a < G && rc == TB_OK; ++a)
+    for (int b = 0; b < G && rc == TB_OK; ++b)
+      if (a != b && tb_session_link_peer(ss[(size_t)a], ss[(size_t)b]) != TB_OK && o.verbose)
+        std::printf("%% GPUs %d and %d are not linked (%s): the host relays the bound.\n", a, b, tb_last_error());
+  for (int g = 0; g < G && rc == TB_OK; ++g) rc = tb_session_arm(ss[(size_t)g]);  // every cell is reset before any kernel can touch it
   for (int g = 0; g < G && rc == TB_OK; ++g) rc = tb_session_start(ss[(size_t)g]);
   std::vector<tb_itv> tmp(best.size());
   auto drain = [&]() {

@@ -1,11 +1,18 @@
-"""Multi-GPU driver: one process per GPU, the EPS index space sharded in contiguous slices, and the
-incumbent objective bound as the only payload exchanged during the search.
+"""Multi-GPU driver: one process per GPU of one node.
 
-The reference is single-GPU (device 0 hard-coded: gpu_dive_and_solve.hpp:537,636, barebones:532); its
-only inter-workgroup state is `next_subproblem`, `appx_best_bound` and a stop flag
-(barebones_dive_and_solve.hpp:409-453).  Across GPUs the work counter becomes a static slice per rank
-(`tb_eps_slice`) and the bound becomes an `all_reduce(MIN)` of one int32 over RCCL (backend "nccl" on
-ROCm; "gloo" in the CPU tests).  A 4-byte message is latency bound: link bandwidth is irrelevant.
+The reference is single-GPU (device 0 hard-coded: gpu_dive_and_solve.hpp:537,636, barebones:532); its only
+inter-workgroup state is `next_subproblem`, `appx_best_bound` and a stop flag (barebones_dive_and_solve.hpp:409-453).
+Across GPUs:
+
+* the 2^d subproblems are dealt block-cyclically (`tb_eps_global_index`) -- static, balanced, no communication;
+* every session owns one cell in fine-grained device memory (queue word + imported bound).  `link_group` exchanges the
+  cells' IPC handles through torch.distributed (an all_gather of 64 bytes per rank: RCCL with backend "nccl", gloo in
+  the CPU tests) and maps them, after which the KERNELS exchange the incumbent (one int32 atomicMin per peer) and steal
+  work from each other directly over xGMI.  During the search the processes do not talk to each other at all;
+* when the cells cannot be mapped (no IPC / no peer path) the processes fall back to relaying the bound through the
+  host: `exchange_until_done`, an all_reduce(MIN) of one int32 per round.
+
+torch.distributed is plumbing here: rendezvous, the handle exchange, barriers, and the end-of-search reductions.
 """
 from __future__ import annotations
 
@@ -14,8 +21,76 @@ import time
 PINF = 2**31 - 1
 
 
+def agree_on_plan(session, dist=None, tensor_device="cpu") -> dict:
+    """All ranks must have planned the same 2^d (and chunking): the shares only tile the index space then."""
+    plan = session.plan()
+    if dist is None or dist.get_world_size() == 1:
+        return plan
+    import torch
+    mine = torch.tensor([plan["subproblems_power"], -plan["subproblems_power"], plan["eps_chunk_log2"], -plan["eps_chunk_log2"]],
+                        dtype=torch.int64, device=tensor_device)
+    dist.all_reduce(mine, op=dist.ReduceOp.MIN)
+    lo, hi, klo, khi = int(mine[0]), -int(mine[1]), int(mine[2]), -int(mine[3])
+    if lo != hi or klo != khi:
+        raise RuntimeError(f"ranks planned different subproblem counts (2^{lo} .. 2^{hi}, chunk 2^{klo} .. 2^{khi}): "
+                           f"pass the same subproblems_power / eps_chunk_log2 to every rank")
+    return plan
+
+
+def link_group(session, dist=None, tensor_device="cpu") -> bool:
+    """Map every other rank's cell into this session (collective).  Returns True when all ranks are fully linked --
+    the kernels then exchange bounds and work among themselves -- False when the host relay must be used."""
+    if dist is None or dist.get_world_size() == 1:
+        return True
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ok = 1
+    try:
+        handle = session.export_peer()
+    except Exception:
+        handle, ok = bytes(64), 0
+    mine = torch.tensor(list(handle) + [ok], dtype=torch.uint8, device=tensor_device)
+    everyone = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    for r, t in enumerate(everyone):
+        if r == rank:
+            continue
+        raw = bytes(t.cpu().tolist())
+        if not raw[64]:
+            ok = 0
+            continue
+        try:
+            session.import_peer(r, raw[:64])
+        except Exception:
+            ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=tensor_device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
+def run_linked(session, dist=None, period_s: float = 0.0002, max_seconds: float | None = None):
+    """One search of a linked group (collective): arm, synchronise, start, wait for the own kernel, finish, synchronise.
+    A peer must not touch a cell that is being reset, hence the two barriers.  Returns session.finish()."""
+    session.arm()
+    if dist is not None and dist.get_world_size() > 1:
+        dist.barrier()
+    session.start()
+    t0 = time.perf_counter()
+    while True:
+        _, done = session.poll()
+        if done:
+            break
+        if max_seconds is not None and time.perf_counter() - t0 > max_seconds:
+            session.stop()
+        time.sleep(period_s)
+    out = session.finish()
+    if dist is not None and dist.get_world_size() > 1:
+        dist.barrier()
+    return out
+
+
 def exchange_until_done(session, dist=None, tensor_device="cpu", period_s: float = 0.0005, max_seconds: float | None = None):
-    """Drive one started session to completion.
+    """Host relay (fallback when the cells are not linked): drive one started session to completion.
 
     `session` needs poll() -> (local_best, done), push_bound(b) and stop().  With a process group,
     every rank calls this collectively: each round all-reduces (min) the pair (best bound, done flag),
@@ -49,10 +124,10 @@ def exchange_until_done(session, dist=None, tensor_device="cpu", period_s: float
 
 
 def reduce_results(has_solution: bool, best_bound: int, stats: dict, dist=None, tensor_device="cpu"):
-    """End of search: min of bounds (ties -> lowest rank = lowest subproblem slice), sum of counters.
+    """End of search: min of bounds (ties -> lowest rank), sum of counters.
     Returns (winner_rank or -1, global_bound, summed_stats)."""
     keys = ["nodes", "fails", "solutions", "fixpoint_iterations", "num_deductions", "eps_solved_subproblems",
-            "eps_skipped_subproblems", "num_blocks_done", "store_writes"]
+            "eps_skipped_subproblems", "num_blocks_done", "store_writes", "eps_stolen_subproblems"]
     if dist is None or dist.get_world_size() == 1:
         return (0 if has_solution else -1), (best_bound if has_solution else PINF), {k: stats.get(k, 0) for k in keys}
     import torch
@@ -66,3 +141,15 @@ def reduce_results(has_solution: bool, best_bound: int, stats: dict, dist=None, 
     s = torch.tensor([int(stats.get(x, 0)) for x in keys], dtype=torch.int64, device=tensor_device)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return winner, gbound, dict(zip(keys, (int(v) for v in s.tolist())))
+
+
+def gather_rank_rows(row: dict, dist=None, tensor_device="cpu") -> list:
+    """Per-rank balance figures (kernel time, waiting time, stolen work ...) gathered on every rank, in rank order."""
+    keys = sorted(row)
+    if dist is None or dist.get_world_size() == 1:
+        return [dict(row, rank=0)]
+    import torch
+    mine = torch.tensor([float(row[k]) for k in keys], dtype=torch.float64, device=tensor_device)
+    everyone = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(everyone, mine)
+    return [dict(zip(keys, t.tolist()), rank=r) for r, t in enumerate(everyone)]
