@@ -37,6 +37,13 @@ $(LIBDIR)/libturbo_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
+# the same engine with the device-side tuning / profiling knobs of tb_config.reserved[0] compiled in (scripts/*_probe.py;
+# select it with TURBO_HIP_LIB=turbo_amd/lib/libturbo_hip_tuning.so)
+tuning: $(LIBDIR)/libturbo_hip_tuning.so
+$(LIBDIR)/libturbo_hip_tuning.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DTB_TUNING -shared -o $@ $(HIP_SRC)
+
 $(BINDIR)/turbo: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libturbo_front.so $(LIBDIR)/libturbo_hip.so
 	@mkdir -p $(BINDIR)
 	$(CXX) $(CXXFLAGS) -fPIE -o $@ $(HOST_SRC) -Iinclude -L$(LIBDIR) -lturbo_front -lturbo_hip -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(ROCM)/lib -lpthread
@@ -56,4 +63,4 @@ clean:
 	rm -rf $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all front hip cli oracle sanitize clean
+.PHONY: all front hip cli oracle sanitize clean tuning

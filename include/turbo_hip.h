@@ -92,6 +92,7 @@ typedef struct {
                                            propagator order instead of sorting the records by class; 0x400000 count slice
                                            runs instead of propagator evaluations; 0x800000 test aid: keep the store every workgroup stopped
                                            on (tb_session_debug_last_store); 0x1000000 no work stealing between linked GPUs (A/B runs, tests);
+                                           0x2000000 do not propagate the root at session creation (every subproblem re-derives its fixpoint, as in r01);
                                        [1] capacity of the event change list; [2] cap on workgroups per CU */
 } tb_config;
 

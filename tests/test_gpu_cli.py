@@ -98,24 +98,27 @@ def test_bench_contract_line():
     """bench.py prints ONE JSON line with the keys the driver and the judge read."""
     import json
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--event-steps", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--side-steps", "1",
                         "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-                "config", "roofline", "cpu_baseline"):
+                "config", "roofline", "cpu_baseline", "nodes_per_sec", "wac1_mode", "balance"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "propagations/s" and d["dtype"] == "int32" and "workload" in d["config"] and "model" not in d["config"]
     roof = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, key
-    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    # the store of the headline workload is LDS resident: the fraction is priced against the level that serves the bytes, never above 1
+    assert roof["bound"] == "lds" and 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert 0 < roof["records_from_l2"]["frac"] <= 1
     cpu = d["cpu_baseline"]
-    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and "sample" in cpu
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and "sample" in cpu and "dfs_sample" in cpu
     assert d["value"] > 10 * cpu["value"]  # north star: >= 10x the CPU propagation rate
+    assert d["wac1_mode"]["propagations_per_sec"] > 10 * cpu["value"]
 
 
 @pytest.mark.parametrize("fp", ["wac1", "event"])

@@ -13,7 +13,8 @@ import numpy as np
 from .frontend import ITV_DTYPE, PROP_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libturbo_hip.so")
+# TURBO_HIP_LIB: another build of the same engine (e.g. `make tuning`: -DTB_TUNING, the in-kernel profiling knobs compiled in)
+LIB_PATH = os.environ.get("TURBO_HIP_LIB") or os.path.join(_HERE, "lib", "libturbo_hip.so")
 
 TB_PINF = 2**31 - 1
 TB_NINF = -(2**31)

@@ -137,6 +137,8 @@ struct DevProblem {
   int rank, world;         // this device among the GPUs of the search
   int chunk_log2;          // k of the block-cyclic partition
   int poll_ticks;          // wall-clock ticks between two polls of the mailbox / peer cell
+  int root_fixpoint;       // 1: root_store is already the fixpoint of the root node (propagated once at session creation): the first
+                           // node of every subproblem then has nothing to propagate instead of re-deriving it from the caller's store
   int steal;               // 1: a device whose queue is empty takes work from its peers (0: tb_config.reserved[0] & 0x1000000, A/B runs and tests)
   unsigned long long cut_nodes;       // 0 = none
   unsigned long long cut_nodes_total; // 0 = none: budget of all workgroups of all GPUs together

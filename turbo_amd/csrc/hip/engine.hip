@@ -157,7 +157,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   if (auto_threads && !event && !cfg.only_global_memory && (n_props + 63) / 64 >= 32) {
     // A store that leaves room for a single workgroup per CU: make that workgroup wide enough to fill the CU's 16 wave
     // slots (trains15 simplified, 87 KB store: 4.9e6 -> 7.3e6 nodes/s going from 512 to 1024 threads).
-    const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64) * 8) + align16((size_t)((n_props + 63) / 64 + 31) / 32 * 4) + 4096 + SH_BYTES;
+    const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64) * 8) + dirty_region_bytes(((n_props + 63) / 64 + 31) / 32) + 4096 + SH_BYTES;
     while (T < 1024 && slab <= (size_t)caps.lds_per_cu && std::min<size_t>((size_t)caps.lds_per_cu / slab, (size_t)(2048 / T)) * (size_t)(T / 64) < 16) T *= 2;
   }
   if (T != 64 && T != 128 && T != 256 && T != 512 && T != 1024) return fail(TB_ERR_INVALID, "threads_per_block must be 64, 128, 256, 512 or 1024");
@@ -173,7 +173,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   // event-driven fixpoint always live in LDS (an overflowing change list falls back to running every slice)
   p.chg_cap = std::min(1024, std::max(64, n_vars / 4));
   if (cfg.reserved[1] > 0) p.chg_cap = cfg.reserved[1];  // tuning knob
-  const size_t dirty_b = align16((size_t)dirty_words * 4) + align16((size_t)p.chg_cap * 4);
+  const size_t dirty_b = dirty_region_bytes(dirty_words) + align16((size_t)p.chg_cap * 4);
   const size_t store_b = align16((size_t)vext * 8) + dirty_b, props_b = (size_t)n_slices * 64 * 16;  // padded to whole slices
   const size_t fixed = SH_BYTES;
   int bpc_max = std::min(cfg.reserved[2] > 0 ? cfg.reserved[2] : 8, 2048 / T);  // 32 waves per CU (reserved[2]: tuning knob)
@@ -767,6 +767,33 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&s->ev_start));
   HIP_TRY(hipEventCreate(&s->ev_stop));
+  // Propagate the root once, here: every subproblem starts from the root (barebones:665-672), and its fixpoint -- the same
+  // for all of them -- would otherwise be re-derived from the caller's store at the first node of each of the 2^d dives.
+  // The node is still visited and counted; it just finds nothing left to do.  (tb_config.reserved[0] & 0x2000000 keeps the
+  // caller's store, for A/B runs.)  An inconsistent root is left as it is: every subproblem then fails on its first node.
+  if (n_props > 0 && !(s->cfg.reserved[0] & 0x2000000)) {
+    const bool event = s->cfg.fixpoint == 2, opt = event ? plan.compact != 0 : s->cfg.entailed_prop_removal != 0;
+    int occ = 0;
+    if ((rc = prepare_kernel(false, plan.mem_kind, plan.tmax, event, opt, plan.shared_bytes, plan.threads, &occ)) != TB_OK) return rc;
+    PropagateOut* d_out = nullptr;
+    if ((rc = s->bufs.alloc(&d_out, 1)) != TB_OK) return rc;
+    std::vector<unsigned char> original(std::max<size_t>(16, VX * 8));
+    HIP_TRY(hipMemcpy(original.data(), d_root, VX * 8, hipMemcpyDeviceToHost));
+    DevProblem Q = P;
+    Q.deadline_ticks = 0;
+    if (s->cfg.timeout_ms != 0) {
+      long long now = 0;
+      if ((rc = device_now(s->stream, s->d_now, &now)) != TB_OK) return rc;
+      Q.deadline_ticks = now + (long long)s->cfg.timeout_ms * (long long)s->caps.wall_khz;
+    }
+    DISPATCH_KERNEL(propagate_kernel, plan.mem_kind, plan.tmax, event, opt, <<<dim3(1), dim3(plan.threads), plan.shared_bytes, s->stream>>>(Q, d_root, d_out, 1));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    PropagateOut o;
+    HIP_TRY(hipMemcpy(&o, d_out, sizeof(o), hipMemcpyDeviceToHost));
+    if (o.failed == 0) P.root_fixpoint = 1;
+    else HIP_TRY(hipMemcpy(d_root, original.data(), VX * 8, hipMemcpyHostToDevice));
+  }
   *out = s.release();
   return TB_OK;
 }
@@ -869,13 +896,14 @@ int tb_session_start(tb_session* s) {
   if (!s->armed && (rc = tb_session_arm(s)) != TB_OK) return rc;
   s->armed = false;
   s->finished = false;
-  // in-kernel watchdog: device wall clock "now" + timeout + 2 s of margin
-  s->P.deadline_ticks = 0;
-  if (s->cfg.timeout_ms != 0) {
-    long long now = 0;
-    if ((rc = device_now(s->stream, s->d_now, &now)) != TB_OK) return rc;
-    s->P.deadline_ticks = now + (long long)(s->cfg.timeout_ms + 2000) * (long long)s->caps.wall_khz;
-  }
+  // device wall clock "now": the first poll of the mailbox is due immediately (Ctrl::next_poll holds the low 32 bits of a
+  // tick and is compared by signed difference), and the in-kernel watchdog fires at now + timeout + 2 s of margin
+  long long now = 0;
+  if ((rc = device_now(s->stream, s->d_now, &now)) != TB_OK) return rc;
+  const unsigned first_poll = (unsigned)now;
+  HIP_TRY(hipMemcpyAsync(&s->P.ctrl->next_poll, &first_poll, sizeof(first_poll), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->P.deadline_ticks = s->cfg.timeout_ms != 0 ? now + (long long)(s->cfg.timeout_ms + 2000) * (long long)s->caps.wall_khz : 0;
   s->t_start = std::chrono::steady_clock::now();
   HIP_TRY(hipEventRecord(s->ev_start, s->stream));
   const LaunchPlan& plan = s->plan;

@@ -330,6 +330,10 @@ __device__ __forceinline__ bool mark_head(unsigned* dirty, const int4 h, int sel
   if (h.x >= 2 && h.z != self) mark_slice(dirty, h.z);
   return h.x > 2;
 }
+// does the head name a slice other than `self`?
+__device__ __forceinline__ bool has_other_reader(const int4 h, int self) {
+  return (h.x >= 1 && h.y != self) || (h.x >= 2 && h.z != self) || h.x > 2;
+}
 // Cooperative walk of the long adjacency lists of the lanes in `mask` (wave-uniform): one lane at a time is
 // broadcast, the 64 lanes stride over its list -- a high-degree variable costs one memory latency.
 __device__ __forceinline__ void mark_rest(const DevProblem& P, unsigned* dirty, unsigned long long mask, const int4 h, int self) {
@@ -345,144 +349,142 @@ __device__ __forceinline__ void mark_rest(const DevProblem& P, unsigned* dirty, 
   }
 }
 
-// Claim one dirty slice (all lanes return the same id, -1 if the bitmap is empty).  The 64 lanes read 64
-// bitmap words at once; `rot` spreads the waves over the words so that claims rarely collide.
-__device__ __forceinline__ int claim_slice(const EventState& es, int rot) {
-  const int lane = threadIdx.x & 63;
-  for (int base = 0; base < es.words; base += 64) {
-    const int wi = base + lane;
-    unsigned w = wi < es.words ? __hip_atomic_load(&es.dirty[wi], TB_RLX, TB_WG) : 0u;
-    unsigned long long nz = __ballot(w != 0);
-    while (nz) {
-      const unsigned long long r = rot ? ((nz >> rot) | (nz << (64 - rot))) : nz;
-      const int l = (__builtin_ctzll(r) + rot) & 63;
-      const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)w, l);
-      const int b = __builtin_ctz(word);
-      unsigned old = 0;
-      if (lane == 0) old = __hip_atomic_fetch_and(&es.dirty[base + l], ~(1u << b), TB_RLX, TB_WG);
-      old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-      if ((old >> b) & 1u) return (base + l) * 32 + b;
-      if (lane == l) w = old & ~(1u << b);  // somebody else was faster: refresh our copy of that word
-      nz = __ballot(w != 0);
-    }
-  }
-  return -1;
-}
+// LDS bytes of the two dirty bitmaps of the event-driven fixpoint (current round, next round).
+__host__ __device__ inline size_t dirty_region_bytes(int dirty_words) { return (((size_t)dirty_words * 8 + 15) / 16) * 16; }
 
-// Event-driven WAC1 (tb_config.fixpoint = 2), asynchronous: waves claim dirty slices, iterate each to its
-// local fixpoint, and mark the slices that read a narrowed variable IMMEDIATELY; there is no barrier between
-// "sweeps" -- a propagation chain advances at the latency of one slice run, not of one workgroup barrier.
-// A wave leaves when the bitmap is empty and no wave is running a slice (`busy`): a wave that marks slices
-// re-scans the bitmap itself, so no work is lost when others have already left.
+// Event-driven WAC1 (tb_config.fixpoint = 2): rounds over a dirty set of 64-propagator slices.
+//
+// Round r runs every slice whose bit is set in bitmap r & 1; a slice that narrows a variable marks the OTHER slices
+// reading it in bitmap (r + 1) & 1; one s_barrier separates two rounds; the fixpoint is reached when a round marks
+// nothing.  Slices are owned statically: slice s belongs to wave s % nw, which clears the bit before it loads the
+// domains and is the only one to do so -- no claim, no atomic with a return value, no "busy" counter.
+// Why rounds: a slice fed by many variables that one long cascade narrows one after the other (the terms of the
+// objective's sum, each read by the same element-constraint slice) is run once per round in which any of them moved,
+// not once per narrowing as it is when idle waves grab marked slices immediately (measured on wordpress7_500 with 4
+// waves: 250 slice runs per node asynchronously against 82 with a single wave).
+// Inside a round a wave still iterates each slice to its local fixpoint (WAC1), and a slice sees the narrowings other
+// waves have already made in the same round.
 template <bool C>
 __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
                                               const EventState& es, ThreadCounters& tc, bool& all_entailed) {
-  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = T >> 6;
   const int n = P.n_props, W = es.words, S = P.n_slices;
   const bool prof = (knobs(P) & 0x10000) != 0;
   long long tp0 = 0;
   if (tid == 0 && prof) tp0 = wall_clock64();
-  // ---- initial dirty set: everything, or the slices of the variables changed since the last fixpoint
+  // ---- initial dirty set (bitmap 0): everything, or the slices of the variables changed since the last fixpoint
   const int cnt = ld(&sh.chg_count[0]);
   const bool all = ld(&sh.ev_all) != 0 || cnt > es.cap;
   // Entailed-slice removal: a slice whose 64 propagators were all entailed when it last ran stays entailed in the
-  // whole subtree (domains only shrink), so it is dropped when claimed.  The bytes are undefined before the root pass.
+  // whole subtree (domains only shrink), so it is dropped when its turn comes.  The bytes are undefined before the root pass.
   const bool root_pass = ld(&sh.ev_all) != 0;
   const bool drop_entailed = !root_pass && !(knobs(P) & 0x20000);
+  unsigned* bm0 = es.dirty;
   if (all) {
     for (int i = tid; i < W; i += T) {
       const int left = S - i * 32;
-      es.dirty[i] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+      bm0[i] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
     }
     if (root_pass) for (int s = tid; s < S; s += T) es.unent[s] = 1;  // nothing is known to be entailed yet
   } else {
     for (int e = tid; e < cnt; e += T) {  // one lane per entry; long lists are finished cooperatively
       const int4 h = P.adj_head[es.list[e]];
-      (void)mark_head(es.dirty, h, -1);
+      (void)mark_head(bm0, h, -1);
     }
     for (int e0 = wave * 64; e0 < cnt; e0 += T) {
       const int e = e0 + lane;
       int4 h = make_int4(0, 0, 0, 0);
       if (e < cnt) h = P.adj_head[es.list[e]];
-      mark_rest(P, es.dirty, __ballot(h.x > 2), h, -1);
+      mark_rest(P, bm0, __ballot(h.x > 2), h, -1);
     }
   }
-  if (tid == 0) { st(&sh.unent[0], 0); st(&sh.flag[0], (all ? S : cnt) > 0 ? 1 : 0); }
+  if (tid == 0) { st(&sh.unent[0], 0); st(&sh.flag[0], 0); st(&sh.flag[1], 0); }
   __syncthreads();
   if (tid == 0) { st(&sh.ev_all, 0); st(&sh.chg_count[0], 0); }
-  const int ran = ld(&sh.flag[0]);
   if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_WAIT_CPU] += t - tp0; tp0 = t; }  // profiling: seeding
-  // ---- asynchronous worklist
-  const int rot = (wave * 64) / nw;
-  int idle_spins = 0;
-  for (;;) {
-    if (ld(&sh.bot) || ld(&sh.abort)) break;
-    const int s = claim_slice(es, rot);
-    if (s < 0) {
-      if (ld(&sh.ev_busy) == 0) break;  // nothing to run and nobody can create work any more
-      __builtin_amdgcn_s_sleep(4);
-      if ((++idle_spins & 1023) == 0 && lane == 0 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
-      continue;
-    }
-    if (lane == 0) (void)__hip_atomic_fetch_add(&sh.ev_busy, 1, TB_RLX, TB_WG);
-    const int i = s * 64 + lane;
-    const bool act = i < n;
-    const int4 pr = props[i];  // the record array is padded to whole slices with idle records
-    if (drop_entailed && es.unent[s] == 0) {
-      if (lane == 0) (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG);
-      continue;
-    }
-    int wave_iters = 0;  // wave-uniform
-    for (;;) {
-      bool ch = false, un_i = false;
-      int nar = 0;
-      apply<true, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, 0, &nar);
-      ++wave_iters;
-      if (!__any(ch)) {
-        // The byte only ever goes 1 -> 0 below a node (entailment is monotone): two waves may run the same slice
-        // at once, and the one that read the older domains must not overwrite the verdict of the other.
-        if (!__any(un_i) && lane == 0) es.unent[s] = 0;
-        break;
+  // ---- rounds
+  // bits of a bitmap word owned by this wave: slices s with s % nw == wave (nw divides 32)
+  unsigned own = 0;
+  for (int b = wave; b < 32; b += nw) own |= 1u << b;
+  int rounds = 0;
+  unsigned wave_iters_total = 0;  // wave-uniform
+  for (;; ++rounds) {
+    const int k = rounds % 3;
+    unsigned* cur = es.dirty + (rounds & 1) * W;
+    unsigned* nxt = es.dirty + ((rounds + 1) & 1) * W;
+    bool marked = false;  // wave-uniform: this wave marked something for the next round
+    for (int base = 0; base < W; base += 64) {
+      const int wi = base + lane;
+      const unsigned w = wi < W ? (__hip_atomic_load(&cur[wi], TB_RLX, TB_WG) & own) : 0u;
+      if (w != 0) (void)__hip_atomic_fetch_and(&cur[wi], ~w, TB_RLX, TB_WG);  // mine, cleared before any domain is loaded
+      unsigned long long nz = __ballot(w != 0);
+      while (nz) {
+        const int l = __builtin_ctzll(nz);
+        nz &= nz - 1;
+        unsigned word = (unsigned)__builtin_amdgcn_readlane((int)w, l);
+        while (word) {
+          const int s = (base + l) * 32 + __builtin_ctz(word);
+          word &= word - 1;
+          if (ld(&sh.bot) | ld(&sh.abort)) { word = 0; nz = 0; break; }  // the node failed in another wave
+          if (drop_entailed && es.unent[s] == 0) continue;
+          const int i = s * 64 + lane;
+          const bool act = i < n;
+          const int4 pr = props[i];  // the record array is padded to whole slices with idle records
+          unsigned wave_iters = 0;   // wave-uniform
+          for (;;) {
+            bool ch = false, un_i = false;
+            int nar = 0;
+            apply<true, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, 0, &nar);
+            ++wave_iters;
+            if (!__any(ch)) {
+              // The byte only ever goes 1 -> 0 below a node (entailment is monotone).
+              if (!__any(un_i) && lane == 0) es.unent[s] = 0;
+              break;
+            }
+            // successors: every other slice reading a variable I narrowed (operands private to this slice are
+            // flagged at pack time in word0 and skipped) runs in the next round
+            nar &= ~(pr.x >> 8) & 7;
+            int4 hx = make_int4(0, 0, 0, 0), hy = hx, hz = hx;
+            if (nar & 1) hx = P.adj_head[pr.y];
+            if (nar & 2) hy = P.adj_head[pr.z];
+            if (nar & 4) hz = P.adj_head[pr.w];
+            const bool lx = (nar & 1) && mark_head(nxt, hx, s);
+            const bool ly = (nar & 2) && mark_head(nxt, hy, s);
+            const bool lz = (nar & 4) && mark_head(nxt, hz, s);
+            const unsigned long long mx = __ballot(lx), my = __ballot(ly), mz = __ballot(lz);
+            if (mx) mark_rest(P, nxt, mx, hx, s);
+            if (my) mark_rest(P, nxt, my, hy, s);
+            if (mz) mark_rest(P, nxt, mz, hz, s);
+            marked |= __any(((nar & 1) && has_other_reader(hx, s)) || ((nar & 2) && has_other_reader(hy, s)) || ((nar & 4) && has_other_reader(hz, s)));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (ld(&sh.bot)) break;
+            if ((wave_iters % WAVE_WATCHDOG_PERIOD) == 0) {  // watchdog inside the wave-local loop (see fixpoint)
+              if (lane == 0 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
+              if (ld(&sh.abort)) break;
+            }
+          }
+          wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;  // 0x400000: count slice runs (profiling)
+        }
       }
-      // successors: every other slice reading a variable I narrowed (operands private to this slice are
-      // flagged at pack time in word0 and skipped)
-      // (the adjacency heads are not kept across iterations: they would be live through the evaluation, and the
-      //  kernel is register bound)
-      nar &= ~(pr.x >> 8) & 7;
-      int4 hx = make_int4(0, 0, 0, 0), hy = hx, hz = hx;
-      if (nar & 1) hx = P.adj_head[pr.y];
-      if (nar & 2) hy = P.adj_head[pr.z];
-      if (nar & 4) hz = P.adj_head[pr.w];
-      // my narrowings are performed (global-memory atomics included) before any slice I mark can be claimed
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      const bool lx = (nar & 1) && mark_head(es.dirty, hx, s);
-      const bool ly = (nar & 2) && mark_head(es.dirty, hy, s);
-      const bool lz = (nar & 4) && mark_head(es.dirty, hz, s);
-      const unsigned long long mx = __ballot(lx), my = __ballot(ly), mz = __ballot(lz);
-      if (mx) mark_rest(P, es.dirty, mx, hx, s);
-      if (my) mark_rest(P, es.dirty, my, hy, s);
-      if (mz) mark_rest(P, es.dirty, mz, hz, s);
-      if (ld(&sh.bot)) break;
-      if ((wave_iters % WAVE_WATCHDOG_PERIOD) == 0) {  // watchdog inside the wave-local loop (see fixpoint)
-        if (lane == 0 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
-        if (ld(&sh.abort)) break;
-      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my marks are visible before I stop being busy
-    if (lane == 0) { (void)__hip_atomic_fetch_add(&sh.ev_busy, -1, TB_RLX, TB_WG); tc.deductions += 64ull * (unsigned)((knobs(P) & 0x400000) ? 1 : wave_iters); }  // 0x400000: count slice runs (profiling)
+    if (lane == 0 && marked) st(&sh.flag[k], 1);
+    if (tid == 0) {
+      st(&sh.flag[(k + 1) % 3], 0);
+      if ((rounds & 255) == 255 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
+    }
+    __syncthreads();  // the narrowings and the marks of this round are visible to everybody
+    if (!ld(&sh.flag[k]) || ld(&sh.bot) || ld(&sh.abort)) break;
   }
-  if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += t - tp0; tp0 = t; }  // profiling: own work
-  __syncthreads();
-  if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_GPU2CPU] += t - tp0; }  // profiling: waiting for the last wave
-  // leave the bitmap empty for the next node (it is not after a failure), reduce the entailment bytes
-  for (int i = tid; i < W; i += T) es.dirty[i] = 0;
-  if (tid == 0) st(&sh.ev_busy, 0);
+  if (lane == 0) tc.deductions += 64ull * wave_iters_total;
+  if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += t - tp0; tp0 = t; }  // profiling: rounds
+  // leave both bitmaps empty for the next node (they are not after a failure), reduce the entailment bytes
+  for (int i = tid; i < 2 * W; i += T) es.dirty[i] = 0;
   bool un = false;
   for (int s = tid; s < S; s += T) un |= es.unent[s] != 0;
   if (__any(un) && lane == 0) st(&sh.unent[0], 1);
   __syncthreads();
   all_entailed = !ld(&sh.unent[0]);
-  return ran;
+  return rounds + 1;
 }
 
 // ---- small helpers -------------------------------------------------------------------------------
@@ -960,11 +962,11 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   // LDS: [control block][store slab: vext x 8 B (STORE/TCN_SHARED)][dirty bitmap][change list][bytecodes (TCN_SHARED)]
   const int VX = P.vext;
   const size_t store_bytes = MEM >= TB_MEM_STORE_SHARED ? (((size_t)VX * 8 + 15) / 16) * 16 : 0;
-  const size_t dirty_bytes = (((size_t)P.dirty_words * 4 + 15) / 16) * 16 + (((size_t)P.chg_cap * 4 + 15) / 16) * 16;
+  const size_t dirty_bytes = dirty_region_bytes(P.dirty_words) + (((size_t)P.chg_cap * 4 + 15) / 16) * 16;
   int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : P.g_store + (size_t)b * VX;
   EventState es;
   es.dirty = reinterpret_cast<unsigned*>(smem + SH_BYTES + store_bytes);
-  es.list = reinterpret_cast<int*>(smem + SH_BYTES + store_bytes + (((size_t)P.dirty_words * 4 + 15) / 16) * 16);
+  es.list = reinterpret_cast<int*>(smem + SH_BYTES + store_bytes + dirty_region_bytes(P.dirty_words));
   es.unent = reinterpret_cast<unsigned char*>(store) + P.unent_off;
   es.words = P.dirty_words; es.cap = P.chg_cap;
   const int4* props = P.props;
@@ -973,7 +975,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     for (int i = tid; i < P.n_slices * 64; i += blockDim.x) lprops[i] = P.props[i];  // whole slices: the array is padded
     props = lprops;
   }
-  for (int i = tid; i < P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
+  for (int i = tid; i < 2 * P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
   int2* snap = P.g_snap + (size_t)b * P.snapshot_levels * VX;
   int2* best_store = P.g_best + (size_t)b * VX;
   Decision* dec = P.g_dec + (size_t)b * P.max_depth;
@@ -998,8 +1000,8 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   while (sh.has_work && !sh.stop) {
     // C. restore the root
     copy_store(store, P.root_store, VX);  // the root slab is laid out like a workgroup slab
-    if (EVENT && tid == 0) sh.ev_all = 1;  // the root store is not a fixpoint: every slice runs once
-    if (RM) {  // nothing is known to be entailed yet (the event fixpoint does this in its root pass)
+    if (EVENT && tid == 0) { sh.ev_all = P.root_fixpoint ? 0 : 1; sh.chg_count[0] = 0; }  // a root that is not a fixpoint: every slice runs once
+    if (RM && !P.root_fixpoint) {  // nothing is known to be entailed yet (the event fixpoint does this in its root pass)
       __syncthreads();
       for (int s = tid; s < P.n_slices; s += blockDim.x) es.unent[s] = 1;
     }
@@ -1171,12 +1173,12 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
   const int tid = threadIdx.x, V = P.n_vars;
   const int VX = P.vext;
   const size_t store_bytes = MEM >= TB_MEM_STORE_SHARED ? (((size_t)VX * 8 + 15) / 16) * 16 : 0;
-  const size_t dirty_bytes = (((size_t)P.dirty_words * 4 + 15) / 16) * 16 + (((size_t)P.chg_cap * 4 + 15) / 16) * 16;
+  const size_t dirty_bytes = dirty_region_bytes(P.dirty_words) + (((size_t)P.chg_cap * 4 + 15) / 16) * 16;
   EventState es;
   es.dirty = reinterpret_cast<unsigned*>(smem + SH_BYTES + store_bytes);
-  es.list = reinterpret_cast<int*>(smem + SH_BYTES + store_bytes + (((size_t)P.dirty_words * 4 + 15) / 16) * 16);
+  es.list = reinterpret_cast<int*>(smem + SH_BYTES + store_bytes + dirty_region_bytes(P.dirty_words));
   es.words = P.dirty_words; es.cap = P.chg_cap;
-  for (int i = tid; i < P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
+  for (int i = tid; i < 2 * P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
   const int4* props = P.props;
   if (MEM == TB_MEM_TCN_SHARED) {
     int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + store_bytes + dirty_bytes);
