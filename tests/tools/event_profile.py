@@ -163,6 +163,15 @@ def main():
             for v in (x, y, z):
                 rel_lb[v].add(s_); rel_ub[v].add(s_)
     S = (P + 63) // 64
+    names = ["HEAVY", "ADD", "MIN", "MAX", "EQ_R", "LEQ_R", "EQ_T", "EQ_F", "LEQ_T", "LEQ_F", "mixed"]
+    slice_class = []
+    for s_ in range(S):
+        cl = set()
+        for i in range(s_ * 64, min(P, s_ * 64 + 64)):
+            d = tcn.store[int(props[i]["x"])]
+            cl.add(class_of(int(props[i]["op"]), bool(d["lb"] == d["ub"]), int(d["lb"])))
+        slice_class.append(cl.pop() if len(cl) == 1 else 10)
+    iter_hist = collections.defaultdict(lambda: [0, 0])  # class -> [iterations, runs]
 
     def run_slices2(store, seeds, filtered):
         """seeds: list of (var, lb_changed, ub_changed).  Returns (runs, useful runs, evaluations, failed, slices with only irrelevant events)."""
@@ -187,10 +196,14 @@ def main():
         while q:
             s_ = q.popleft(); dirty[s_] = False; entd[s_] = False
             runs += 1
+            if not filtered:
+                iter_hist[slice_class[s_]][1] += 1
             lo, hi = s_ * 64, min(P, s_ * 64 + 64)
             first = True
             while True:
                 evals += 64
+                if not filtered:
+                    iter_hist[slice_class[s_]][0] += 1
                 ch = {}
                 for i in range(lo, hi):
                     p = props[i]
@@ -275,6 +288,11 @@ def main():
         print(f"{label}: {int(sel.sum())} nodes, {int(sum(1 for x, s_ in zip(rows, sel) if s_ and x[7]))} failed | unfiltered: {q[:, 0].mean():.0f} slice runs/node "
               f"({q[:, 1].mean():.0f} useful), {q[:, 2].mean():.0f} evaluations | bound-event filter: {q[:, 3].mean():.0f} runs ({q[:, 4].mean():.0f} useful), "
               f"{q[:, 5].mean():.0f} evaluations, {q[:, 6].mean():.0f} slices left entailment-dirty")
+
+
+
+    for c, (it, rn) in sorted(iter_hist.items(), key=lambda kv: -kv[1][0]):
+        print(f"   {names[c]:6s}: {rn / len(rows):7.1f} runs/node, {it / len(rows):7.1f} iterations/node, {it / max(1, rn):.2f} iterations per run")
 
 
 if __name__ == "__main__":

@@ -227,6 +227,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
 
 int validate_network(int32_t n_vars, const tb_itv* store, int32_t n_props, const tb_prop* props) {
   if (n_vars < 0 || n_props < 0 || (n_vars > 0 && !store) || (n_props > 0 && !props)) return fail(TB_ERR_INVALID, "null or negative-sized network");
+  if ((size_t)n_props > (size_t)0xfffe * 64) return fail(TB_ERR_INVALID, "more than 4 194 176 propagators: slice ids are 16 bits wide in the adjacency records");
   for (int32_t i = 0; i < n_props; ++i) {
     const tb_prop& p = props[i];
     if (p.op < 0 || p.op >= TB_NUM_OPS) return fail(TB_ERR_INVALID, "propagator " + std::to_string(i) + ": unknown operator");
@@ -269,7 +270,7 @@ Adjacency build_adjacency(int32_t n_vars, int32_t n_props, const tb_prop* props,
 // Rewrite the caller's bytecodes into the engine's packed records (propagators.hpp): word0 = pack-time class |
 // "operand is read by no other slice" bits 8-10 | original op << 12 | classes present in the 64-record slice << 16.
 std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::vector<char>& is_const, const std::vector<int>& value,
-                             const Adjacency& adj) {
+                             const Adjacency& adj, int n_int) {
   // padded to whole slices with idle records (never narrow, always entailed): the kernels may load any lane of a slice
   std::vector<int4> out(((size_t)n_props + 63) / 64 * 64, make_int4(K_LEQ_T, 0, 0, 0));
   for (int32_t base = 0; base < n_props; base += 64) {
@@ -289,7 +290,62 @@ std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::v
       }
       out[(size_t)i] = make_int4(cls | (priv << 8) | (p.op << 12), p.x, p.y, p.z);
     }
-    for (int32_t i = base; i < end; ++i) out[(size_t)i].x |= present << 16;  // same mask in the 64 records of a slice
+    // operand kinds of the slice (bits 26-31, two per operand): 1 all integer variables, 2 all Booleans of the COMPACT layout
+    // (internal id >= n_int), 3 all constants, 0 mixed.  The event kernels have dedicated runs for the commonest signatures.
+    unsigned kinds = 0;
+    for (int k = 0; k < 3; ++k) {
+      int seen = 0;
+      for (int32_t i = base; i < end; ++i) {
+        const int v = k == 0 ? props[i].x : (k == 1 ? props[i].y : props[i].z);
+        seen |= is_const[(size_t)v] ? 4 : (v >= n_int ? 2 : 1);
+      }
+      const unsigned code = seen == 1 ? 1u : (seen == 2 ? 2u : (seen == 4 ? 3u : 0u));
+      kinds |= code << (2 * k);
+    }
+    for (int32_t i = base; i < end; ++i) out[(size_t)i].x |= (present << 16) | (int)(kinds << 26);  // same in the 64 records of a slice
+  }
+  return out;
+}
+
+// Per variable: 32-byte adjacency record of the event-driven fixpoint (device_types.hpp: DevProblem::head13) + overflow list.
+void pack_head13(const Adjacency& adj, std::vector<int4>* heads, std::vector<int>* rest) {
+  const size_t V = adj.lists.size();
+  std::vector<unsigned short> hw(std::max<size_t>(1, V) * 16, 0);
+  rest->clear();
+  for (size_t v = 0; v < V; ++v) {
+    const std::vector<int>& l = adj.lists[v];
+    unsigned short* h = hw.data() + v * 16;
+    h[0] = (unsigned short)std::min<size_t>(l.size(), 0xffffu);
+    for (size_t k = 0; k < l.size() && k < 13; ++k) h[1 + k] = (unsigned short)l[k];
+    const unsigned off = (unsigned)rest->size();
+    h[14] = (unsigned short)(off & 0xffffu); h[15] = (unsigned short)(off >> 16);
+    for (size_t k = 13; k < l.size(); ++k) rest->push_back(l[k]);
+  }
+  if (rest->empty()) rest->push_back(0);
+  heads->resize(std::max<size_t>(1, V) * 2);
+  std::memcpy(heads->data(), hw.data(), heads->size() * sizeof(int4));
+}
+
+// Successor slices of each record's operands for the event-driven fixpoint (device_types.hpp: DevProblem::succ).
+std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacency& adj) {
+  std::vector<int4> out(((size_t)n_props + 63) / 64 * 64, make_int4(-1, -1, -1, 0));
+  const bool ids_fit = ((size_t)n_props + 63) / 64 < 0xffffu;
+  for (int32_t i = 0; i < n_props; ++i) {
+    const int s = i / 64;
+    const int vs[3] = {props[i].x, props[i].y, props[i].z};
+    unsigned packed[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    int lng = 0;
+    for (int k = 0; k < 3; ++k) {
+      unsigned o[2] = {0xffffu, 0xffffu};
+      int n = 0;
+      bool too_many = false;
+      for (int t : adj.lists[(size_t)vs[k]]) {
+        if (t == s) continue;
+        if (n < 2 && ids_fit) o[n++] = (unsigned)t; else too_many = true;
+      }
+      if (too_many) lng |= 1 << k; else packed[k] = (o[1] << 16) | o[0];
+    }
+    out[(size_t)i] = make_int4((int)packed[0], (int)packed[1], (int)packed[2], lng);
   }
   return out;
 }
@@ -551,8 +607,23 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     for (int v = 0; v < n_vars; ++v) { is_const[(size_t)lay.perm[(size_t)v]] = c0[(size_t)v]; value[(size_t)lay.perm[(size_t)v]] = v0[(size_t)v]; }
     const InternalNet net = to_internal(lay, stores_inout, n_props, props, (cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL);
     const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const);
-    const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj);
+    const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj, lay.n_int);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
+    {
+      const std::vector<int4> succ = pack_succ(n_props, net.props.data(), adj);
+      int4* d_succ = nullptr;
+      if ((rc = bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
+      if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
+      P.succ = d_succ;
+      std::vector<int4> h13; std::vector<int> r13;
+      pack_head13(adj, &h13, &r13);
+      int4* d_h13 = nullptr; int* d_r13 = nullptr;
+      if ((rc = bufs.alloc(&d_h13, h13.size())) != TB_OK) return rc;
+      if ((rc = bufs.alloc(&d_r13, r13.size())) != TB_OK) return rc;
+      HIP_TRY(hipMemcpy(d_h13, h13.data(), h13.size() * sizeof(int4), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(d_r13, r13.data(), r13.size() * sizeof(int), hipMemcpyHostToDevice));
+      P.head13 = d_h13; P.adj13 = d_r13;
+    }
     int4* d_head = nullptr; int* d_adj = nullptr;
     if ((rc = bufs.alloc(&d_head, adj.heads.size())) != TB_OK) return rc;
     if ((rc = bufs.alloc(&d_adj, adj.rest.size())) != TB_OK) return rc;
@@ -680,8 +751,23 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     std::vector<int> value;
     find_constants(n_vars, 1, net.store.data(), &is_const, &value);  // constants = singleton variables of the root store
     const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const);
-    const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj);
+    const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj, lay.n_int);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
+    {
+      const std::vector<int4> succ = pack_succ(n_props, net.props.data(), adj);
+      int4* d_succ = nullptr;
+      if ((rc = s->bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
+      if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
+      s->P.succ = d_succ;
+      std::vector<int4> h13; std::vector<int> r13;
+      pack_head13(adj, &h13, &r13);
+      int4* d_h13 = nullptr; int* d_r13 = nullptr;
+      if ((rc = s->bufs.alloc(&d_h13, h13.size())) != TB_OK) return rc;
+      if ((rc = s->bufs.alloc(&d_r13, r13.size())) != TB_OK) return rc;
+      HIP_TRY(hipMemcpy(d_h13, h13.data(), h13.size() * sizeof(int4), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(d_r13, r13.data(), r13.size() * sizeof(int), hipMemcpyHostToDevice));
+      s->P.head13 = d_h13; s->P.adj13 = d_r13;
+    }
     int4* d_head = nullptr; int* d_adj = nullptr;
     if ((rc = s->bufs.alloc(&d_head, adj.heads.size())) != TB_OK) return rc;
     if ((rc = s->bufs.alloc(&d_adj, adj.rest.size())) != TB_OK) return rc;

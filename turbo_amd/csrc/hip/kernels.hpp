@@ -80,17 +80,24 @@ __device__ __forceinline__ void st(int* p, int v) { __hip_atomic_store(p, v, TB_
 template <bool C>
 __device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v) {
   Itv d;
-  if (C && v >= ni) {
-    const int b = v - ni;
-    const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store + ni) + (b >> 4), TB_RLX, TB_WG);
-    const unsigned bits = (w >> ((b & 15) * 2)) & 3u;
-    d.lb = (int)(bits & 1u);
-    d.ub = 1 - (int)(bits >> 1);
+  if (!C) {
+    const long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + v), TB_RLX, TB_WG);
+    d.lb = (int)(raw & 0xffffffffll);
+    d.ub = (int)(raw >> 32);
     return d;
   }
-  long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + v), TB_RLX, TB_WG);
-  d.lb = (int)(raw & 0xffffffffll);
-  d.ub = (int)(raw >> 32);
+  // COMPACT: one 8-byte load whatever the kind of the variable -- an interval, or the pair of Boolean words holding its
+  // two bits (the Boolean words start at store + ni, which is 8-byte aligned) -- and selects instead of branches: the
+  // three gathers of a propagator are in flight together and a wave with mixed operands does not serialise them.
+  const bool isb = v >= ni;
+  const int b = v - ni;
+  const int idx = isb ? ni + (b >> 5) : v;
+  const long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + idx), TB_RLX, TB_WG);
+  const int lo = (int)(raw & 0xffffffffll), hi = (int)(raw >> 32);
+  const unsigned word = (unsigned)(((b >> 4) & 1) ? hi : lo);
+  const unsigned bits = (word >> ((b & 15) * 2)) & 3u;
+  d.lb = isb ? (int)(bits & 1u) : lo;
+  d.ub = isb ? 1 - (int)(bits >> 1) : hi;
   return d;
 }
 template <bool C>
@@ -142,7 +149,7 @@ template <bool EVENT, bool C>
 __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store, const int ni, int* bot, bool& changed, bool& un, ThreadCounters& tc, const int dbg = 0,
                                       int* narrowed = nullptr) {
   const int w0 = pr.x;
-  if (dbg == 0 && (__builtin_amdgcn_readfirstlane(w0) >> 16) == (1 << K_LEQ_T)) {
+  if (dbg == 0 && ((__builtin_amdgcn_readfirstlane(w0) >> 16) & CLASS_SET_MASK) == (1 << K_LEQ_T)) {
     // Class-pure slice of `y <= z` (x is the constant true; two thirds of wordpress7_500 after sorting the records by
     // class): two gathers instead of three, no candidate bookkeeping for x, one comparison per bound.
     const Itv Y = load_dom<C>(store, ni, pr.z), Z = load_dom<C>(store, ni, pr.w);
@@ -330,6 +337,13 @@ __device__ __forceinline__ bool mark_head(unsigned* dirty, const int4 h, int sel
   if (h.x >= 2 && h.z != self) mark_slice(dirty, h.z);
   return h.x > 2;
 }
+// Up to two successor slices packed with the record (16-bit ids, 0xffff = none).  True when something was marked.
+__device__ __forceinline__ bool mark_packed(unsigned* dirty, unsigned packed) {
+  const unsigned s0 = packed & 0xffffu, s1 = packed >> 16;
+  if (s0 != 0xffffu) mark_slice(dirty, (int)s0);
+  if (s1 != 0xffffu) mark_slice(dirty, (int)s1);
+  return s0 != 0xffffu;
+}
 // does the head name a slice other than `self`?
 __device__ __forceinline__ bool has_other_reader(const int4 h, int self) {
   return (h.x >= 1 && h.y != self) || (h.x >= 2 && h.z != self) || h.x > 2;
@@ -348,6 +362,122 @@ __device__ __forceinline__ void mark_rest(const DevProblem& P, unsigned* dirty, 
     }
   }
 }
+
+// ---- event-driven fixpoint: one slice run ------------------------------------------------------------------------------
+//
+// A run iterates the 64 propagators of a slice to their local fixpoint.  `eval(ch, un, nar)` is one iteration: it
+// narrows the store, reports whether this lane changed something (ch), whether its propagator is not entailed (un) and
+// which operands it narrowed (nar: bit 0 x, 1 y, 2 z).  Everything that does not change between two iterations -- LDS
+// addresses, bit positions, the value of a constant operand -- is computed once per run by the caller of run_slice.
+struct RunEnv {
+  const DevProblem& P;
+  BlockShared& sh;
+  unsigned* nxt;            // dirty bitmap of the next round
+  unsigned char* unent;     // per-slice "some propagator is not entailed" bytes
+  int s;                    // the slice
+};
+
+// Mark every slice reading variable v, except `self`, from the variable's 32-byte adjacency record (DevProblem::head13:
+// halfword 0 = number of reader slices, halfwords 1-13 = the first thirteen, halfwords 14-15 = offset of the others in
+// DevProblem::adj).  One L2 round trip whatever the degree up to 13; returns true when the list is longer.
+__device__ __forceinline__ bool mark_var(const DevProblem& P, unsigned* dirty, int v, int self, bool on, int& deg_out, int& off_out) {
+  int4 a = make_int4(0, 0, 0, 0), b = a;
+  if (on) { a = P.head13[2 * (size_t)v]; b = P.head13[2 * (size_t)v + 1]; }
+  const unsigned w[8] = {(unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w, (unsigned)b.x, (unsigned)b.y, (unsigned)b.z, (unsigned)b.w};
+  const int deg = (int)(w[0] & 0xffffu);
+#pragma unroll
+  for (int j = 0; j < 13; ++j) {
+    const int hw = j + 1;
+    const int t = (int)((hw & 1) ? (w[hw >> 1] >> 16) : (w[hw >> 1] & 0xffffu));
+    if (j < deg && t != self) mark_slice(dirty, t);
+  }
+  deg_out = deg;
+  off_out = (int)w[7];  // halfwords 14 (low) and 15 (high)
+  return deg > 13;
+}
+// the tail of the lists longer than 13, cooperatively: one lane at a time is broadcast, the 64 lanes stride over its list
+__device__ __forceinline__ void mark_tail(const DevProblem& P, unsigned* dirty, unsigned long long mask, int deg, int off, int self) {
+  const int lane = threadIdx.x & 63;
+  while (mask) {
+    const int l = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    const int d = __builtin_amdgcn_readlane(deg, l), o = __builtin_amdgcn_readlane(off, l);
+    for (int j = lane; j < d - 13; j += 64) {
+      const int t = P.adj13[o + j];
+      if (t != self) mark_slice(dirty, t);
+    }
+  }
+}
+
+template <class Eval>
+__device__ __forceinline__ unsigned run_slice(const RunEnv& E, const int4 pr, const int4 sc, bool& marked, Eval&& eval) {
+  const DevProblem& P = E.P;
+  const int lane = threadIdx.x & 63, s = E.s;
+  unsigned wave_iters = 0;  // wave-uniform
+  int nar_all = 0;          // operands this lane narrowed during the run
+  for (;;) {
+    bool ch = false, un_i = false;
+    int nar = 0;
+    eval(ch, un_i, nar);
+    ++wave_iters;
+    if (!__any(ch)) {
+      // The byte only ever goes 1 -> 0 below a node (entailment is monotone).
+      if (!__any(un_i) && lane == 0) E.unent[s] = 0;
+      break;
+    }
+    nar_all |= nar;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (ld(&E.sh.bot)) break;
+    if ((wave_iters % WAVE_WATCHDOG_PERIOD) == 0) {  // watchdog inside the wave-local loop (see fixpoint)
+      if (lane == 0 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&E.sh.abort, 1);
+      if (ld(&E.sh.abort)) break;
+    }
+  }
+  // Successors, once per run: every OTHER slice reading a variable this run narrowed runs in the next round (in a round
+  // based fixpoint nobody looks at the marks before the barrier, so they need not follow each narrowing).  Up to two
+  // successors per operand travel with the record (P.succ: 16-bit slice ids, 0xffff = none) and need no memory access;
+  // the others come from the variable's 32-byte adjacency record, one L2 round trip for the whole wave.
+  nar_all &= ~(pr.x >> 8) & 7;  // operands private to this slice are flagged at pack time
+  if (__any(nar_all != 0)) {
+    bool did = false;
+    if ((nar_all & 1) && !(sc.w & 1)) did |= mark_packed(E.nxt, (unsigned)sc.x);
+    if ((nar_all & 2) && !(sc.w & 2)) did |= mark_packed(E.nxt, (unsigned)sc.y);
+    if ((nar_all & 4) && !(sc.w & 4)) did |= mark_packed(E.nxt, (unsigned)sc.z);
+    const int lng = nar_all & sc.w;
+    if (__any(lng != 0)) {
+      int dx = 0, dy = 0, dz = 0, ox = 0, oy = 0, oz = 0;
+      const bool tx = mark_var(P, E.nxt, pr.y, s, (lng & 1) != 0, dx, ox);
+      const bool ty = mark_var(P, E.nxt, pr.z, s, (lng & 2) != 0, dy, oy);
+      const bool tz = mark_var(P, E.nxt, pr.w, s, (lng & 4) != 0, dz, oz);
+      const unsigned long long mx = __ballot(tx), my = __ballot(ty), mz = __ballot(tz);
+      if (mx) mark_tail(P, E.nxt, mx, dx, ox, s);
+      if (my) mark_tail(P, E.nxt, my, dy, oy, s);
+      if (mz) mark_tail(P, E.nxt, mz, dz, oz, s);
+      did |= lng != 0;
+    }
+    marked |= __any(did);
+  }
+  return wave_iters;
+}
+
+// A 2-bit Boolean of the COMPACT layout as an LDS word address and a bit position (computed once per run).
+struct BoolRef { unsigned* word; int shift; };
+__device__ __forceinline__ BoolRef bool_ref(int2* store, int ni, int v, bool act) {
+  const int b = act ? v - ni : 0;  // idle lanes of a padded slice look at the first Boolean and touch nothing
+  BoolRef r;
+  r.word = reinterpret_cast<unsigned*>(store + ni) + (b >> 4);
+  r.shift = (b & 15) * 2;
+  return r;
+}
+__device__ __forceinline__ unsigned bool_bits(const BoolRef r) { return (__hip_atomic_load(r.word, TB_RLX, TB_WG) >> r.shift) & 3u; }
+__device__ __forceinline__ void bool_or(const BoolRef r, unsigned bits) { (void)__hip_atomic_fetch_or(r.word, bits << r.shift, TB_RLX, TB_WG); }
+
+// Slice signatures with a dedicated run (word0 >> 16 of the slice's records: class set | operand kinds << 10; see pack_props).
+// kinds per operand: 0 mixed, 1 integer variables, 2 Booleans of the COMPACT layout, 3 constants.
+constexpr unsigned kinds(unsigned kx, unsigned ky, unsigned kz) { return (kx | (ky << 2) | (kz << 4)) << 10; }
+constexpr unsigned KEY_LEQT_BB = (1u << K_LEQ_T) | kinds(3, 2, 2);   // b1 <= b2 (implication between two Booleans)
+constexpr unsigned KEY_EQR_BIC = (1u << K_EQ_R) | kinds(2, 1, 3);    // b = (y = k)
+constexpr unsigned KEY_LEQR_BIC = (1u << K_LEQ_R) | kinds(2, 1, 3);  // b = (y <= k)
 
 // LDS bytes of the two dirty bitmaps of the event-driven fixpoint (current round, next round).
 __host__ __device__ inline size_t dirty_region_bytes(int dirty_words) { return (((size_t)dirty_words * 8 + 15) / 16) * 16; }
@@ -417,54 +547,109 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       const int wi = base + lane;
       const unsigned w = wi < W ? (__hip_atomic_load(&cur[wi], TB_RLX, TB_WG) & own) : 0u;
       if (w != 0) (void)__hip_atomic_fetch_and(&cur[wi], ~w, TB_RLX, TB_WG);  // mine, cleared before any domain is loaded
+      // my slices of this round, one after the other; the records of the next one are fetched while the current one runs
       unsigned long long nz = __ballot(w != 0);
-      while (nz) {
-        const int l = __builtin_ctzll(nz);
-        nz &= nz - 1;
-        unsigned word = (unsigned)__builtin_amdgcn_readlane((int)w, l);
-        while (word) {
-          const int s = (base + l) * 32 + __builtin_ctz(word);
-          word &= word - 1;
-          if (ld(&sh.bot) | ld(&sh.abort)) { word = 0; nz = 0; break; }  // the node failed in another wave
-          if (drop_entailed && es.unent[s] == 0) continue;
-          const int i = s * 64 + lane;
-          const bool act = i < n;
-          const int4 pr = props[i];  // the record array is padded to whole slices with idle records
-          unsigned wave_iters = 0;   // wave-uniform
-          for (;;) {
-            bool ch = false, un_i = false;
-            int nar = 0;
-            apply<true, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, 0, &nar);
-            ++wave_iters;
-            if (!__any(ch)) {
-              // The byte only ever goes 1 -> 0 below a node (entailment is monotone).
-              if (!__any(un_i) && lane == 0) es.unent[s] = 0;
-              break;
-            }
-            // successors: every other slice reading a variable I narrowed (operands private to this slice are
-            // flagged at pack time in word0 and skipped) runs in the next round
-            nar &= ~(pr.x >> 8) & 7;
-            int4 hx = make_int4(0, 0, 0, 0), hy = hx, hz = hx;
-            if (nar & 1) hx = P.adj_head[pr.y];
-            if (nar & 2) hy = P.adj_head[pr.z];
-            if (nar & 4) hz = P.adj_head[pr.w];
-            const bool lx = (nar & 1) && mark_head(nxt, hx, s);
-            const bool ly = (nar & 2) && mark_head(nxt, hy, s);
-            const bool lz = (nar & 4) && mark_head(nxt, hz, s);
-            const unsigned long long mx = __ballot(lx), my = __ballot(ly), mz = __ballot(lz);
-            if (mx) mark_rest(P, nxt, mx, hx, s);
-            if (my) mark_rest(P, nxt, my, hy, s);
-            if (mz) mark_rest(P, nxt, mz, hz, s);
-            marked |= __any(((nar & 1) && has_other_reader(hx, s)) || ((nar & 2) && has_other_reader(hy, s)) || ((nar & 4) && has_other_reader(hz, s)));
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            if (ld(&sh.bot)) break;
-            if ((wave_iters % WAVE_WATCHDOG_PERIOD) == 0) {  // watchdog inside the wave-local loop (see fixpoint)
-              if (lane == 0 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
-              if (ld(&sh.abort)) break;
-            }
+      unsigned word = 0;
+      int wl = 0;
+      auto next_slice = [&]() -> int {  // wave-uniform iteration over the set bits of the words held by the lanes
+        while (word == 0) {
+          if (nz == 0) return -1;
+          wl = __builtin_ctzll(nz);
+          nz &= nz - 1;
+          word = (unsigned)__builtin_amdgcn_readlane((int)w, wl);
+        }
+        const int b = __builtin_ctz(word);
+        word &= word - 1;
+        return (base + wl) * 32 + b;
+      };
+      int s = next_slice();
+      int4 pr = idle_record(), sc = make_int4(-1, -1, -1, 0);
+      if (s >= 0) { pr = props[s * 64 + lane]; sc = P.succ[s * 64 + lane]; }  // the arrays are padded to whole slices
+      while (s >= 0) {
+        const int s_next = next_slice();
+        int4 pr_next = pr, sc_next = sc;
+        if (s_next >= 0) { pr_next = props[s_next * 64 + lane]; sc_next = P.succ[s_next * 64 + lane]; }
+        if (ld(&sh.bot) | ld(&sh.abort)) break;  // the node failed in another wave
+        if (!(drop_entailed && es.unent[s] == 0)) {
+          const bool act = s * 64 + lane < n;
+          const RunEnv E{P, sh, nxt, es.unent, s};
+          const unsigned key = (unsigned)__builtin_amdgcn_readfirstlane(pr.x) >> 16;  // wave-uniform: scalar dispatch
+          unsigned wave_iters;
+          unsigned run_writes = 0;  // per lane, folded into the 64-bit counter once per run
+          if (C && key == KEY_LEQT_BB) {
+            // y <= z on two Booleans, straight on their 2-bit encodings (bit 0: lb raised to 1, bit 1: ub lowered to 0):
+            // z.ub = 0 forces y.ub = 0, y.lb = 1 forces z.lb = 1; entailed once y.ub = 0 or z.lb = 1.
+            const BoolRef ry = bool_ref(store, P.n_int, pr.z, act), rz = bool_ref(store, P.n_int, pr.w, act);
+            wave_iters = run_slice(E, pr, sc, marked, [&](bool& ch, bool& un_i, int& nar) {
+              const unsigned yb = bool_bits(ry), zb = bool_bits(rz);
+              const bool ny = (zb & 2u) && !(yb & 2u), nz = (yb & 1u) && !(zb & 1u);
+              const bool empty_in = yb == 3u || zb == 3u;
+              if (__any(act & (ny | nz | empty_in))) {
+                if (act) {
+                  if (empty_in | ((yb & 1u) && (zb & 2u))) st(&sh.bot, 1);
+                  if (!empty_in) {
+                    if (ny) bool_or(ry, 2u);
+                    if (nz) bool_or(rz, 1u);
+                    run_writes += (unsigned)ny + (unsigned)nz;
+                    ch = ny | nz;
+                    nar = ((int)ny << 1) | ((int)nz << 2);
+                  }
+                }
+              }
+              un_i = act & !((yb & 2u) || (zb & 1u));
+            });
+          } else if (C && (key == KEY_EQR_BIC || key == KEY_LEQR_BIC)) {
+            // b = (y = k) / b = (y <= k): Boolean truth variable, integer y, constant k (read once per run)
+            const bool is_eq = key == KEY_EQR_BIC;
+            const BoolRef rx = bool_ref(store, P.n_int, pr.y, act);
+            const int yv = act ? pr.z : 0;
+            const int kc = load_dom<C>(store, P.n_int, act ? pr.w : 0).lb;
+            wave_iters = run_slice(E, pr, sc, marked, [&](bool& ch, bool& un_i, int& nar) {
+              const unsigned xb = bool_bits(rx);
+              const Itv Y = load_dom<false>(store, P.n_int, yv);
+              const bool t = (xb & 1u) != 0, f = (xb & 2u) != 0, u = !t && !f;
+              const bool empty_in = (xb == 3u) | (Y.lb > Y.ub);
+              bool set1, set0, ent;
+              int nyl = Y.lb, nyu = Y.ub;
+              if (is_eq) {  // wave-uniform
+                const bool disjoint = Y.ub < kc || Y.lb > kc, same = Y.lb == Y.ub && Y.lb == kc;
+                set1 = u && same; set0 = u && disjoint;
+                nyl = t ? imax(Y.lb, kc) : ((f && Y.lb == kc) ? sat_add(kc, 1) : Y.lb);
+                nyu = t ? imin(Y.ub, kc) : ((f && Y.ub == kc) ? sat_sub(kc, 1) : Y.ub);
+                ent = (t && same) || (f && disjoint);
+              } else {
+                const bool le = Y.ub <= kc, gt = Y.lb > kc;
+                set1 = u && le; set0 = u && gt;
+                nyu = t ? imin(Y.ub, kc) : Y.ub;
+                nyl = f ? imax(Y.lb, add_lo(kc, 1)) : Y.lb;
+                ent = (t && le) || (f && gt);
+              }
+              const bool cyl = nyl != Y.lb, cyu = nyu != Y.ub;
+              if (__any(act & (set1 | set0 | cyl | cyu | empty_in))) {
+                if (act) {
+                  if (empty_in | (nyl > nyu)) st(&sh.bot, 1);  // (a narrowed constant is an empty y: same condition)
+                  if (!empty_in) {
+                    if (set1 | set0) bool_or(rx, set1 ? 1u : 2u);
+                    if (cyl) raise_lb<false>(store, P.n_int, yv, nyl);
+                    if (cyu) lower_ub<false>(store, P.n_int, yv, nyu);
+                    const int kw = (int)(set1 | set0) + (int)cyl + (int)cyu;
+                    run_writes += (unsigned)kw;
+                    ch = kw != 0;
+                    nar = (int)(set1 | set0) | ((int)(cyl | cyu) << 1);
+                  }
+                }
+              }
+              un_i = act & !ent;
+            });
+          } else {
+            wave_iters = run_slice(E, pr, sc, marked, [&](bool& ch, bool& un_i, int& nar) {
+              apply<true, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, 0, &nar);
+            });
           }
+          tc.writes += run_writes;
           wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;  // 0x400000: count slice runs (profiling)
         }
+        s = s_next; pr = pr_next; sc = sc_next;
       }
     }
     if (lane == 0 && marked) st(&sh.flag[k], 1);

@@ -146,6 +146,8 @@ enum Class : int {
   K_LEQ_T = 8, K_LEQ_F = 9  // y <= z, y > z
 };
 
+constexpr int CLASS_SET_MASK = 0x3ff;  // word0 bits 16-25: the classes present in the slice; bits 26-31: operand kinds (kernels.hpp)
+
 __host__ __device__ inline int class_of(int op, bool x_const, int x_value) {
   switch (op) {
     case OP_ADD: return K_ADD;
@@ -160,7 +162,7 @@ __host__ __device__ inline int class_of(int op, bool x_const, int x_value) {
 __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y, const Itv Z) {
   Cand c;
   int cls = w0 & 0xff;
-  const int present = __builtin_amdgcn_readfirstlane(w0) >> 16;
+  const int present = (__builtin_amdgcn_readfirstlane(w0) >> 16) & CLASS_SET_MASK;
   bool ent = false;
   // Class-pure slices (the records are sorted by class, engine.hip: to_internal): the commonest classes get a body
   // without any per-lane class predicate.
