@@ -62,6 +62,7 @@ class TbStats(C.Structure):
         for k, _ in self._fields_:
             if k == "reserved":
                 d["why_not_exhaustive"] = int(self.reserved[0])
+                d["debug_slice"] = int(self.reserved[1])
                 continue
             v = getattr(self, k)
             d[k] = list(v) if hasattr(v, "__len__") else v

@@ -302,7 +302,15 @@ std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::v
       const unsigned code = seen == 1 ? 1u : (seen == 2 ? 2u : (seen == 4 ? 3u : 0u));
       kinds |= code << (2 * k);
     }
-    for (int32_t i = base; i < end; ++i) out[(size_t)i].x |= (present << 16) | (int)(kinds << 26);  // same in the 64 records of a slice
+    // bit 11: no truth variable x occurs twice in the slice (the joint evaluation of `b_i = (y = k_i)` slices is then complete in one pass)
+    int distinct_x = 1;
+    {
+      std::vector<int> xs;
+      for (int32_t i = base; i < end; ++i) xs.push_back(props[i].x);
+      std::sort(xs.begin(), xs.end());
+      if (std::adjacent_find(xs.begin(), xs.end()) != xs.end()) distinct_x = 0;
+    }
+    for (int32_t i = base; i < end; ++i) out[(size_t)i].x |= (present << 16) | (int)(kinds << 26) | (distinct_x << 11);  // same in the 64 records of a slice
   }
   return out;
 }
@@ -437,7 +445,7 @@ struct InternalNet {
   std::vector<tb_itv> store;  // first store of the batch, internal order
   std::vector<tb_prop> props;
 };
-InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, const tb_prop* props, bool keep_order) {
+InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, const tb_prop* props, bool keep_order, bool event = false) {
   InternalNet n;
   n.store.resize((size_t)L.n_vars);
   for (int v = 0; v < L.n_vars; ++v) n.store[(size_t)L.perm[(size_t)v]] = store[v];
@@ -460,7 +468,17 @@ InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, c
     const bool xc = d.lb == d.ub && d.lb != TB_NINF && d.lb != TB_PINF;
     return class_of(q.op, xc, xc ? d.lb : 0) * 16 + q.op;
   };
-  std::stable_sort(n.props.begin(), n.props.end(), [&](const tb_prop& a, const tb_prop& c) { return key(a) < key(c); });
+  // Event-driven fixpoint: inside the reified comparisons against a constant (`b = (y = k)`, `b = (y <= k)`: the channelling of
+  // element constraints) the records of one variable y are made contiguous, so that a slice holds few distinct y and the
+  // kernel can evaluate the lanes sharing a variable jointly (kernels.hpp: KEY_EQR_BIC).
+  auto key2 = [&](const tb_prop& q) -> long long {
+    const long long k1 = key(q);
+    if (!event || (q.op != TB_EQ && q.op != TB_LEQ)) return k1 << 32;
+    const tb_itv dz = n.store[(size_t)q.z];
+    const bool zc = dz.lb == dz.ub && dz.lb != TB_NINF && dz.lb != TB_PINF;
+    return (k1 << 32) | (zc ? (long long)q.y + 1 : 0);
+  };
+  std::stable_sort(n.props.begin(), n.props.end(), [&](const tb_prop& a, const tb_prop& c) { return key2(a) < key2(c); });
   return n;
 }
 
@@ -605,7 +623,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     std::vector<int> v0, value((size_t)n_vars);
     find_constants(n_vars, n_stores, stores_inout, &c0, &v0);
     for (int v = 0; v < n_vars; ++v) { is_const[(size_t)lay.perm[(size_t)v]] = c0[(size_t)v]; value[(size_t)lay.perm[(size_t)v]] = v0[(size_t)v]; }
-    const InternalNet net = to_internal(lay, stores_inout, n_props, props, (cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL);
+    const InternalNet net = to_internal(lay, stores_inout, n_props, props, (cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL, cfg.fixpoint == 2 && !(cfg.reserved[0] & 0x8000000));
     const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const);
     const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj, lay.n_int);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -746,7 +764,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   if ((rc = s->bufs.alloc(&d_off, (size_t)n_strats + 1)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_sv, (size_t)total_svars)) != TB_OK) return rc;
   {
-    const InternalNet net = to_internal(lay, root_store, n_props, props, (s->cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL);
+    const InternalNet net = to_internal(lay, root_store, n_props, props, (s->cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL, s->cfg.fixpoint == 2 && !(s->cfg.reserved[0] & 0x8000000));
     std::vector<char> is_const;
     std::vector<int> value;
     find_constants(n_vars, 1, net.store.data(), &is_const, &value);  // constants = singleton variables of the root store
@@ -1120,6 +1138,10 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
     st.depth_max = std::max(st.depth_max, x.depth_max);
     st.exhaustive = st.exhaustive && x.exhaustive;
     st.reserved[0] |= x.why;
+    if (st.reserved[1] == 0) st.reserved[1] = x.pad_why;
+    if ((x.why & 0x300) && x.dbg[1] != 0 && s->cfg.verbose)
+      std::fprintf(stderr, "%% self-check: workgroup %zu node %d slice %d lane %d word0 %#x x=%d [%d,%d] y=%d [%d,%d] z=%d [%d,%d]\n", b, x.dbg[11], x.pad_why - 1, x.dbg[0],
+                   (unsigned)x.dbg[1], x.dbg[2], x.dbg[5], x.dbg[6], x.dbg[3], x.dbg[7], x.dbg[8], x.dbg[4], x.dbg[9], x.dbg[10]);
     for (int t = 0; t < TB_NUM_TIMERS; ++t)
       if (t != TB_T_FIRST_BLOCK_IDLE && t != TB_T_LATEST_BEST_OBJ_FOUND) st.timers_ns[t] += (int64_t)((double)x.timers[t] * ns_per_tick);
     st.cumulative_time_block_ns += (int64_t)((double)x.timers[TB_T_FIRST_BLOCK_IDLE] * ns_per_tick);

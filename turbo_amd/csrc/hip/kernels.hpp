@@ -420,12 +420,12 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, const int4 pr, co
     int nar = 0;
     eval(ch, un_i, nar);
     ++wave_iters;
+    nar_all |= nar;  // (a cooperative body reaches the slice's fixpoint in one pass: it narrows, reports nar and no change)
     if (!__any(ch)) {
       // The byte only ever goes 1 -> 0 below a node (entailment is monotone).
       if (!__any(un_i) && lane == 0) E.unent[s] = 0;
       break;
     }
-    nar_all |= nar;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (ld(&E.sh.bot)) break;
     if ((wave_iters % WAVE_WATCHDOG_PERIOD) == 0) {  // watchdog inside the wave-local loop (see fixpoint)
@@ -598,6 +598,68 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               }
               un_i = act & !((yb & 2u) || (zb & 1u));
             });
+          } else if (C && key == KEY_EQR_BIC && !(knobs(P) & 0x4000000)) {
+            // Channelling propagators b_i = (y = k_i) -- the index of an element constraint against its positions, its value
+            // against the table.  Evaluated one by one, a false b_i only strips k_i when it sits exactly on a bound of y, so
+            // a run of m excluded values costs m wave iterations.  Here the lanes that share a variable y (the records are
+            // sorted by y: a slice holds one to three groups) compute the fixpoint of their rules jointly: the bounds walk over
+            // the excluded values with ballots (scalar work, no memory traffic), then every b_i outside the new bounds
+            // becomes false and, if y is assigned, its b_i true.  Same fixpoint, one pass, no confirmation pass.
+            const BoolRef rx = bool_ref(store, P.n_int, pr.y, act);
+            const int kc = load_dom<C>(store, P.n_int, act ? pr.w : 0).lb;
+            const bool single_pass = ((__builtin_amdgcn_readfirstlane(pr.x) >> 11) & 1) != 0;
+            wave_iters = run_slice(E, pr, sc, marked, [&](bool& ch, bool& un_i, int& nar) {
+              const unsigned xb = bool_bits(rx);
+              const bool t = act && (xb & 1u), f = act && (xb & 2u), u = act && xb == 0u;
+              bool bad = __any(act && xb == 3u);
+              un_i = false;
+              for (unsigned long long rem = __ballot(act); rem && !bad;) {
+                const int leader = __builtin_ctzll(rem);
+                const int yv = __builtin_amdgcn_readlane(pr.z, leader);
+                const bool in = act && pr.z == yv;  // my group
+                rem &= ~__ballot(in);
+                const Itv Y = load_dom<false>(store, P.n_int, yv);
+                int lb = __builtin_amdgcn_readfirstlane(Y.lb), ub = __builtin_amdgcn_readfirstlane(Y.ub);
+                const int lb0 = lb, ub0 = ub;
+                for (unsigned long long tm = __ballot(in && t); tm; tm &= tm - 1) {  // y = k for every true b (normally at most one)
+                  const int k = __builtin_amdgcn_readlane(kc, __builtin_ctzll(tm));
+                  lb = lb > k ? lb : k; ub = ub < k ? ub : k;
+                }
+                while (lb <= ub && __any(in && f && kc == lb)) lb = sat_add(lb, 1);  // excluded values on the bounds
+                while (lb <= ub && __any(in && f && kc == ub)) ub = sat_sub(ub, 1);
+                if (lb > ub) { bad = true; break; }
+                const bool outside = kc < lb || kc > ub, hit = lb == ub && kc == lb;
+                const bool set0 = in && u && outside, set1 = in && u && hit;
+                // There is no confirmation pass to notice that ANOTHER wave emptied a domain I narrow in the same round (two slices
+                // of one y walking its bounds towards each other, a b made true elsewhere while I make it false): look at what
+                // my own atomics left behind.
+                if (set0 | set1) {
+                  const unsigned mine = set1 ? 1u : 2u;
+                  const unsigned before = (__hip_atomic_fetch_or(rx.word, mine << rx.shift, TB_RLX, TB_WG) >> rx.shift) & 3u;
+                  if ((before | mine) == 3u) st(&sh.bot, 1);
+                }
+                const bool cyl = lb != lb0, cyu = ub != ub0;  // wave-uniform
+                const bool writer = (threadIdx.x & 63) == leader;
+                if (writer && (cyl | cyu)) {
+                  if (cyl) raise_lb<false>(store, P.n_int, yv, lb);
+                  if (cyu) lower_ub<false>(store, P.n_int, yv, ub);
+                  run_writes += (unsigned)cyl + (unsigned)cyu;
+                  const Itv now = load_dom<false>(store, P.n_int, yv);
+                  if (now.lb > now.ub) st(&sh.bot, 1);
+                }
+                run_writes += (unsigned)(set0 | set1);
+                nar |= (int)(set0 | set1) | ((writer && (cyl | cyu)) ? 2 : 0);
+                un_i |= in && !(((t || set1) && hit) || ((f || set0) && outside));
+              }
+              if (bad) {
+                if (lane == 0) st(&sh.bot, 1);
+                un_i = act;
+                nar = 0;
+              }
+              // When no truth variable occurs twice in the slice (word0 bit 11, pack_props) the joint fixpoint is reached and no
+              // confirmation pass is needed; otherwise a b made false for one lane may still have to act through another one.
+              ch = single_pass ? false : nar != 0;
+            });
           } else if (C && (key == KEY_EQR_BIC || key == KEY_LEQR_BIC)) {
             // b = (y = k) / b = (y <= k): Boolean truth variable, integer y, constant k (read once per run)
             const bool is_eq = key == KEY_EQR_BIC;
@@ -647,7 +709,12 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             });
           }
           tc.writes += run_writes;
-          wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;  // 0x400000: count slice runs (profiling)
+          {  // profiling (tuning build): 0x400000 counts slice runs instead of iterations; bits 28-31 = 1 + class to count only that class (11 = mixed slices)
+            const int want = (knobs(P) >> 28) & 15;
+            const unsigned cm = key & CLASS_SET_MASK;
+            const int cls_of_slice = (cm & (cm - 1)) ? 10 : __builtin_ctz(cm | 0x400u);
+            if (want == 0 || want - 1 == cls_of_slice) wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;
+          }
         }
         s = s_next; pr = pr_next; sc = sc_next;
       }
@@ -1055,6 +1122,42 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
   const bool aborted = ld(&sh.abort) != 0;
   const bool failed = !aborted && ld(&sh.bot) != 0;
   if (aborted) all_entailed = false;
+#ifdef TB_TUNING
+  // Self-check of the event-driven fixpoint (tuning build, tb_config.reserved[0] & 0x1000000): after a node that did not fail,
+  // every propagator is evaluated once more with the generic rules, without writing.  BlockStats::why bit 8: some propagator
+  // could still narrow (a wake-up was missed); bit 9: a slice is flagged all-entailed but one of its propagators is not.
+  // pad_why keeps 1 + the first offending slice.
+  if (EVENT && (knobs(P) & 0x1000000) && !failed && !aborted) {
+    const int lane = threadIdx.x & 63;
+    for (int s = threadIdx.x >> 6; s < P.n_slices; s += blockDim.x >> 6) {
+      const int i = s * 64 + lane;
+      const bool act = i < P.n_props;
+      const int4 pr = props[i];
+      const Itv X = load_dom<C>(store, P.n_int, pr.y), Y = load_dom<C>(store, P.n_int, pr.z), Z = load_dom<C>(store, P.n_int, pr.w);
+      const Cand c = evaluate_packed(pr.x, X, Y, Z);
+      const bool narrows = act && ((c.xl > X.lb) | (c.xu < X.ub) | (c.yl > Y.lb) | (c.yu < Y.ub) | (c.zl > Z.lb) | (c.zu < Z.ub));
+      const bool un = act && !c.ent;
+      int bad = 0;
+      if (__any(narrows)) bad |= 1 << 8;
+      if (__any(un) && es.unent[s] == 0) bad |= 1 << 9;
+      if (bad) {
+        int zero = 0;
+        bool first = false;
+        if (lane == 0) {
+          (void)__hip_atomic_fetch_or(&sh.bs.why, bad, TB_RLX, TB_WG);
+          first = __hip_atomic_compare_exchange_strong(&sh.bs.pad_why, &zero, s + 1, TB_RLX, TB_RLX, TB_WG);
+        }
+        first = __builtin_amdgcn_readfirstlane((int)first) != 0;
+        const unsigned long long m = __ballot(narrows);
+        if (first && m && lane == __builtin_ctzll(m)) {
+          int* d = sh.bs.dbg;
+          d[0] = lane; d[1] = pr.x; d[2] = pr.y; d[3] = pr.z; d[4] = pr.w; d[5] = X.lb; d[6] = X.ub; d[7] = Y.lb; d[8] = Y.ub; d[9] = Z.lb; d[10] = Z.ub; d[11] = (int)sh.bs.nodes;
+        }
+      }
+    }
+    __syncthreads();
+  }
+#endif
   if (tid == 0) {
     const long long t1 = wall_clock64();
     bs.timers[TB_T_FIXPOINT] += t1 - t0;
