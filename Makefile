@@ -21,7 +21,7 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter
 # wave-aggregation prologue (mbcnt/bcnt) around each of them costs the event loop 3-5 %
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter -Wno-bitwise-instead-of-logical -mllvm -amdgpu-atomic-optimizer-strategy=None $(EXTRA_HIPFLAGS)
 
-all: front hip cli oracle
+all: front hip tuning cli oracle
 
 front: $(LIBDIR)/libturbo_front.so
 hip: $(LIBDIR)/libturbo_hip.so

@@ -30,7 +30,8 @@ struct Options {
   uint64_t subproblems_factor = 300;          // -subfactor
   uint64_t stack_kb = 0;                      // -stack (accepted, meaningless here: no device stack frames)
   Arch arch = Arch::BAREBONES;                // GPU build default (config.hpp:84-90)
-  Fixpoint fixpoint = Fixpoint::WAC1;         // GPU build default (config.hpp:91-97)
+  Fixpoint fixpoint = Fixpoint::EVENT;        // the engine's event-driven WAC1: same fixpoint at every node, hence the same tree, as the
+                                              // reference's GPU default `-fp wac1` (config.hpp:91-97), which stays available like `-fp ac1`
   uint64_t wac1_threshold = 0;
   uint64_t seed = 0;
   std::string eps_var_order = "default", eps_value_order = "default";
