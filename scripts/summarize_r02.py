@@ -3,7 +3,7 @@
 
 Per fixpoint mode of the default bench workload, per launch of tb::solve_kernel (averages over the profiled launches):
   launch_ms                     average duration in the counter passes (rocprofv3 dispatch timestamps)
-  valu_busy / salu_busy / lds_busy   SQ_ACTIVE_INST_{VALU,SCA,LDS} / (1024 SIMDs x GRBM_GUI_ACTIVE / 4): the counters are in quad-cycles
+  valu_busy / salu_busy / lds_busy   SQ_ACTIVE_INST_{VALU,SCA,LDS} / (1024 SIMDs x (GRBM_GUI_ACTIVE / 8 XCDs) / 4): the counters are in quad-cycles
   wait_any_share, wait_inst_any_share   SQ_WAIT_ANY, SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (waves parked at s_waitcnt / s_barrier; issue stalls)
   valu_per_64_propagations ...   SQ_INSTS_* / (num_deductions / 64), num_deductions from the bench line of the same pass
   hbm_bytes_per_launch          (2 x FETCH_SIZE + WRITE_SIZE) x 1024: MI355X_MICROARCH.md's gfx950 correction for wide coalesced reads -- the
@@ -71,7 +71,7 @@ for fp in ("event", "wac1"):
     line = bench_line(f"{fp}_sq1.log")
     if not sq1 or not grbm:
         continue
-    gui = grbm.get("GRBM_GUI_ACTIVE", 0.0)
+    gui = grbm.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # the counter is summed over the 8 XCDs
     cap = 1024.0 * gui / 4.0  # quad-cycles available to the 1024 SIMDs during one launch
     launch_ms = sq1.get("_launch_ms")
     props = line.get("balance", {}).get("propagations")
@@ -93,7 +93,9 @@ for fp in ("event", "wac1"):
         hbm = (2.0 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024.0
         ms = fetch.get("_launch_ms") or launch_ms
         r.update({"FETCH_SIZE_KiB": fetch["FETCH_SIZE"], "WRITE_SIZE_KiB": write["WRITE_SIZE"], "hbm_bytes_per_launch": hbm,
-                  "hbm_gbps": hbm / (ms * 1e-3) / 1e9 if ms else None, "hbm_frac_of_peak": hbm / (ms * 1e-3) / 1e9 / 8000.0 if ms else None})
+                  "hbm_gbps": hbm / (ms * 1e-3) / 1e9 if ms else None, "hbm_frac_of_peak": hbm / (ms * 1e-3) / 1e9 / 8000.0 if ms else None,
+                  "hbm_note": "memory-side requests of the L2 (Infinity Cache hits included): record stream, snapshot copies, and the register spills of "
+                              "the event kernel (scratch); WRITE_SIZE is not calibrated"})
     rec[f"wordpress7_500/{fp}"] = r
 json.dump(rec, open(os.path.join(prof, f"{tag}_counters.json"), "w"), indent=1)
 print(json.dumps({k: {a: b for a, b in v.items() if a != "counters"} if isinstance(v, dict) else v for k, v in rec.items()}, indent=1))

@@ -410,11 +410,10 @@ __device__ __forceinline__ void mark_tail(const DevProblem& P, unsigned* dirty, 
 }
 
 template <class Eval>
-__device__ __forceinline__ unsigned run_slice(const RunEnv& E, const int4 pr, const int4 sc, bool& marked, Eval&& eval) {
+__device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eval&& eval) {
   const DevProblem& P = E.P;
   const int lane = threadIdx.x & 63, s = E.s;
   unsigned wave_iters = 0;  // wave-uniform
-  int nar_all = 0;          // operands this lane narrowed during the run
   for (;;) {
     bool ch = false, un_i = false;
     int nar = 0;
@@ -433,31 +432,34 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, const int4 pr, co
       if (ld(&E.sh.abort)) break;
     }
   }
-  // Successors, once per run: every OTHER slice reading a variable this run narrowed runs in the next round (in a round
-  // based fixpoint nobody looks at the marks before the barrier, so they need not follow each narrowing).  Up to two
-  // successors per operand travel with the record (P.succ: 16-bit slice ids, 0xffff = none) and need no memory access;
-  // the others come from the variable's 32-byte adjacency record, one L2 round trip for the whole wave.
-  nar_all &= ~(pr.x >> 8) & 7;  // operands private to this slice are flagged at pack time
-  if (__any(nar_all != 0)) {
-    bool did = false;
-    if ((nar_all & 1) && !(sc.w & 1)) did |= mark_packed(E.nxt, (unsigned)sc.x);
-    if ((nar_all & 2) && !(sc.w & 2)) did |= mark_packed(E.nxt, (unsigned)sc.y);
-    if ((nar_all & 4) && !(sc.w & 4)) did |= mark_packed(E.nxt, (unsigned)sc.z);
-    const int lng = nar_all & sc.w;
-    if (__any(lng != 0)) {
-      int dx = 0, dy = 0, dz = 0, ox = 0, oy = 0, oz = 0;
-      const bool tx = mark_var(P, E.nxt, pr.y, s, (lng & 1) != 0, dx, ox);
-      const bool ty = mark_var(P, E.nxt, pr.z, s, (lng & 2) != 0, dy, oy);
-      const bool tz = mark_var(P, E.nxt, pr.w, s, (lng & 4) != 0, dz, oz);
-      const unsigned long long mx = __ballot(tx), my = __ballot(ty), mz = __ballot(tz);
-      if (mx) mark_tail(P, E.nxt, mx, dx, ox, s);
-      if (my) mark_tail(P, E.nxt, my, dy, oy, s);
-      if (mz) mark_tail(P, E.nxt, mz, dz, oz, s);
-      did |= lng != 0;
-    }
-    marked |= __any(did);
-  }
   return wave_iters;
+}
+
+// Successors of one run: every OTHER slice reading a variable the run narrowed (`nar_all`, per lane: bit 0 x, 1 y, 2 z) runs
+// in the next round.  In a round based fixpoint nobody looks at the marks before the barrier, so they are issued once per
+// run, not after each narrowing.  Up to two successors per operand travel with the record (DevProblem::succ: 16-bit slice
+// ids, 0xffff = none) and need no memory access; the others come from the variable's 32-byte adjacency record, one L2
+// round trip for the whole wave.  Returns true (wave-uniform) when something was marked.
+__device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* nxt, int s, const int4 pr, const int4 sc, int nar_all) {
+  nar_all &= ~(pr.x >> 8) & 7;  // operands private to this slice are flagged at pack time
+  if (!__any(nar_all != 0)) return false;
+  bool did = false;
+  if ((nar_all & 1) && !(sc.w & 1)) did |= mark_packed(nxt, (unsigned)sc.x);
+  if ((nar_all & 2) && !(sc.w & 2)) did |= mark_packed(nxt, (unsigned)sc.y);
+  if ((nar_all & 4) && !(sc.w & 4)) did |= mark_packed(nxt, (unsigned)sc.z);
+  const int lng = nar_all & sc.w;
+  if (__any(lng != 0)) {
+    int dx = 0, dy = 0, dz = 0, ox = 0, oy = 0, oz = 0;
+    const bool tx = mark_var(P, nxt, pr.y, s, (lng & 1) != 0, dx, ox);
+    const bool ty = mark_var(P, nxt, pr.z, s, (lng & 2) != 0, dy, oy);
+    const bool tz = mark_var(P, nxt, pr.w, s, (lng & 4) != 0, dz, oz);
+    const unsigned long long mx = __ballot(tx), my = __ballot(ty), mz = __ballot(tz);
+    if (mx) mark_tail(P, nxt, mx, dx, ox, s);
+    if (my) mark_tail(P, nxt, my, dy, oy, s);
+    if (mz) mark_tail(P, nxt, mz, dz, oz, s);
+    did |= lng != 0;
+  }
+  return __any(did);
 }
 
 // A 2-bit Boolean of the COMPACT layout as an LDS word address and a bit position (computed once per run).
@@ -563,12 +565,12 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
         return (base + wl) * 32 + b;
       };
       int s = next_slice();
-      int4 pr = idle_record(), sc = make_int4(-1, -1, -1, 0);
-      if (s >= 0) { pr = props[s * 64 + lane]; sc = P.succ[s * 64 + lane]; }  // the arrays are padded to whole slices
+      int4 pr = idle_record();
+      if (s >= 0) pr = props[s * 64 + lane];  // the arrays are padded to whole slices
       while (s >= 0) {
         const int s_next = next_slice();
-        int4 pr_next = pr, sc_next = sc;
-        if (s_next >= 0) { pr_next = props[s_next * 64 + lane]; sc_next = P.succ[s_next * 64 + lane]; }
+        int4 pr_next = pr;
+        if (s_next >= 0) pr_next = props[s_next * 64 + lane];
         if (ld(&sh.bot) | ld(&sh.abort)) break;  // the node failed in another wave
         if (!(drop_entailed && es.unent[s] == 0)) {
           const bool act = s * 64 + lane < n;
@@ -576,11 +578,13 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
           const unsigned key = (unsigned)__builtin_amdgcn_readfirstlane(pr.x) >> 16;  // wave-uniform: scalar dispatch
           unsigned wave_iters;
           unsigned run_writes = 0;  // per lane, folded into the 64-bit counter once per run
+          int nar_all = 0;          // operands this lane narrowed during the run
+          const int4 sc = P.succ[s * 64 + lane];  // needed after the run only: the load hides behind it
           if (C && key == KEY_LEQT_BB) {
             // y <= z on two Booleans, straight on their 2-bit encodings (bit 0: lb raised to 1, bit 1: ub lowered to 0):
             // z.ub = 0 forces y.ub = 0, y.lb = 1 forces z.lb = 1; entailed once y.ub = 0 or z.lb = 1.
             const BoolRef ry = bool_ref(store, P.n_int, pr.z, act), rz = bool_ref(store, P.n_int, pr.w, act);
-            wave_iters = run_slice(E, pr, sc, marked, [&](bool& ch, bool& un_i, int& nar) {
+            wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               const unsigned yb = bool_bits(ry), zb = bool_bits(rz);
               const bool ny = (zb & 2u) && !(yb & 2u), nz = (yb & 1u) && !(zb & 1u);
               const bool empty_in = yb == 3u || zb == 3u;
@@ -608,7 +612,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             const BoolRef rx = bool_ref(store, P.n_int, pr.y, act);
             const int kc = load_dom<C>(store, P.n_int, act ? pr.w : 0).lb;
             const bool single_pass = ((__builtin_amdgcn_readfirstlane(pr.x) >> 11) & 1) != 0;
-            wave_iters = run_slice(E, pr, sc, marked, [&](bool& ch, bool& un_i, int& nar) {
+            wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               const unsigned xb = bool_bits(rx);
               const bool t = act && (xb & 1u), f = act && (xb & 2u), u = act && xb == 0u;
               bool bad = __any(act && xb == 3u);
@@ -666,7 +670,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             const BoolRef rx = bool_ref(store, P.n_int, pr.y, act);
             const int yv = act ? pr.z : 0;
             const int kc = load_dom<C>(store, P.n_int, act ? pr.w : 0).lb;
-            wave_iters = run_slice(E, pr, sc, marked, [&](bool& ch, bool& un_i, int& nar) {
+            wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               const unsigned xb = bool_bits(rx);
               const Itv Y = load_dom<false>(store, P.n_int, yv);
               const bool t = (xb & 1u) != 0, f = (xb & 2u) != 0, u = !t && !f;
@@ -704,10 +708,11 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               un_i = act & !ent;
             });
           } else {
-            wave_iters = run_slice(E, pr, sc, marked, [&](bool& ch, bool& un_i, int& nar) {
+            wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               apply<true, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, 0, &nar);
             });
           }
+          marked |= mark_successors(P, nxt, s, pr, sc, nar_all);
           tc.writes += run_writes;
           {  // profiling (tuning build): 0x400000 counts slice runs instead of iterations; bits 28-31 = 1 + class to count only that class (11 = mixed slices)
             const int want = (knobs(P) >> 28) & 15;
@@ -716,7 +721,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             if (want == 0 || want - 1 == cls_of_slice) wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;
           }
         }
-        s = s_next; pr = pr_next; sc = sc_next;
+        s = s_next; pr = pr_next;
       }
     }
     if (lane == 0 && marked) st(&sh.flag[k], 1);
