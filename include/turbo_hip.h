@@ -62,7 +62,9 @@ typedef struct {
   uint64_t stop_after_n_nodes_total;/* node budget of the whole search, all workgroups of all linked GPUs together (0 = none): fixed total
                                        work for strong-scaling measurements.  Counted in rank 0's cell in batches of 32 nodes per workgroup */
   int32_t subproblems_power;        /* -sub; -1 = auto */
-  int32_t fixpoint;                 /* 0 = AC1, 1 = WAC1 (config.hpp:22-25), 2 = event-driven WAC1 (this engine) */
+  int32_t fixpoint;                 /* 0 = AC1, 1 = WAC1 (config.hpp:22-25), 2 = event-driven WAC1 (this engine), 3 = automatic: event-driven from
+                                       2048 propagators on, WAC1 below (a sweep over a few slices is cheaper than any bookkeeping); all of
+                                       them compute the same fixpoint at every node, hence the same search tree */
   int32_t only_global_memory;       /* -globalmem */
   int32_t verbose;
   int32_t has_eps_strategy;         /* strategy 0 is the EPS strategy (barebones:434,747-750) */

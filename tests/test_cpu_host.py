@@ -197,7 +197,7 @@ class TestCli:
     def test_command_line_echo_defaults(self):
         r = run_turbo("-s", os.path.join(BENCH, "unsolved_bugs_data", "false.fzn"))
         line = r.stdout.splitlines()[0]
-        for part in ("-t 0", "-n 1", "-arch barebones", "-or 0", "-sub -1", "-subfactor 300", "-fp event",
+        for part in ("-t 0", "-n 1", "-arch barebones", "-or 0", "-sub -1", "-subfactor 300", "-fp auto",
                      "-seed 0", "-eps_var_order default", "-cutnodes 0"):
             assert part in line, part
 

@@ -271,3 +271,20 @@ def test_synthetic_search_finds_a_solution(synthetic, fixpoint):
     if has:  # any reported solution satisfies every propagator
         _, failed, ent, _, _ = pyoracle.propagate(best, tcn.props)
         assert not failed and ent
+
+
+def test_automatic_fixpoint_picks_by_size_and_keeps_the_tree():
+    """tb_config.fixpoint = 3 (the CLI default): WAC1 sweeps below 2048 propagators, the event-driven fixpoint from there on;
+    either way the tree is the oracle's."""
+    small = load("test_data/pat7.fzn")
+    assert small.n_props < 2048
+    has_o, best_o, st_o = pyoracle.solve(small, subproblems_power=0)
+    has_g, best_g, st_g = capi.solve(small, capi.make_config(or_nodes=1, subproblems_power=0, timeout_ms=60000, fixpoint=3))
+    assert has_g == has_o and all(st_g[k] == st_o[k] for k in ("nodes", "fails", "solutions", "depth_max"))
+    np.testing.assert_array_equal(best_g, best_o)
+    big = load("example_wordpress7_500.fzn")
+    _, _, st_auto = capi.solve(big, capi.make_config(stop_after_n_nodes_total=50000, timeout_ms=60000, fixpoint=3))
+    _, _, st_event = capi.solve(big, capi.make_config(stop_after_n_nodes_total=50000, timeout_ms=60000, fixpoint=2))
+    _, _, st_wac1 = capi.solve(big, capi.make_config(stop_after_n_nodes_total=50000, timeout_ms=60000, fixpoint=1))
+    assert (st_auto["num_blocks"], st_auto["threads_per_block"]) == (st_event["num_blocks"], st_event["threads_per_block"])
+    assert (st_auto["num_blocks"], st_auto["threads_per_block"]) != (st_wac1["num_blocks"], st_wac1["threads_per_block"])

@@ -225,6 +225,11 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   return TB_OK;
 }
 
+// tb_config.fixpoint = 3: the engine chooses (same fixpoint, same tree either way)
+void resolve_fixpoint(tb_config* cfg, int32_t n_props) {
+  if (cfg->fixpoint == 3) cfg->fixpoint = n_props >= 2048 ? 2 : 1;
+}
+
 int validate_network(int32_t n_vars, const tb_itv* store, int32_t n_props, const tb_prop* props) {
   if (n_vars < 0 || n_props < 0 || (n_vars > 0 && !store) || (n_props > 0 && !props)) return fail(TB_ERR_INVALID, "null or negative-sized network");
   if ((size_t)n_props > (size_t)0xfffe * 64) return fail(TB_ERR_INVALID, "more than 4 194 176 propagators: slice ids are 16 bits wide in the adjacency records");
@@ -602,6 +607,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   if (!cfg_in) return fail(TB_ERR_INVALID, "null config");
   if (n_stores < 0 || (n_stores > 0 && !stores_inout)) return fail(TB_ERR_INVALID, "null stores");
   tb_config cfg = *cfg_in;
+  resolve_fixpoint(&cfg, n_props);
   int rc = validate_network(n_vars, stores_inout, n_props, props);
   if (rc != TB_OK) return rc;
   if (n_stores == 0) return TB_OK;
@@ -723,6 +729,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
 
   std::unique_ptr<tb_session> s(new tb_session);
   s->cfg = *cfg_in;
+  resolve_fixpoint(&s->cfg, n_props);
   s->n_vars = n_vars; s->obj_var = obj_var;
   if ((rc = query_caps(s->cfg.device, &s->caps)) != TB_OK) return rc;
   if ((rc = choose_layout(s->cfg, s->caps, n_vars, 1, root_store, n_props, &s->lay, &s->plan)) != TB_OK) return rc;

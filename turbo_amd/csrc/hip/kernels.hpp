@@ -387,6 +387,7 @@ __device__ __forceinline__ bool mark_var(const DevProblem& P, unsigned* dirty, i
   const int deg = (int)(w[0] & 0xffffu);
 #pragma unroll
   for (int j = 0; j < 13; ++j) {
+    if (!__any(j < deg)) break;  // wave-uniform: most variables have four or five readers, not thirteen
     const int hw = j + 1;
     const int t = (int)((hw & 1) ? (w[hw >> 1] >> 16) : (w[hw >> 1] & 0xffffu));
     if (j < deg && t != self) mark_slice(dirty, t);

@@ -19,13 +19,13 @@ const char* name_of(Arch a) {
     default: return "hybrid";
   }
 }
-const char* name_of(Fixpoint f) { return f == Fixpoint::AC1 ? "ac1" : (f == Fixpoint::WAC1 ? "wac1" : "event"); }
+const char* name_of(Fixpoint f) { return f == Fixpoint::AC1 ? "ac1" : (f == Fixpoint::WAC1 ? "wac1" : (f == Fixpoint::EVENT ? "event" : "auto")); }
 
 void usage_and_exit(const std::string& program) {
   std::cout
       << "usage: " << program
       << " [-t 2000] [-a] [-n 10] [-i] [-f] [-s] [-v] [-arch <gpu|barebones>] [-p 48] [-or 48] [-sub 12] [-subfactor 300]"
-         " [-fp <ac1|wac1|event>] [-wac1_threshold 0] [-eps_var_order <input_order|first_fail|anti_first_fail|smallest|largest>]"
+         " [-fp <ac1|wac1|event|auto>] [-wac1_threshold 0] [-eps_var_order <input_order|first_fail|anti_first_fail|smallest|largest>]"
          " [-eps_value_order <min|max|split|reverse_split>] [-seed 0] [-cutnodes 0] [-disable_simplify] [-entailed_removal] [-globalmem]"
          " [-gpus 1] [-deterministic] [-threads 0] [-version 1.0.0] [-hardware \"...\"] fzninstance.fzn\n"
       << "\t-t / -timeout <ms>: timeout in milliseconds (-timeout overrides -t).\n"
@@ -35,7 +35,7 @@ void usage_and_exit(const std::string& program) {
       << "\t-f: free search (accepted, search annotations are still followed).\n"
       << "\t-s: print statistics.  -v: verbose (repeatable).\n"
       << "\t-arch <gpu|barebones>: both run the MI355X dive-and-solve engine; cpu and hybrid are not provided by this build.\n"
-      << "\t-fp <ac1|wac1|event>: fixpoint strategy (default event: wac1 that only re-evaluates the 64-propagator slices reading a narrowed variable -- same search tree, fastest; wac1, the reference's default: each wave reaches a local fixpoint over its 64 propagators in every sweep; ac1: plain sweeps).\n"
+      << "\t-fp <ac1|wac1|event|auto>: fixpoint strategy (default auto: event from 2048 propagators on, wac1 below; event: wac1 that only re-evaluates the 64-propagator slices reading a narrowed variable -- same search tree, fastest; wac1, the reference's default: each wave reaches a local fixpoint over its 64 propagators in every sweep; ac1: plain sweeps).\n"
       << "\t-or / -p <n>: number of workgroups (default 0: automatic).\n"
       << "\t-sub <d>: 2^d subproblems (default -1: at least subfactor x workgroups).  -subfactor <f>: default 300.\n"
       << "\t-cutnodes <n>: stop a workgroup after n nodes (0: no limit).  -globalmem: keep the store in global memory.\n"
@@ -142,6 +142,7 @@ Options parse_options(int argc, char** argv) {
     if (s == "ac1") o.fixpoint = Fixpoint::AC1;
     else if (s == "wac1") o.fixpoint = Fixpoint::WAC1;
     else if (s == "event") o.fixpoint = Fixpoint::EVENT;
+    else if (s == "auto") o.fixpoint = Fixpoint::AUTO;
     else { std::cerr << "Unknown fixpoint -fp " << s << std::endl; std::exit(EXIT_FAILURE); }
   }
   u64("-wac1_threshold", o.wac1_threshold);

@@ -9,7 +9,7 @@
 namespace turbo_host {
 
 enum class Arch { CPU, GPU, BAREBONES, HYBRID };
-enum class Fixpoint { AC1, WAC1, EVENT };  // EVENT: this engine's event-driven WAC1 (not a reference flag)
+enum class Fixpoint { AC1, WAC1, EVENT, AUTO };  // EVENT: this engine's event-driven WAC1; AUTO: EVENT from 2048 propagators on, else WAC1 (not reference flags)
 
 struct Options {
   bool print_intermediate_solutions = false;  // -i / -a
@@ -30,7 +30,7 @@ struct Options {
   uint64_t subproblems_factor = 300;          // -subfactor
   uint64_t stack_kb = 0;                      // -stack (accepted, meaningless here: no device stack frames)
   Arch arch = Arch::BAREBONES;                // GPU build default (config.hpp:84-90)
-  Fixpoint fixpoint = Fixpoint::EVENT;        // the engine's event-driven WAC1: same fixpoint at every node, hence the same tree, as the
+  Fixpoint fixpoint = Fixpoint::AUTO;         // the engine's event-driven WAC1 (WAC1 sweeps on very small networks): same fixpoint at every node, hence the same tree, as the
                                               // reference's GPU default `-fp wac1` (config.hpp:91-97), which stays available like `-fp ac1`
   uint64_t wac1_threshold = 0;
   uint64_t seed = 0;

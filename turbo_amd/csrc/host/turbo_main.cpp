@@ -110,7 +110,7 @@ tb_config make_config(const Options& o, bool has_eps) {
   c.timeout_ms = o.timeout_ms; c.or_nodes = o.or_nodes; c.subproblems_factor = o.subproblems_factor;
   c.stop_after_n_nodes = o.stop_after_n_nodes == UINT64_MAX ? 0 : o.stop_after_n_nodes;
   c.stop_after_n_solutions = o.stop_after_n_solutions; c.wac1_threshold = o.wac1_threshold;
-  c.subproblems_power = o.subproblems_power; c.fixpoint = o.fixpoint == Fixpoint::AC1 ? 0 : (o.fixpoint == Fixpoint::WAC1 ? 1 : 2);
+  c.subproblems_power = o.subproblems_power; c.fixpoint = o.fixpoint == Fixpoint::AC1 ? 0 : (o.fixpoint == Fixpoint::WAC1 ? 1 : (o.fixpoint == Fixpoint::EVENT ? 2 : 3));
   c.only_global_memory = o.only_global_memory; c.verbose = o.verbose; c.has_eps_strategy = has_eps;
   c.threads_per_block = o.threads_per_block; c.device = 0; c.rank = 0; c.world_size = 1;
   c.deterministic = o.deterministic;
@@ -330,7 +330,7 @@ int main(int argc, char** argv) {
     for (size_t b = 0, e; (e = lines.find('\n', b)) != std::string::npos; b = e + 1) std::printf("%%%%%%mzn-stat: %s\n", lines.substr(b, e - b).c_str());
   }
   p.s("abstract_domain", "pir_itv32_z");
-  p.s("entailed_prop_removal", (o.fixpoint == Fixpoint::EVENT || o.entailed_removal) ? "by_slice_entailment" : "deactivated");
+  p.s("entailed_prop_removal", (o.fixpoint == Fixpoint::EVENT || o.fixpoint == Fixpoint::AUTO || o.entailed_removal) ? "by_slice_entailment" : "deactivated");
   analyze_tcn(o, p, "tcn", m);
   if (!o.disable_simplify && !tf_trivially_unsat(m)) {
     std::string err_text;
