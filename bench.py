@@ -123,6 +123,7 @@ def main() -> int:
     ap.add_argument("--nodes-total", type=int, default=0, help="node budget of one step, all GPUs together (0 = workload default)")
     ap.add_argument("--cutnodes", type=int, default=0, help="additionally cap every workgroup at this many nodes (the reference's -cutnodes)")
     ap.add_argument("--or-nodes", type=int, default=0, help="workgroups per GPU (0 = fill the GPU)")
+    ap.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = the engine's choice)")
     ap.add_argument("--side-steps", type=int, default=2, help="steps of the other fixpoint (wac1 <-> event) timed beside the headline (0 = skip)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: the node budget of a step does not depend on the number of GPUs; weak: it is multiplied by it")
@@ -173,7 +174,7 @@ def main() -> int:
         linked = world > 1 and args.exchange == "peer"
         per_rank_budget = budget if (world == 1 or linked) else max(1, budget // world)  # unlinked ranks count on their own
         cfg = capi.make_config(fixpoint=FP_CODE[fixpoint], stop_after_n_nodes_total=per_rank_budget, stop_after_n_nodes=args.cutnodes,
-                               or_nodes=args.or_nodes, timeout_ms=600000, device=local_rank, rank=rank, world_size=world, debug=args.debug_bits)
+                               or_nodes=args.or_nodes, threads_per_block=args.threads, timeout_ms=600000, device=local_rank, rank=rank, world_size=world, debug=args.debug_bits)
         sess = capi.Session(tcn, cfg)  # inputs uploaded to HBM here, outside the timed region
         tdist.agree_on_plan(sess, dist, tdev)
         if linked:
