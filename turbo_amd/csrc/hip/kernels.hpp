@@ -433,6 +433,7 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
       if (ld(&E.sh.abort)) break;
     }
   }
+  if (knobs(P) & 0x8) { bool ch = false, un_i = false; int nar = 0; eval(ch, un_i, nar); nar_all |= nar; }  // tuning: cost of one iteration
   return wave_iters;
 }
 
@@ -714,6 +715,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             });
           }
           marked |= mark_successors(P, nxt, s, pr, sc, nar_all);
+          if (knobs(P) & 0x1) marked |= mark_successors(P, nxt, s, pr, sc, nar_all);  // tuning: cost of the marks (idempotent)
           tc.writes += run_writes;
           {  // profiling (tuning build): 0x400000 counts slice runs instead of iterations; bits 28-31 = 1 + class to count only that class (11 = mixed slices)
             const int want = (knobs(P) >> 28) & 15;
@@ -739,6 +741,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   for (int i = tid; i < 2 * W; i += T) es.dirty[i] = 0;
   bool un = false;
   for (int s = tid; s < S; s += T) un |= es.unent[s] != 0;
+  if (knobs(P) & 0x2) for (int s = tid; s < S; s += T) un |= es.unent[s] != 0;  // tuning: cost of the reduction
   if (__any(un) && lane == 0) st(&sh.unent[0], 1);
   __syncthreads();
   all_entailed = !ld(&sh.unent[0]);
@@ -1360,6 +1363,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
           long long tp = 0;
           if (prof && tid == 0) tp = wall_clock64();
           if (d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * VX, store, VX);  // d0 == 0: barebones:785-791
+          if ((knobs(P) & 0x4) && d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * VX, store, VX);  // tuning: cost of the snapshot
           if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
           __syncthreads();
           if (prof && tid == 0) { const long long t = wall_clock64(); bs.timers[TB_T_PREPROCESSING] += t - tp; tp = t; }  // profiling: snapshot push
