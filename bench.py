@@ -30,9 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# instance, node budget of one step for the event / sweeping fixpoints (about one second of one MI355X each)
+# instance, node budget of one step for the event / sweeping fixpoints (a little under one second of one MI355X each)
 WORKLOADS = {
-    "wordpress7_500": ("example_wordpress7_500.fzn", 6_000_000, 1_500_000),
+    "wordpress7_500": ("example_wordpress7_500.fzn", 12_000_000, 1_500_000),
     "accap_a3": ("accap_a3.fzn", 12_000_000, 12_000_000),
     "trains15": ("trains15.fzn", 12_000_000, 4_000_000),
     "synthetic": ("synthetic 100k x 500k (seed 42)", 8_000, 8_000),

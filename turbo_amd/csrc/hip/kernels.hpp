@@ -551,7 +551,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       const int wi = base + lane;
       const unsigned w = wi < W ? (__hip_atomic_load(&cur[wi], TB_RLX, TB_WG) & own) : 0u;
       if (w != 0) (void)__hip_atomic_fetch_and(&cur[wi], ~w, TB_RLX, TB_WG);  // mine, cleared before any domain is loaded
-      // my slices of this round, one after the other; the records of the next one are fetched while the current one runs
+      // my slices of this round, one after the other
       unsigned long long nz = __ballot(w != 0);
       unsigned word = 0;
       int wl = 0;
@@ -567,12 +567,11 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
         return (base + wl) * 32 + b;
       };
       int s = next_slice();
-      int4 pr = idle_record();
-      if (s >= 0) pr = props[s * 64 + lane];  // the arrays are padded to whole slices
       while (s >= 0) {
         const int s_next = next_slice();
-        int4 pr_next = pr;
-        if (s_next >= 0) pr_next = props[s_next * 64 + lane];
+        // (no software prefetch of the next slice's records: under the 80-register budget of this kernel the prefetched
+        //  int4 lived in scratch, and the round trip cost more than the L2 latency it hid -- 15.3 -> 19.3e6 nodes/s without it)
+        const int4 pr = props[s * 64 + lane];  // the arrays are padded to whole slices
         if (ld(&sh.bot) | ld(&sh.abort)) break;  // the node failed in another wave
         if (!(drop_entailed && es.unent[s] == 0)) {
           const bool act = s * 64 + lane < n;
@@ -724,7 +723,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             if (want == 0 || want - 1 == cls_of_slice) wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;
           }
         }
-        s = s_next; pr = pr_next;
+        s = s_next;
       }
     }
     if (lane == 0 && marked) st(&sh.flag[k], 1);
