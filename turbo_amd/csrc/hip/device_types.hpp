@@ -116,13 +116,12 @@ struct DevProblem {
   const int* strat_val_order;
   const int* strat_off;
   const int* strat_vars;
-  // event-driven fixpoint: variable -> 64-propagator slices adjacency (CSR), built by the shim
-  const int4* adj_head; // [n_vars] {degree, first slice, second slice, offset of the remaining slices in adj}
-  const int* adj;       // remaining slice ids of the variables read by more than two slices
-  const int4* head13;   // [2 * n_vars] per variable: 16 halfwords {number of reader slices, the first 13 of them, offset of the rest in adj13}
-  const int* adj13;     // reader slices beyond the thirteenth
+  // event-driven fixpoint: variable -> 64-propagator slices adjacency, built by the shim (engine.hip: pack_var_adj, pack_succ)
+  const int4* var_adj;  // [2 * n_vars] per variable 16 halfwords: number of reader slices, the first 11, their interests (2 bits each:
+                        // 1 = woken when the lower bound rises, 2 = when the upper bound falls), offset of the others in adj_rest
+  const int* adj_rest;  // reader slices beyond the eleventh: slice | interest << 30
   const int4* succ;     // [padded n_props] per record {x, y, z: up to two OTHER slices reading the operand, 16 bits each, 0xffff = none;
-                        //  w: bit k set = operand k has more of them -> walk adj_head / adj}
+                        //  w: bit k = operand k has more of them (walk var_adj), bits 4..15 = interests of the packed ones}
   int n_slices;         // ceil(n_props / 64)
   int dirty_words;      // ceil(n_slices / 32)
   int vext;             // int2 elements of a store slab (even): intervals, Boolean words, one "not entailed" byte per slice

@@ -241,34 +241,38 @@ int validate_network(int32_t n_vars, const tb_itv* store, int32_t n_props, const
   return TB_OK;
 }
 
+// Variable -> slices adjacency of the event-driven fixpoint: slice s = propagators [64 s, 64 s + 64).  Constants never change,
+// so they get an empty list.  Each reader comes with its INTEREST in the two kinds of event a variable can undergo (1: its
+// lower bound was raised, 2: its upper bound was lowered): `y <= z` with a constant-true truth value can only narrow
+// something after y.lb rose or z.ub fell, `y > z` after y.ub fell or z.lb rose; every other propagator reacts to both.  A
+// narrowing wakes up only the readers interested in it.
+struct Reader { int slice, interest; };
 struct Adjacency {
-  std::vector<std::vector<int>> lists;  // per variable: the slices reading it (ascending, no duplicates); empty for constants
-  std::vector<int4> heads;              // {degree, first, second, offset of the rest}
-  std::vector<int> rest;
+  std::vector<std::vector<Reader>> lists;  // per variable: the slices reading it (ascending, no duplicates)
 };
 
-// Variable -> slices adjacency of the event-driven fixpoint: slice s = propagators [64 s, 64 s + 64).
-// Constants never change, so they get an empty list.
-Adjacency build_adjacency(int32_t n_vars, int32_t n_props, const tb_prop* props, const std::vector<char>& is_const) {
+inline int interest_of(int cls, int operand) {  // operand: 0 x, 1 y, 2 z
+  if (cls == K_LEQ_T) return operand == 1 ? 1 : (operand == 2 ? 2 : 3);
+  if (cls == K_LEQ_F) return operand == 1 ? 2 : (operand == 2 ? 1 : 3);
+  return 3;
+}
+
+Adjacency build_adjacency(int32_t n_vars, int32_t n_props, const tb_prop* props, const std::vector<char>& is_const, const std::vector<int>& value, bool filter) {
   Adjacency a;
   a.lists.resize((size_t)n_vars);
   for (int32_t i = 0; i < n_props; ++i) {
     const int s = i / 64;
+    const bool xc = is_const[(size_t)props[i].x] != 0;
+    const int cls = class_of(props[i].op, xc, xc ? value[(size_t)props[i].x] : 0);
     const int vs[3] = {props[i].x, props[i].y, props[i].z};
-    for (int v : vs) {
+    for (int k = 0; k < 3; ++k) {
+      const int v = vs[k];
       if (is_const[(size_t)v]) continue;
-      std::vector<int>& l = a.lists[(size_t)v];
-      if (l.empty() || l.back() != s) l.push_back(s);
+      const int in = filter ? interest_of(cls, k) : 3;
+      std::vector<Reader>& l = a.lists[(size_t)v];
+      if (!l.empty() && l.back().slice == s) l.back().interest |= in; else l.push_back(Reader{s, in});
     }
   }
-  a.heads.resize((size_t)std::max(1, n_vars));
-  for (int32_t v = 0; v < n_vars; ++v) {
-    const std::vector<int>& l = a.lists[(size_t)v];
-    int4 h = make_int4((int)l.size(), l.size() > 0 ? l[0] : -1, l.size() > 1 ? l[1] : -1, (int)a.rest.size());
-    for (size_t k = 2; k < l.size(); ++k) a.rest.push_back(l[k]);
-    a.heads[(size_t)v] = h;
-  }
-  if (a.rest.empty()) a.rest.push_back(0);
   return a;
 }
 
@@ -290,8 +294,8 @@ std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::v
       int priv = 0;
       const int vs[3] = {p.x, p.y, p.z};
       for (int k = 0; k < 3; ++k) {
-        const std::vector<int>& l = adj.lists[(size_t)vs[k]];
-        if (l.empty() || (l.size() == 1 && l[0] == s)) priv |= 1 << k;
+        const std::vector<Reader>& l = adj.lists[(size_t)vs[k]];
+        if (l.empty() || (l.size() == 1 && l[0].slice == s)) priv |= 1 << k;
       }
       out[(size_t)i] = make_int4(cls | (priv << 8) | (p.op << 12), p.x, p.y, p.z);
     }
@@ -320,45 +324,53 @@ std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::v
   return out;
 }
 
-// Per variable: 32-byte adjacency record of the event-driven fixpoint (device_types.hpp: DevProblem::head13) + overflow list.
-void pack_head13(const Adjacency& adj, std::vector<int4>* heads, std::vector<int>* rest) {
+// Per variable: 32-byte adjacency record of the event-driven fixpoint (device_types.hpp: DevProblem::var_adj) + overflow list.
+// 16 halfwords: [0] number of reader slices, [1..11] the first eleven, [12..13] their interests (2 bits each), [14..15] offset
+// of the others in the overflow list, whose entries are slice | interest << 30.
+void pack_var_adj(const Adjacency& adj, std::vector<int4>* heads, std::vector<int>* rest) {
   const size_t V = adj.lists.size();
-  std::vector<unsigned short> hw(std::max<size_t>(1, V) * 16, 0);
+  std::vector<unsigned> w(std::max<size_t>(1, V) * 8, 0);
   rest->clear();
   for (size_t v = 0; v < V; ++v) {
-    const std::vector<int>& l = adj.lists[v];
-    unsigned short* h = hw.data() + v * 16;
-    h[0] = (unsigned short)std::min<size_t>(l.size(), 0xffffu);
-    for (size_t k = 0; k < l.size() && k < 13; ++k) h[1 + k] = (unsigned short)l[k];
-    const unsigned off = (unsigned)rest->size();
-    h[14] = (unsigned short)(off & 0xffffu); h[15] = (unsigned short)(off >> 16);
-    for (size_t k = 13; k < l.size(); ++k) rest->push_back(l[k]);
+    const std::vector<Reader>& l = adj.lists[v];
+    unsigned* h = w.data() + v * 8;
+    unsigned short hw[16] = {0};
+    hw[0] = (unsigned short)std::min<size_t>(l.size(), 0xffffu);
+    unsigned interest = 0;
+    for (size_t k = 0; k < l.size() && k < 11; ++k) { hw[1 + k] = (unsigned short)l[k].slice; interest |= (unsigned)l[k].interest << (2 * k); }
+    for (int k = 0; k < 6; ++k) h[k] = (unsigned)hw[2 * k] | ((unsigned)hw[2 * k + 1] << 16);
+    h[6] = interest;
+    h[7] = (unsigned)rest->size();
+    for (size_t k = 11; k < l.size(); ++k) rest->push_back(l[k].slice | (l[k].interest << 30));
   }
   if (rest->empty()) rest->push_back(0);
   heads->resize(std::max<size_t>(1, V) * 2);
-  std::memcpy(heads->data(), hw.data(), heads->size() * sizeof(int4));
+  std::memcpy(heads->data(), w.data(), heads->size() * sizeof(int4));
 }
 
-// Successor slices of each record's operands for the event-driven fixpoint (device_types.hpp: DevProblem::succ).
+// Successor slices of each record's operands for the event-driven fixpoint (device_types.hpp: DevProblem::succ): x, y, z =
+// up to two OTHER slices reading the operand (16-bit ids, 0xffff = none); w = bit k: operand k has more of them (walk
+// var_adj), bits 4 + 2 (2 k + j): interest of the j-th packed successor of operand k.
 std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacency& adj) {
   std::vector<int4> out(((size_t)n_props + 63) / 64 * 64, make_int4(-1, -1, -1, 0));
-  const bool ids_fit = ((size_t)n_props + 63) / 64 < 0xffffu;
   for (int32_t i = 0; i < n_props; ++i) {
     const int s = i / 64;
     const int vs[3] = {props[i].x, props[i].y, props[i].z};
     unsigned packed[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
-    int lng = 0;
+    int flags = 0;
     for (int k = 0; k < 3; ++k) {
       unsigned o[2] = {0xffffu, 0xffffu};
+      int in[2] = {0, 0};
       int n = 0;
       bool too_many = false;
-      for (int t : adj.lists[(size_t)vs[k]]) {
-        if (t == s) continue;
-        if (n < 2 && ids_fit) o[n++] = (unsigned)t; else too_many = true;
+      for (const Reader& r : adj.lists[(size_t)vs[k]]) {
+        if (r.slice == s) continue;
+        if (n < 2) { o[n] = (unsigned)r.slice; in[n] = r.interest; ++n; } else too_many = true;
       }
-      if (too_many) lng |= 1 << k; else packed[k] = (o[1] << 16) | o[0];
+      if (too_many) flags |= 1 << k;
+      else { packed[k] = (o[1] << 16) | o[0]; flags |= (in[0] << (4 + 2 * (2 * k))) | (in[1] << (4 + 2 * (2 * k + 1))); }
     }
-    out[(size_t)i] = make_int4((int)packed[0], (int)packed[1], (int)packed[2], lng);
+    out[(size_t)i] = make_int4((int)packed[0], (int)packed[1], (int)packed[2], flags);
   }
   return out;
 }
@@ -630,7 +642,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     find_constants(n_vars, n_stores, stores_inout, &c0, &v0);
     for (int v = 0; v < n_vars; ++v) { is_const[(size_t)lay.perm[(size_t)v]] = c0[(size_t)v]; value[(size_t)lay.perm[(size_t)v]] = v0[(size_t)v]; }
     const InternalNet net = to_internal(lay, stores_inout, n_props, props, (cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL, cfg.fixpoint == 2 && !(cfg.reserved[0] & 0x8000000));
-    const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const);
+    const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const, value, !(cfg.reserved[0] & 0x80));
     const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj, lay.n_int);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
     {
@@ -639,21 +651,15 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
       if ((rc = bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
       if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
       P.succ = d_succ;
-      std::vector<int4> h13; std::vector<int> r13;
-      pack_head13(adj, &h13, &r13);
-      int4* d_h13 = nullptr; int* d_r13 = nullptr;
-      if ((rc = bufs.alloc(&d_h13, h13.size())) != TB_OK) return rc;
-      if ((rc = bufs.alloc(&d_r13, r13.size())) != TB_OK) return rc;
-      HIP_TRY(hipMemcpy(d_h13, h13.data(), h13.size() * sizeof(int4), hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(d_r13, r13.data(), r13.size() * sizeof(int), hipMemcpyHostToDevice));
-      P.head13 = d_h13; P.adj13 = d_r13;
+      std::vector<int4> heads; std::vector<int> rest;
+      pack_var_adj(adj, &heads, &rest);
+      int4* d_heads = nullptr; int* d_rest = nullptr;
+      if ((rc = bufs.alloc(&d_heads, heads.size())) != TB_OK) return rc;
+      if ((rc = bufs.alloc(&d_rest, rest.size())) != TB_OK) return rc;
+      HIP_TRY(hipMemcpy(d_heads, heads.data(), heads.size() * sizeof(int4), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(d_rest, rest.data(), rest.size() * sizeof(int), hipMemcpyHostToDevice));
+      P.var_adj = d_heads; P.adj_rest = d_rest;
     }
-    int4* d_head = nullptr; int* d_adj = nullptr;
-    if ((rc = bufs.alloc(&d_head, adj.heads.size())) != TB_OK) return rc;
-    if ((rc = bufs.alloc(&d_adj, adj.rest.size())) != TB_OK) return rc;
-    HIP_TRY(hipMemcpy(d_head, adj.heads.data(), adj.heads.size() * sizeof(int4), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_adj, adj.rest.data(), adj.rest.size() * 4, hipMemcpyHostToDevice));
-    P.adj_head = d_head; P.adj = d_adj;
   }
   P.n_slices = plan.n_slices; P.dirty_words = plan.dirty_words; P.vext = plan.vext; P.chg_cap = plan.chg_cap;
   P.n_int = plan.n_int; P.unent_off = plan.unent_off;
@@ -775,7 +781,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     std::vector<char> is_const;
     std::vector<int> value;
     find_constants(n_vars, 1, net.store.data(), &is_const, &value);  // constants = singleton variables of the root store
-    const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const);
+    const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const, value, !(s->cfg.reserved[0] & 0x80));
     const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj, lay.n_int);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
     {
@@ -784,21 +790,15 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
       if ((rc = s->bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
       if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
       s->P.succ = d_succ;
-      std::vector<int4> h13; std::vector<int> r13;
-      pack_head13(adj, &h13, &r13);
-      int4* d_h13 = nullptr; int* d_r13 = nullptr;
-      if ((rc = s->bufs.alloc(&d_h13, h13.size())) != TB_OK) return rc;
-      if ((rc = s->bufs.alloc(&d_r13, r13.size())) != TB_OK) return rc;
-      HIP_TRY(hipMemcpy(d_h13, h13.data(), h13.size() * sizeof(int4), hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(d_r13, r13.data(), r13.size() * sizeof(int), hipMemcpyHostToDevice));
-      s->P.head13 = d_h13; s->P.adj13 = d_r13;
+      std::vector<int4> heads; std::vector<int> rest;
+      pack_var_adj(adj, &heads, &rest);
+      int4* d_heads = nullptr; int* d_rest = nullptr;
+      if ((rc = s->bufs.alloc(&d_heads, heads.size())) != TB_OK) return rc;
+      if ((rc = s->bufs.alloc(&d_rest, rest.size())) != TB_OK) return rc;
+      HIP_TRY(hipMemcpy(d_heads, heads.data(), heads.size() * sizeof(int4), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(d_rest, rest.data(), rest.size() * sizeof(int), hipMemcpyHostToDevice));
+      s->P.var_adj = d_heads; s->P.adj_rest = d_rest;
     }
-    int4* d_head = nullptr; int* d_adj = nullptr;
-    if ((rc = s->bufs.alloc(&d_head, adj.heads.size())) != TB_OK) return rc;
-    if ((rc = s->bufs.alloc(&d_adj, adj.rest.size())) != TB_OK) return rc;
-    HIP_TRY(hipMemcpy(d_head, adj.heads.data(), adj.heads.size() * sizeof(int4), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_adj, adj.rest.data(), adj.rest.size() * 4, hipMemcpyHostToDevice));
-    s->P.adj_head = d_head; s->P.adj = d_adj;
   }
   s->P.n_slices = s->plan.n_slices; s->P.dirty_words = s->plan.dirty_words; s->P.vext = s->plan.vext; s->P.chg_cap = s->plan.chg_cap;
   s->P.n_int = s->plan.n_int; s->P.unent_off = s->plan.unent_off;

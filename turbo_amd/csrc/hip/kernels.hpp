@@ -54,7 +54,7 @@ struct alignas(16) BlockShared {
   unsigned long long sub_idx;  // global index of the current subproblem
   unsigned long long sub_j;    // its index in the local numbering of rank sub_owner (eps_global_index)
   int sub_owner, sub_gen;      // rank whose share it belongs to; generation of the queue range it was fetched from
-  int has_work, pad_work;
+  int has_work, witness;       // witness: index of a propagator found un-entailed (fixpoint_event), -1 = none
   long long ticket;  // streaming: sequence number of the solution being handed to the host, -1 if none
   unsigned long long red_key[MAX_WAVES];
   int red_first[MAX_WAVES];
@@ -164,7 +164,7 @@ __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store
           if (nz) raise_lb<C>(store, ni, pr.w, Y.lb);
           tc.writes += (unsigned)ny + (unsigned)nz;
           changed = true;
-          if (EVENT) *narrowed = ((int)ny << 1) | ((int)nz << 2);
+          if (EVENT) *narrowed = ((int)ny << 3) | ((int)nz << 4);  // y.ub lowered, z.lb raised
         }
       }
     }
@@ -196,7 +196,7 @@ __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store
         if (nzu != Z.ub) { lower_ub<C>(store, ni, pr.w, nzu); ++k; }
         tc.writes += (unsigned)k;
         changed |= (k != 0);
-        if (EVENT) *narrowed = (int)((nxl != X.lb) | (nxu != X.ub)) | ((int)((nyl != Y.lb) | (nyu != Y.ub)) << 1) | ((int)((nzl != Z.lb) | (nzu != Z.ub)) << 2);
+        if (EVENT) *narrowed = (int)(nxl != X.lb) | ((int)(nxu != X.ub) << 1) | ((int)(nyl != Y.lb) << 2) | ((int)(nyu != Y.ub) << 3) | ((int)(nzl != Z.lb) << 4) | ((int)(nzu != Z.ub) << 5);
       }
     }
   }
@@ -320,54 +320,70 @@ struct EventState {
   int words, cap;
 };
 
-__device__ __forceinline__ void note_change(BlockShared& sh, const EventState& es, int v) {
+// `ev`: EV_LB / EV_UB bits (what happened to v); stored in the two top bits of the entry
+__device__ __forceinline__ void note_change(BlockShared& sh, const EventState& es, int v, int ev) {
   const ChangeList cl{es.list, &sh.chg_count[0], es.cap};
-  append_change(cl, v);
+  append_change(cl, v | (ev << 30));
 }
 
 __device__ __forceinline__ void mark_slice(unsigned* dirty, int t) {
   (void)__hip_atomic_fetch_or(&dirty[t >> 5], 1u << (t & 31), TB_RLX, TB_WG);
 }
 
-// Adjacency head of a variable: {degree, first slice, second slice, offset of the rest in P.adj}.  Most
-// variables of a lowered model are read by one or two slices, so one 16-byte load usually settles it.
-// Low-degree part: done by the lane itself.  Returns true when the rest must be walked cooperatively.
-__device__ __forceinline__ bool mark_head(unsigned* dirty, const int4 h, int self) {
-  if (h.x >= 1 && h.y != self) mark_slice(dirty, h.y);
-  if (h.x >= 2 && h.z != self) mark_slice(dirty, h.z);
-  return h.x > 2;
-}
-// Up to two successor slices packed with the record (16-bit ids, 0xffff = none).  True when something was marked.
-__device__ __forceinline__ bool mark_packed(unsigned* dirty, unsigned packed) {
+// Events a variable can undergo: EV_LB its lower bound was raised, EV_UB its upper bound was lowered.  A reader slice is woken
+// up only by the events it declared an interest in (engine.hip: interest_of): `b1 <= b2` does not care that b1 became false.
+constexpr int EV_LB = 1, EV_UB = 2;
+
+// Up to two successor slices packed with the record (16-bit ids, 0xffff = none; `interest`: 2 bits each).  True when something was marked.
+__device__ __forceinline__ bool mark_packed(unsigned* dirty, unsigned packed, int interest, int ev) {
   const unsigned s0 = packed & 0xffffu, s1 = packed >> 16;
-  if (s0 != 0xffffu) mark_slice(dirty, (int)s0);
-  if (s1 != 0xffffu) mark_slice(dirty, (int)s1);
-  return s0 != 0xffffu;
+  const bool m0 = s0 != 0xffffu && (interest & ev) != 0, m1 = s1 != 0xffffu && ((interest >> 2) & ev) != 0;
+  if (m0) mark_slice(dirty, (int)s0);
+  if (m1) mark_slice(dirty, (int)s1);
+  return m0 | m1;
 }
-// does the head name a slice other than `self`?
-__device__ __forceinline__ bool has_other_reader(const int4 h, int self) {
-  return (h.x >= 1 && h.y != self) || (h.x >= 2 && h.z != self) || h.x > 2;
+
+// Mark the slices reading variable v that are interested in the events `ev` (0: nothing to do for this lane), except `self`,
+// from the variable's 32-byte adjacency record (DevProblem::var_adj: halfword 0 = number of reader slices, halfwords 1-11 =
+// the first eleven, word 6 = their interests, word 7 = offset of the others in DevProblem::adj_rest).  One L2 round trip
+// whatever the degree up to 11; returns true when the list is longer (mark_tail).
+__device__ __forceinline__ bool mark_var(const DevProblem& P, unsigned* dirty, int v, int self, int ev, int& deg_out, int& off_out, bool& did) {
+  int4 a = make_int4(0, 0, 0, 0), b = a;
+  if (ev) { a = P.var_adj[2 * (size_t)v]; b = P.var_adj[2 * (size_t)v + 1]; }
+  const unsigned w[8] = {(unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w, (unsigned)b.x, (unsigned)b.y, (unsigned)b.z, (unsigned)b.w};
+  const int deg = (int)(w[0] & 0xffffu);
+#pragma unroll
+  for (int j = 0; j < 11; ++j) {
+    if (!__any(j < deg)) break;  // wave-uniform: most variables have four or five readers, not eleven
+    const int hw = j + 1;
+    const int t = (int)((hw & 1) ? (w[hw >> 1] >> 16) : (w[hw >> 1] & 0xffffu));
+    if (j < deg && t != self && ((w[6] >> (2 * j)) & (unsigned)ev)) { mark_slice(dirty, t); did = true; }
+  }
+  deg_out = deg;
+  off_out = (int)w[7];
+  return deg > 11;
 }
-// Cooperative walk of the long adjacency lists of the lanes in `mask` (wave-uniform): one lane at a time is
-// broadcast, the 64 lanes stride over its list -- a high-degree variable costs one memory latency.
-__device__ __forceinline__ void mark_rest(const DevProblem& P, unsigned* dirty, unsigned long long mask, const int4 h, int self) {
+// the tail of the lists longer than 11, cooperatively: one lane at a time is broadcast, the 64 lanes stride over its list
+__device__ __forceinline__ bool mark_tail(const DevProblem& P, unsigned* dirty, unsigned long long mask, int deg, int off, int ev, int self) {
   const int lane = threadIdx.x & 63;
+  bool did = false;
   while (mask) {
     const int l = __builtin_ctzll(mask);
     mask &= mask - 1;
-    const int deg = __builtin_amdgcn_readlane(h.x, l), off = __builtin_amdgcn_readlane(h.w, l);
-    for (int j = lane; j < deg - 2; j += 64) {
-      const int t = P.adj[off + j];
-      if (t != self) mark_slice(dirty, t);
+    const int d = __builtin_amdgcn_readlane(deg, l), o = __builtin_amdgcn_readlane(off, l), e = __builtin_amdgcn_readlane(ev, l);
+    for (int j = lane; j < d - 11; j += 64) {
+      const int t = P.adj_rest[o + j];
+      if ((t & 0x3fffffff) != self && ((t >> 30) & e)) { mark_slice(dirty, t & 0x3fffffff); did = true; }
     }
   }
+  return did;
 }
 
 // ---- event-driven fixpoint: one slice run ------------------------------------------------------------------------------
 //
 // A run iterates the 64 propagators of a slice to their local fixpoint.  `eval(ch, un, nar)` is one iteration: it
 // narrows the store, reports whether this lane changed something (ch), whether its propagator is not entailed (un) and
-// which operands it narrowed (nar: bit 0 x, 1 y, 2 z).  Everything that does not change between two iterations -- LDS
+// which bounds it narrowed (nar: bits 2k / 2k+1 = lower bound raised / upper bound lowered of operand k, 0 x, 1 y, 2 z).  Everything that does not change between two iterations -- LDS
 // addresses, bit positions, the value of a constant operand -- is computed once per run by the caller of run_slice.
 struct RunEnv {
   const DevProblem& P;
@@ -376,39 +392,6 @@ struct RunEnv {
   unsigned char* unent;     // per-slice "some propagator is not entailed" bytes
   int s;                    // the slice
 };
-
-// Mark every slice reading variable v, except `self`, from the variable's 32-byte adjacency record (DevProblem::head13:
-// halfword 0 = number of reader slices, halfwords 1-13 = the first thirteen, halfwords 14-15 = offset of the others in
-// DevProblem::adj).  One L2 round trip whatever the degree up to 13; returns true when the list is longer.
-__device__ __forceinline__ bool mark_var(const DevProblem& P, unsigned* dirty, int v, int self, bool on, int& deg_out, int& off_out) {
-  int4 a = make_int4(0, 0, 0, 0), b = a;
-  if (on) { a = P.head13[2 * (size_t)v]; b = P.head13[2 * (size_t)v + 1]; }
-  const unsigned w[8] = {(unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w, (unsigned)b.x, (unsigned)b.y, (unsigned)b.z, (unsigned)b.w};
-  const int deg = (int)(w[0] & 0xffffu);
-#pragma unroll
-  for (int j = 0; j < 13; ++j) {
-    if (!__any(j < deg)) break;  // wave-uniform: most variables have four or five readers, not thirteen
-    const int hw = j + 1;
-    const int t = (int)((hw & 1) ? (w[hw >> 1] >> 16) : (w[hw >> 1] & 0xffffu));
-    if (j < deg && t != self) mark_slice(dirty, t);
-  }
-  deg_out = deg;
-  off_out = (int)w[7];  // halfwords 14 (low) and 15 (high)
-  return deg > 13;
-}
-// the tail of the lists longer than 13, cooperatively: one lane at a time is broadcast, the 64 lanes stride over its list
-__device__ __forceinline__ void mark_tail(const DevProblem& P, unsigned* dirty, unsigned long long mask, int deg, int off, int self) {
-  const int lane = threadIdx.x & 63;
-  while (mask) {
-    const int l = __builtin_ctzll(mask);
-    mask &= mask - 1;
-    const int d = __builtin_amdgcn_readlane(deg, l), o = __builtin_amdgcn_readlane(off, l);
-    for (int j = lane; j < d - 13; j += 64) {
-      const int t = P.adj13[o + j];
-      if (t != self) mark_slice(dirty, t);
-    }
-  }
-}
 
 template <class Eval>
 __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eval&& eval) {
@@ -437,29 +420,31 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
   return wave_iters;
 }
 
-// Successors of one run: every OTHER slice reading a variable the run narrowed (`nar_all`, per lane: bit 0 x, 1 y, 2 z) runs
-// in the next round.  In a round based fixpoint nobody looks at the marks before the barrier, so they are issued once per
-// run, not after each narrowing.  Up to two successors per operand travel with the record (DevProblem::succ: 16-bit slice
-// ids, 0xffff = none) and need no memory access; the others come from the variable's 32-byte adjacency record, one L2
-// round trip for the whole wave.  Returns true (wave-uniform) when something was marked.
+// Successors of one run: the OTHER slices reading a variable the run narrowed, if they care about that kind of narrowing,
+// run in the next round.  `nar_all`, per lane: bits 2k / 2k+1 = lower bound raised / upper bound lowered of operand k
+// (0 x, 1 y, 2 z).  In a round based fixpoint nobody looks at the marks before the barrier, so they are issued once per
+// run, not after each narrowing.  Up to two successors per operand travel with the record (DevProblem::succ) and need no
+// memory access; the others come from the variable's 32-byte adjacency record, one L2 round trip for the whole wave.
+// Returns true (wave-uniform) when something was marked.
 __device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* nxt, int s, const int4 pr, const int4 sc, int nar_all) {
-  nar_all &= ~(pr.x >> 8) & 7;  // operands private to this slice are flagged at pack time
-  if (!__any(nar_all != 0)) return false;
+  const int priv = (pr.x >> 8) & 7;  // operands private to this slice are flagged at pack time
+  int ex = (priv & 1) ? 0 : (nar_all & 3), ey = (priv & 2) ? 0 : ((nar_all >> 2) & 3), ez = (priv & 4) ? 0 : ((nar_all >> 4) & 3);
+  if (!__any((ex | ey | ez) != 0)) return false;
   bool did = false;
-  if ((nar_all & 1) && !(sc.w & 1)) did |= mark_packed(nxt, (unsigned)sc.x);
-  if ((nar_all & 2) && !(sc.w & 2)) did |= mark_packed(nxt, (unsigned)sc.y);
-  if ((nar_all & 4) && !(sc.w & 4)) did |= mark_packed(nxt, (unsigned)sc.z);
-  const int lng = nar_all & sc.w;
-  if (__any(lng != 0)) {
+  if (ex && !(sc.w & 1)) { did |= mark_packed(nxt, (unsigned)sc.x, sc.w >> 4, ex); ex = 0; }
+  if (ey && !(sc.w & 2)) { did |= mark_packed(nxt, (unsigned)sc.y, sc.w >> 8, ey); ey = 0; }
+  if (ez && !(sc.w & 4)) { did |= mark_packed(nxt, (unsigned)sc.z, sc.w >> 12, ez); ez = 0; }
+  if (__any((ex | ey | ez) != 0)) {
     int dx = 0, dy = 0, dz = 0, ox = 0, oy = 0, oz = 0;
-    const bool tx = mark_var(P, nxt, pr.y, s, (lng & 1) != 0, dx, ox);
-    const bool ty = mark_var(P, nxt, pr.z, s, (lng & 2) != 0, dy, oy);
-    const bool tz = mark_var(P, nxt, pr.w, s, (lng & 4) != 0, dz, oz);
+    const bool tx = mark_var(P, nxt, pr.y, s, ex, dx, ox, did);
+    const bool ty = mark_var(P, nxt, pr.z, s, ey, dy, oy, did);
+    const bool tz = mark_var(P, nxt, pr.w, s, ez, dz, oz, did);
     const unsigned long long mx = __ballot(tx), my = __ballot(ty), mz = __ballot(tz);
-    if (mx) mark_tail(P, nxt, mx, dx, ox, s);
-    if (my) mark_tail(P, nxt, my, dy, oy, s);
-    if (mz) mark_tail(P, nxt, mz, dz, oz, s);
-    did |= lng != 0;
+    bool dt = false;
+    if (mx) dt |= mark_tail(P, nxt, mx, dx, ox, ex, s);
+    if (my) dt |= mark_tail(P, nxt, my, dy, oy, ey, s);
+    if (mz) dt |= mark_tail(P, nxt, mz, dz, oz, ez, s);
+    did |= dt;
   }
   return __any(did);
 }
@@ -521,15 +506,15 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     }
     if (root_pass) for (int s = tid; s < S; s += T) es.unent[s] = 1;  // nothing is known to be entailed yet
   } else {
-    for (int e = tid; e < cnt; e += T) {  // one lane per entry; long lists are finished cooperatively
-      const int4 h = P.adj_head[es.list[e]];
-      (void)mark_head(bm0, h, -1);
-    }
-    for (int e0 = wave * 64; e0 < cnt; e0 += T) {
+    for (int e0 = wave * 64; e0 < cnt; e0 += T) {  // one lane per entry; long lists are finished cooperatively
       const int e = e0 + lane;
-      int4 h = make_int4(0, 0, 0, 0);
-      if (e < cnt) h = P.adj_head[es.list[e]];
-      mark_rest(P, bm0, __ballot(h.x > 2), h, -1);
+      const int entry = e < cnt ? es.list[e] : 0;
+      const int ev = e < cnt ? ((entry >> 30) & 3) : 0;
+      int deg = 0, off = 0;
+      bool did = false;
+      const bool more = mark_var(P, bm0, entry & 0x3fffffff, -1, ev, deg, off, did);
+      const unsigned long long mm = __ballot(more);
+      if (mm) (void)mark_tail(P, bm0, mm, deg, off, ev, -1);
     }
   }
   if (tid == 0) { st(&sh.unent[0], 0); st(&sh.flag[0], 0); st(&sh.flag[1], 0); }
@@ -597,7 +582,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                     if (nz) bool_or(rz, 1u);
                     run_writes += (unsigned)ny + (unsigned)nz;
                     ch = ny | nz;
-                    nar = ((int)ny << 1) | ((int)nz << 2);
+                    nar = ((int)ny << 3) | ((int)nz << 4);  // y.ub lowered, z.lb raised
                   }
                 }
               }
@@ -653,7 +638,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                   if (now.lb > now.ub) st(&sh.bot, 1);
                 }
                 run_writes += (unsigned)(set0 | set1);
-                nar |= (int)(set0 | set1) | ((writer && (cyl | cyu)) ? 2 : 0);
+                nar |= (int)set1 | ((int)set0 << 1) | ((writer && cyl) ? 4 : 0) | ((writer && cyu) ? 8 : 0);  // b true / false, y.lb / y.ub
                 un_i |= in && !(((t || set1) && hit) || ((f || set0) && outside));
               }
               if (bad) {
@@ -702,7 +687,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                     const int kw = (int)(set1 | set0) + (int)cyl + (int)cyu;
                     run_writes += (unsigned)kw;
                     ch = kw != 0;
-                    nar = (int)(set1 | set0) | ((int)(cyl | cyu) << 1);
+                    nar = (int)set1 | ((int)set0 << 1) | ((int)cyl << 2) | ((int)cyu << 3);
                   }
                 }
               }
@@ -720,7 +705,8 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             const int want = (knobs(P) >> 28) & 15;
             const unsigned cm = key & CLASS_SET_MASK;
             const int cls_of_slice = (cm & (cm - 1)) ? 10 : __builtin_ctz(cm | 0x400u);
-            if (want == 0 || want - 1 == cls_of_slice) wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;
+            const bool useless = !__any(nar_all != 0);  // the run narrowed nothing
+            if ((want == 0 || want - 1 == cls_of_slice) && (!(knobs(P) & 0x40) || useless)) wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;  // 0x40: only the runs that narrowed nothing
           }
         }
         s = s_next;
@@ -736,12 +722,39 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   }
   if (lane == 0) tc.deductions += 64ull * wave_iters_total;
   if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += t - tp0; tp0 = t; }  // profiling: rounds
-  // leave both bitmaps empty for the next node (they are not after a failure), reduce the entailment bytes
+  // leave both bitmaps empty for the next node (they are not after a failure)
   for (int i = tid; i < 2 * W; i += T) es.dirty[i] = 0;
-  bool un = false;
-  for (int s = tid; s < S; s += T) un |= es.unent[s] != 0;
-  if (knobs(P) & 0x2) for (int s = tid; s < S; s += T) un |= es.unent[s] != 0;  // tuning: cost of the reduction
-  if (__any(un) && lane == 0) st(&sh.unent[0], 1);
+  // ---- is every propagator entailed (the node is a solution, barebones:971-993)?
+  // A byte says "some propagator of the slice was not entailed when the slice last ran".  With event filtering a slice may
+  // sleep through a narrowing that cannot make it propagate but can make it entailed (`b1 <= b2` once b1 is false), so a
+  // set byte is an upper bound.  One genuinely un-entailed propagator settles the question: the workgroup keeps such a
+  // WITNESS (BlockShared::witness, a propagator index) and wave 0 re-evaluates just that one -- the common case, no scan of
+  // the bytes at all.  When the witness has become entailed, the slices whose byte is set are examined one by one (their
+  // byte is corrected on the way) until a new witness turns up or none is left.
+  if (wave == 0 && !ld(&sh.bot) && !ld(&sh.abort)) {
+    auto unentailed_lanes = [&](int first_prop, bool whole_slice) -> unsigned long long {  // wave-uniform result
+      const int i = whole_slice ? first_prop + lane : first_prop;
+      const bool act = i < n;
+      const int4 pr = props[act ? i : 0];
+      const Itv X = load_dom<C>(store, P.n_int, pr.y), Y = load_dom<C>(store, P.n_int, pr.z), Z = load_dom<C>(store, P.n_int, pr.w);
+      const Cand c = evaluate_single(pr.x, X, Y, Z);
+      return __ballot(act && !c.ent);
+    };
+    int wit = __builtin_amdgcn_readfirstlane(ld(&sh.witness));
+    bool confirmed = wit >= 0 && unentailed_lanes(wit, false) != 0;
+    for (int base = 0; !confirmed && base < S; base += 64) {
+      const int s = base + lane;
+      unsigned long long m = __ballot(s < S && es.unent[s] != 0);
+      while (m && !confirmed) {
+        const int sl = base + __builtin_ctzll(m);
+        m &= m - 1;
+        const unsigned long long un = unentailed_lanes(sl * 64, true);
+        if (un) { wit = sl * 64 + __builtin_ctzll(un); confirmed = true; }
+        else if (lane == 0) es.unent[sl] = 0;  // every propagator of the slice is entailed now
+      }
+    }
+    if (lane == 0) { st(&sh.witness, confirmed ? wit : -1); st(&sh.unent[0], confirmed ? 1 : 0); }
+  }
   __syncthreads();
   all_entailed = !ld(&sh.unent[0]);
   return rounds + 1;
@@ -787,19 +800,19 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 
 // Thread 0 only: VStore::embed of one interval (decisions, objective bound).
 template <bool C>
-__device__ __forceinline__ bool embed0(int2* store, int ni, int* bot, int v, int lb, int ub) {
+__device__ __forceinline__ int embed0(int2* store, int ni, int* bot, int v, int lb, int ub) {  // returns EV_LB / EV_UB bits
   Itv d = load_dom<C>(store, ni, v);
-  bool changed = false;
-  if (lb > d.lb) { raise_lb<C>(store, ni, v, lb); d.lb = lb; changed = true; }
-  if (ub < d.ub) { lower_ub<C>(store, ni, v, ub); d.ub = ub; changed = true; }
+  int ev = 0;
+  if (lb > d.lb) { raise_lb<C>(store, ni, v, lb); d.lb = lb; ev |= EV_LB; }
+  if (ub < d.ub) { lower_ub<C>(store, ni, v, ub); d.ub = ub; ev |= EV_UB; }
   if (d.lb > d.ub) st(bot, 1);
-  return changed;
+  return ev;
 }
 // embed0 + event bookkeeping: the slices reading v must run in the first sweep of the next fixpoint
 template <bool EVENT, bool C>
 __device__ __forceinline__ void embed0_mark(const DevProblem& P, BlockShared& sh, const EventState& es, int2* store, int* bot, int v, int lb, int ub) {
-  const bool changed = embed0<C>(store, P.n_int, bot, v, lb, ub);
-  if (EVENT && changed) note_change(sh, es, v);
+  const int ev = embed0<C>(store, P.n_int, bot, v, lb, ub);
+  if (EVENT && ev) note_change(sh, es, v, ev);
 }
 
 // Key to MINIMISE for each variable order (barebones:193-221); ties resolve to the lowest index
@@ -1286,7 +1299,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     bs.why = 0; bs.pad_why = 0;
     bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
     sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0;
-    sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0;
+    sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; sh.witness = -1;
     t_start = t_mark = wall_clock64();
     sh.has_work = next_subproblem(P, sh, mbox) ? 1 : 0;
   }
@@ -1398,7 +1411,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
             const int2 ch = di.child[di.cur];
             raise_lb<C>(store, P.n_int, di.var, ch.x);
             lower_ub<C>(store, P.n_int, di.var, ch.y);
-            if (EVENT) note_change(sh, es, di.var);
+            if (EVENT) note_change(sh, es, di.var, EV_LB | EV_UB);
           }
           __syncthreads();
           if (tid == 0) {
@@ -1488,7 +1501,7 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
     int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : gstore;
     es.unent = reinterpret_cast<unsigned char*>(store) + P.unent_off;
     ThreadCounters tc;
-    if (tid == 0) { sh.bot = 0; sh.abort = 0; sh.red_key[0] = 0; sh.red_key[1] = 0; }
+    if (tid == 0) { sh.bot = 0; sh.abort = 0; sh.red_key[0] = 0; sh.red_key[1] = 0; sh.witness = -1; }
     __syncthreads();
     if (MEM >= TB_MEM_STORE_SHARED) { copy_store(store, gstore, VX); __syncthreads(); }
     if (RM) for (int q = tid; q < P.n_slices; q += blockDim.x) es.unent[q] = 1;

@@ -159,6 +159,13 @@ __host__ __device__ inline int class_of(int op, bool x_const, int x_value) {
   }
 }
 
+__device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y, const Itv Z);
+// The rules for lanes holding ARBITRARY records (not the 64 records of one slice): the slice-level class set of word0 is
+// replaced by "every class may be present", which sends evaluate_packed down its per-lane path.
+__device__ __forceinline__ Cand evaluate_single(int w0, const Itv X, const Itv Y, const Itv Z) {
+  return evaluate_packed((w0 & 0xffff) | (CLASS_SET_MASK << 16), X, Y, Z);
+}
+
 __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y, const Itv Z) {
   Cand c;
   int cls = w0 & 0xff;
