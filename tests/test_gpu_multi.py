@@ -235,3 +235,20 @@ def test_two_processes_share_one_gpu_through_bench(exchange, tmp_path):
     assert rec["multi_gpu"]["exchange"] == ("peer cells over xGMI" if exchange == "peer" else "host relay")
     assert len(rec["multi_gpu"]["per_rank"]) == 2
     assert all(r["nodes"] > 0 for r in rec["multi_gpu"]["per_rank"])
+
+
+@pytest.mark.parametrize("world,chunk", [(3, 0), (4, 2), (8, 0)])
+@pytest.mark.parametrize("rel", ["test_data/pat7.fzn", "test_data/sudoku_opt4.fzn"])
+def test_many_ranks_on_one_gpu_with_skewed_grids(rel, world, chunk):
+    """3, 4 and 8 ranks sharing the GPU, each with a different number of workgroups (1, 2, 4, ...): the small ones are robbed by
+    the big ones, ranges are stolen from ranges that were stolen themselves, and still every subproblem is accounted for once."""
+    tcn = load(rel)
+    power = 11
+    per_rank = [dict(or_nodes=min(32, 1 << r)) for r in range(world)]
+    out = run_group(tcn, world=world, power=power, fixpoint=2, eps_chunk_log2=chunk, per_rank=per_rank, snapshot_levels=2)
+    win, tot = merged(out, tcn)
+    assert win is not None and tcn.objective_of(win[0]) == ANSWERS[rel]
+    assert all(st["exhaustive"] == 1 for _, _, st in out)
+    assert tot["eps_solved_subproblems"] + tot["eps_skipped_subproblems"] == 2 ** power
+    assert tot["eps_local_subproblems"] == 2 ** power
+    assert tot["eps_stolen_subproblems"] > 0
