@@ -86,6 +86,56 @@ def test_network_analysis_statistics():
     assert q.returncode == 0 and "tcn_variables=" in q.stdout and "histogram" not in q.stdout and "fcn_variables" not in q.stdout
 
 
+def _stat_dict(out, key):
+    txt = re.search(r'mzn-stat: %s="\{([^}]*)\}"' % key, out).group(1)
+    d = {}
+    for item in filter(None, (x.strip() for x in txt.split(","))):
+        k, v = item.rsplit(":", 1)
+        k = k.strip()
+        d[k.strip("'") if k.startswith("'") else int(k)] = int(v)
+    return d
+
+
+@pytest.mark.parametrize("rel", ["test_data/pat2.fzn", "test_data/sudoku_opt4.fzn", "example_wordpress7_500.fzn"])
+def test_network_analysis_histogram_values(rel):
+    """Values, not only keys, of analyze_tcn (common_solving.hpp:728-826), recomputed here with numpy from the lowered
+    network: symbols (a comparison with truth 0 is its negation, an undecided one is reified too), degrees split by
+    assigned / unassigned, domain sizes of the bounded variables."""
+    from collections import Counter
+    import numpy as np
+    from turbo_amd import frontend
+    path = os.path.join(BENCH, rel)
+    r = subprocess.run([TURBO, "-s", "-t", "3000", path], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    tcn = frontend.load_fzn(path)
+    lb, ub = tcn.store["lb"].astype(np.int64), tcn.store["ub"].astype(np.int64)
+    pr = tcn.props
+    sym = ["+", "*", "/", "%", "min", "max", "=", "<="]
+    ops, reified = Counter(), Counter()
+    for op, x in zip(pr["op"].tolist(), pr["x"].tolist()):
+        if op >= 6:
+            if lb[x] == ub[x]:
+                ops[("!=" if op == 6 else ">") if lb[x] == 0 else sym[op]] += 1
+            else:
+                ops[sym[op]] += 1
+                reified[sym[op]] += 1
+        else:
+            ops[sym[op]] += 1
+    occ = np.bincount(np.concatenate([pr["x"], pr["y"], pr["z"]]), minlength=len(lb))
+    inf = (lb == -2 ** 31) | (ub == 2 ** 31 - 1)
+    assigned = ~inf & (lb == ub)
+    assert _stat_dict(r.stdout, "tcn_histogram_symbols") == dict(ops)
+    assert _stat_dict(r.stdout, "tcn_histogram_reified_predicates") == dict(reified)
+    assert _stat_dict(r.stdout, "tcn_histogram_assigned_vars_degree") == dict(Counter(occ[assigned].tolist()))
+    assert _stat_dict(r.stdout, "tcn_histogram_unassigned_vars_degree") == dict(Counter(occ[~assigned].tolist()))
+    assert _stat_dict(r.stdout, "tcn_histogram_vars_dom_size") == dict(Counter((ub - lb + 1)[~inf].tolist()))
+    g = lambda k: int(re.search(r"mzn-stat: %s=(\d+)" % k, r.stdout).group(1))
+    assert g("tcn_variables") == len(lb) and g("tcn_constraints") == len(pr)
+    assert g("tcn_assigned_variables") == int(assigned.sum()) and g("tcn_unbounded_variables") == int(inf.sum())
+    assert g("tcn_assigned_var_occurrences") == int(occ[assigned].sum())
+    assert g("tcn_unassigned_var_occurrences") == int(occ[~assigned].sum())
+
+
 def test_timeout_is_honoured_and_reported():
     r = subprocess.run([TURBO, "-s", "-t", "1500", os.path.join(BENCH, "example_wordpress7_500.fzn")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
