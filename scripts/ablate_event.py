@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 from turbo_amd import capi, preprocess
 _, tcn, _ = preprocess.load_fzn_simplified(os.path.join(ROOT, "benchmarks", "example_wordpress7_500.fzn"))
 base = None
-for name, bits in (("baseline", 0), ("marks x2", 1), ("entailment reduction x2", 2), ("snapshot copy x2", 4), ("one more iteration per run", 8), ("baseline again", 0)):
+for name, bits in (("baseline", 0), ("marks x2", 1), ("snapshot copy x2", 4), ("one more iteration per run", 8), ("baseline again", 0)):
     cfg = capi.make_config(fixpoint=2, stop_after_n_nodes_total=6_000_000, timeout_ms=120000, debug=bits)
     best = 0
     for _ in range(3):

@@ -495,7 +495,16 @@ InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, c
     const bool zc = dz.lb == dz.ub && dz.lb != TB_NINF && dz.lb != TB_PINF;
     return (k1 << 32) | (zc ? (long long)q.y + 1 : 0);
   };
-  std::stable_sort(n.props.begin(), n.props.end(), [&](const tb_prop& a, const tb_prop& c) { return key2(a) < key2(c); });
+  // ... and inside one y by the constant, so that a group's lanes are in value order (dense groups: bit scans instead of walks)
+  auto key3 = [&](const tb_prop& q) -> long long {
+    if (!event || (q.op != TB_EQ && q.op != TB_LEQ)) return 0;
+    const tb_itv dz = n.store[(size_t)q.z];
+    return (dz.lb == dz.ub && dz.lb != TB_NINF && dz.lb != TB_PINF) ? (long long)dz.lb : 0;
+  };
+  std::stable_sort(n.props.begin(), n.props.end(), [&](const tb_prop& a, const tb_prop& c) {
+    const long long ka = key2(a), kc = key2(c);
+    return ka != kc ? ka < kc : key3(a) < key3(c);
+  });
   return n;
 }
 
@@ -1132,6 +1141,22 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
   const double ns_per_tick = 1e6 / (double)s->caps.wall_khz;
   long long best_block = -1;
   long long first_idle = -1, last_idle = 0, wait_ticks = 0;
+#ifdef TB_TUNING
+  if ((s->cfg.reserved[0] & 0x10000) && s->cfg.verbose) {  // wave 0's time inside the rounds of the event fixpoint (kernels.hpp: TB_PROF_MARK)
+    double d[24] = {0};
+    unsigned long long nodes = 0;
+    for (size_t b = 0; b < B; ++b) { for (int i = 0; i < 24; ++i) d[i] += (double)bst[b].dbg[i]; nodes += bst[b].nodes; }
+    const double n = (double)std::max<unsigned long long>(1, nodes);
+    std::fprintf(stderr, "%% event-profile (wave 0, core cycles per node): fetch %.0f body %.0f marks %.0f barrier %.0f; runs/node %.2f rounds/node %.2f\n",
+                 16 * d[0] / n, 16 * d[1] / n, 16 * d[2] / n, 16 * d[3] / n, d[4] / n, d[5] / n);
+    std::fprintf(stderr, "%% event-profile body by kind: implications %.0f (%.2f runs) channelling %.0f reified-const %.0f generic %.0f (%.2f runs)\n",
+                 16 * d[6] / n, d[11] / n, 16 * d[7] / n, 16 * d[8] / n, 16 * d[9] / n, d[10] / n);
+    std::fprintf(stderr, "%% event-profile marks per node: runs with marks %.2f (%.1f lanes), through adjacency records %.2f (%.1f lanes), with a tail %.2f\n",
+                 d[12] / n, d[15] / n, d[13] / n, d[16] / n, d[14] / n);
+    std::fprintf(stderr, "%% event-profile degree (reader slices) of the variables marked through their record, per node: <=4: %.1f  5-6: %.1f  7-11: %.1f  more: %.1f\n",
+                 d[17] / n, d[18] / n, d[19] / n, d[20] / n);
+  }
+#endif
   for (size_t b = 0; b < B; ++b) {
     const BlockStats& x = bst[b];
     st.nodes += x.nodes; st.fails += x.fails; st.solutions += x.solutions;

@@ -5,7 +5,7 @@
 // layout of the event kernels), the propagator bytecodes are 16-byte records read one per lane (coalesced
 // global_load_dwordx4, or ds_read_b128 when they fit in LDS too).  Sweeping fixpoints (AC1 / WAC1): the "has
 // changed" flag is reduced per wave with a ballot and published through one LDS word, one s_barrier separates
-// two sweeps.  Event-driven fixpoint: an asynchronous worklist of dirty 64-propagator slices, no barrier.
+// two sweeps.  Event-driven fixpoint: rounds over a bitmap of dirty 64-propagator slices, one s_barrier per round.
 //
 // Mirrors, without their data structures:
 //   gpu_barebones_solve   include/barebones_dive_and_solve.hpp:620-901   (workgroup main loop)
@@ -15,6 +15,15 @@
 
 #include "device_types.hpp"
 #include "propagators.hpp"
+
+// Build-time variants of the 256-thread event kernel (experiments): waves per SIMD the register allocator is asked for,
+// software prefetch of the next slice's records (a loss below 5 waves' worth of registers: the prefetched records spill).
+#ifndef TB_EVENT_WAVES
+#define TB_EVENT_WAVES 7
+#endif
+#ifndef TB_EVENT_PREFETCH
+#define TB_EVENT_PREFETCH 0
+#endif
 
 namespace tb {
 
@@ -426,11 +435,18 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
 // run, not after each narrowing.  Up to two successors per operand travel with the record (DevProblem::succ) and need no
 // memory access; the others come from the variable's 32-byte adjacency record, one L2 round trip for the whole wave.
 // Returns true (wave-uniform) when something was marked.
-__device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* nxt, int s, const int4 pr, const int4 sc, int nar_all) {
+__device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* nxt, int s, const int4 pr, const int4 sc, int nar_all, int* census = nullptr) {
   const int priv = (pr.x >> 8) & 7;  // operands private to this slice are flagged at pack time
   int ex = (priv & 1) ? 0 : (nar_all & 3), ey = (priv & 2) ? 0 : ((nar_all >> 2) & 3), ez = (priv & 4) ? 0 : ((nar_all >> 4) & 3);
   if (!__any((ex | ey | ez) != 0)) return false;
   bool did = false;
+#ifdef TB_TUNING
+  if (census != nullptr) {  // knob 0x10000: runs with something to mark [12], lanes with something to mark [15], ... through the adjacency records [13] / lanes [16], ... with a tail [14]
+    const unsigned long long m0 = __ballot((ex | ey | ez) != 0);
+    const unsigned long long m1 = __ballot((ex && (sc.w & 1)) || (ey && (sc.w & 2)) || (ez && (sc.w & 4)));
+    if ((threadIdx.x & 63) == 0) { census[12] += 1; census[15] += __builtin_popcountll(m0); if (m1) { census[13] += 1; census[16] += __builtin_popcountll(m1); } }
+  }
+#endif
   if (ex && !(sc.w & 1)) { did |= mark_packed(nxt, (unsigned)sc.x, sc.w >> 4, ex); ex = 0; }
   if (ey && !(sc.w & 2)) { did |= mark_packed(nxt, (unsigned)sc.y, sc.w >> 8, ey); ey = 0; }
   if (ez && !(sc.w & 4)) { did |= mark_packed(nxt, (unsigned)sc.z, sc.w >> 12, ez); ez = 0; }
@@ -441,6 +457,14 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* n
     const bool tz = mark_var(P, nxt, pr.w, s, ez, dz, oz, did);
     const unsigned long long mx = __ballot(tx), my = __ballot(ty), mz = __ballot(tz);
     bool dt = false;
+#ifdef TB_TUNING
+    if (census != nullptr) {  // degree histogram of the variables marked through their adjacency record: <= 4 [17], 5-6 [18], 7-11 [19], more [20]
+      if ((mx | my | mz) && (threadIdx.x & 63) == 0) census[14] += 1;
+      const int degs[3] = {ex ? dx : 0, ey ? dy : 0, ez ? dz : 0};
+      for (int q = 0; q < 3; ++q)
+        if (degs[q] > 0) (void)__hip_atomic_fetch_add(&census[degs[q] <= 4 ? 17 : (degs[q] <= 6 ? 18 : (degs[q] <= 11 ? 19 : 20))], 1, TB_RLX, TB_WG);
+    }
+#endif
     if (mx) dt |= mark_tail(P, nxt, mx, dx, ox, ex, s);
     if (my) dt |= mark_tail(P, nxt, my, dy, oy, ey, s);
     if (mz) dt |= mark_tail(P, nxt, mz, dz, oz, ez, s);
@@ -467,6 +491,16 @@ constexpr unsigned kinds(unsigned kx, unsigned ky, unsigned kz) { return (kx | (
 constexpr unsigned KEY_LEQT_BB = (1u << K_LEQ_T) | kinds(3, 2, 2);   // b1 <= b2 (implication between two Booleans)
 constexpr unsigned KEY_EQR_BIC = (1u << K_EQ_R) | kinds(2, 1, 3);    // b = (y = k)
 constexpr unsigned KEY_LEQR_BIC = (1u << K_LEQ_R) | kinds(2, 1, 3);  // b = (y <= k)
+
+// Tuning build, knob 0x10000: wave 0 splits its time in the rounds into record fetch / slice body / successor marks / barrier
+// (core-clock ticks >> 4 in BlockStats::dbg[0..3], runs and rounds in dbg[4..5]; printed by tb_session_finish when verbose).
+#ifdef TB_TUNING
+#define TB_PROF_MARK(slot) do { if (prof && wave == 0) { const long long t_ = clock64(); if (lane == 0) sh.bs.dbg[slot] += (int)((t_ - tprof) >> 4); tprof = t_; } } while (0)
+#define TB_PROF_COUNT(slot) do { if (prof && wave == 0 && lane == 0) sh.bs.dbg[slot] += 1; } while (0)
+#else
+#define TB_PROF_MARK(slot) do { } while (0)
+#define TB_PROF_COUNT(slot) do { } while (0)
+#endif
 
 // LDS bytes of the two dirty bitmaps of the event-driven fixpoint (current round, next round).
 __host__ __device__ inline size_t dirty_region_bytes(int dirty_words) { return (((size_t)dirty_words * 8 + 15) / 16) * 16; }
@@ -527,6 +561,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   for (int b = wave; b < 32; b += nw) own |= 1u << b;
   int rounds = 0;
   unsigned wave_iters_total = 0;  // wave-uniform
+#ifdef TB_TUNING
+  long long tprof = prof ? clock64() : 0;
+#endif
   for (;; ++rounds) {
     const int k = rounds % 3;
     unsigned* cur = es.dirty + (rounds & 1) * W;
@@ -552,11 +589,23 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
         return (base + wl) * 32 + b;
       };
       int s = next_slice();
+#if TB_EVENT_PREFETCH
+      int4 pr_c = idle_record(), sc_c = make_int4(0, 0, 0, 0);
+      if (s >= 0) { pr_c = props[s * 64 + lane]; sc_c = P.succ[s * 64 + lane]; }
+#endif
       while (s >= 0) {
         const int s_next = next_slice();
+#if TB_EVENT_PREFETCH
+        const int sp = s_next >= 0 ? s_next : s;
+        const int4 pr_n = props[sp * 64 + lane], sc_n = P.succ[sp * 64 + lane];
+#endif
         // (no software prefetch of the next slice's records: under the 80-register budget of this kernel the prefetched
         //  int4 lived in scratch, and the round trip cost more than the L2 latency it hid -- 15.3 -> 19.3e6 nodes/s without it)
+#if TB_EVENT_PREFETCH
+        const int4 pr = pr_c;
+#else
         const int4 pr = props[s * 64 + lane];  // the arrays are padded to whole slices
+#endif
         if (ld(&sh.bot) | ld(&sh.abort)) break;  // the node failed in another wave
         if (!(drop_entailed && es.unent[s] == 0)) {
           const bool act = s * 64 + lane < n;
@@ -565,7 +614,12 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
           unsigned wave_iters;
           unsigned run_writes = 0;  // per lane, folded into the 64-bit counter once per run
           int nar_all = 0;          // operands this lane narrowed during the run
+#if TB_EVENT_PREFETCH
+          const int4 sc = sc_c;
+#else
           const int4 sc = P.succ[s * 64 + lane];  // needed after the run only: the load hides behind it
+#endif
+          TB_PROF_MARK(0);
           if (C && key == KEY_LEQT_BB) {
             // y <= z on two Booleans, straight on their 2-bit encodings (bit 0: lb raised to 1, bit 1: ub lowered to 0):
             // z.ub = 0 forces y.ub = 0, y.lb = 1 forces z.lb = 1; entailed once y.ub = 0 or z.lb = 1.
@@ -592,34 +646,66 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             // Channelling propagators b_i = (y = k_i) -- the index of an element constraint against its positions, its value
             // against the table.  Evaluated one by one, a false b_i only strips k_i when it sits exactly on a bound of y, so
             // a run of m excluded values costs m wave iterations.  Here the lanes that share a variable y (the records are
-            // sorted by y: a slice holds one to three groups) compute the fixpoint of their rules jointly: the bounds walk over
-            // the excluded values with ballots (scalar work, no memory traffic), then every b_i outside the new bounds
-            // becomes false and, if y is assigned, its b_i true.  Same fixpoint, one pass, no confirmation pass.
+            // sorted by y: a slice holds a few groups of neighbouring lanes) compute the fixpoint of their rules jointly, all
+            // groups at once: every lane carries its group's bounds, a ballot masked with the group's lanes says whether some
+            // false b_i sits on a bound, and the bounds step over the excluded values in registers -- no memory traffic; then
+            // every b_i outside the new bounds becomes false and, if y is assigned, its b_i true.  Same fixpoint, one pass.
             const BoolRef rx = bool_ref(store, P.n_int, pr.y, act);
             const int kc = load_dom<C>(store, P.n_int, act ? pr.w : 0).lb;
+            const int yv = act ? pr.z : 0;
             const bool single_pass = ((__builtin_amdgcn_readfirstlane(pr.x) >> 11) & 1) != 0;
+            // my group: the lanes between two changes of y (wave-uniform masks, per-lane selection)
+            const int y_prev = __shfl_up(yv, 1, 64);
+            const unsigned long long actm = __ballot(act);
+            const unsigned long long starts = __ballot(act && (lane == 0 || yv != y_prev));
+            const unsigned long long upto = (2ull << lane) - 1ull;                  // lanes 0..lane
+            const int g_start = 63 - __builtin_clzll((starts & upto) | 1ull);
+            const unsigned long long above = starts & ~upto;
+            const unsigned long long below_end = above ? ((above & (0ull - above)) - 1ull) : ~0ull;  // lanes before the next group's first
+            const unsigned long long gmask = act ? (below_end & ~((1ull << g_start) - 1ull) & actm) : 0ull;
+            const bool writer = act && lane == g_start;
+            // The records of one y are sorted by k: when the k of a group are consecutive integers (the usual channelling of a
+            // whole domain) lane g_start + (v - k0) holds value v, and "how far do the excluded values reach from this bound" is a
+            // bit scan over the ballot of the false b_i instead of a walk.
+            const int k0 = __shfl(kc, g_start, 64);
+            const int g_last = g_start + __builtin_popcountll(gmask) - 1;
+            const int k_last = k0 + (g_last - g_start);
+            const bool dense = !__any(act && (k0 > 0x7fffff00 || kc != k0 + (lane - g_start)));
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               const unsigned xb = bool_bits(rx);
+              const Itv Y = load_dom<false>(store, P.n_int, yv);
               const bool t = act && (xb & 1u), f = act && (xb & 2u), u = act && xb == 0u;
-              bool bad = __any(act && xb == 3u);
-              un_i = false;
-              for (unsigned long long rem = __ballot(act); rem && !bad;) {
-                const int leader = __builtin_ctzll(rem);
-                const int yv = __builtin_amdgcn_readlane(pr.z, leader);
-                const bool in = act && pr.z == yv;  // my group
-                rem &= ~__ballot(in);
-                const Itv Y = load_dom<false>(store, P.n_int, yv);
-                int lb = __builtin_amdgcn_readfirstlane(Y.lb), ub = __builtin_amdgcn_readfirstlane(Y.ub);
-                const int lb0 = lb, ub0 = ub;
-                for (unsigned long long tm = __ballot(in && t); tm; tm &= tm - 1) {  // y = k for every true b (normally at most one)
-                  const int k = __builtin_amdgcn_readlane(kc, __builtin_ctzll(tm));
-                  lb = lb > k ? lb : k; ub = ub < k ? ub : k;
+              int lb = Y.lb, ub = Y.ub;
+              for (unsigned long long tm = __ballot(t); tm; tm &= tm - 1) {  // y = k for every true b (normally at most one per group)
+                const int l = __builtin_ctzll(tm);
+                const int k = __builtin_amdgcn_readlane(kc, l);
+                if ((gmask >> l) & 1ull) { lb = lb > k ? lb : k; ub = ub < k ? ub : k; }
+              }
+              if (dense) {
+                const unsigned long long fm = __ballot(f) & gmask;
+                if (lb <= ub && lb >= k0 && lb <= k_last) {
+                  const unsigned long long open_up = ~(fm >> (g_start + (lb - k0)));  // first lane from lb's upwards whose b is not false
+                  lb += open_up ? __builtin_ctzll(open_up) : 64;
                 }
-                while (lb <= ub && __any(in && f && kc == lb)) lb = sat_add(lb, 1);  // excluded values on the bounds
-                while (lb <= ub && __any(in && f && kc == ub)) ub = sat_sub(ub, 1);
-                if (lb > ub) { bad = true; break; }
+                if (lb <= ub && ub >= k0 && ub <= k_last) {
+                  const unsigned long long open_dn = ~(fm << (63 - (g_start + (ub - k0))));
+                  ub -= open_dn ? __builtin_clzll(open_dn) : 64;
+                }
+              } else {
+                for (;;) {  // excluded values on the bounds, one step at a time, every group at its own pace
+                  const unsigned long long ml = __ballot(f && kc == lb), mu = __ballot(f && kc == ub);
+                  const bool live = lb <= ub;
+                  const bool al = live && (ml & gmask) != 0ull, au = live && (mu & gmask) != 0ull;
+                  if (!__any(al | au)) break;
+                  if (al) lb = sat_add(lb, 1);
+                  if (au) ub = sat_sub(ub, 1);
+                }
+              }
+              const bool bad = __any(act && (xb == 3u || lb > ub));
+              un_i = act;
+              if (!bad) {
                 const bool outside = kc < lb || kc > ub, hit = lb == ub && kc == lb;
-                const bool set0 = in && u && outside, set1 = in && u && hit;
+                const bool set0 = u && outside, set1 = u && hit;
                 // There is no confirmation pass to notice that ANOTHER wave emptied a domain I narrow in the same round (two slices
                 // of one y walking its bounds towards each other, a b made true elsewhere while I make it false): look at what
                 // my own atomics left behind.
@@ -628,24 +714,17 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                   const unsigned before = (__hip_atomic_fetch_or(rx.word, mine << rx.shift, TB_RLX, TB_WG) >> rx.shift) & 3u;
                   if ((before | mine) == 3u) st(&sh.bot, 1);
                 }
-                const bool cyl = lb != lb0, cyu = ub != ub0;  // wave-uniform
-                const bool writer = (threadIdx.x & 63) == leader;
-                if (writer && (cyl | cyu)) {
+                const bool cyl = writer && lb != Y.lb, cyu = writer && ub != Y.ub;
+                if (cyl | cyu) {
                   if (cyl) raise_lb<false>(store, P.n_int, yv, lb);
                   if (cyu) lower_ub<false>(store, P.n_int, yv, ub);
-                  run_writes += (unsigned)cyl + (unsigned)cyu;
                   const Itv now = load_dom<false>(store, P.n_int, yv);
                   if (now.lb > now.ub) st(&sh.bot, 1);
                 }
-                run_writes += (unsigned)(set0 | set1);
-                nar |= (int)set1 | ((int)set0 << 1) | ((writer && cyl) ? 4 : 0) | ((writer && cyu) ? 8 : 0);  // b true / false, y.lb / y.ub
-                un_i |= in && !(((t || set1) && hit) || ((f || set0) && outside));
-              }
-              if (bad) {
-                if (lane == 0) st(&sh.bot, 1);
-                un_i = act;
-                nar = 0;
-              }
+                run_writes += (unsigned)(set0 | set1) + (unsigned)cyl + (unsigned)cyu;
+                nar = (int)set1 | ((int)set0 << 1) | (cyl ? 4 : 0) | (cyu ? 8 : 0);  // b true / false, y.lb / y.ub
+                un_i = act && !(((t || set1) && hit) || ((f || set0) && outside));
+              } else if (lane == 0) st(&sh.bot, 1);
               // When no truth variable occurs twice in the slice (word0 bit 11, pack_props) the joint fixpoint is reached and no
               // confirmation pass is needed; otherwise a b made false for one lane may still have to act through another one.
               ch = single_pass ? false : nar != 0;
@@ -698,7 +777,21 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               apply<true, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, 0, &nar);
             });
           }
+#ifdef TB_TUNING
+          if (prof && wave == 0) {  // body time by kind of run: dbg[6] Boolean implications, [7] joint channelling, [8] b = (y ~ k), [9] generic; dbg[10], dbg[11]: generic / implication runs
+            const long long t_ = clock64();
+            const int kind = (C && key == KEY_LEQT_BB) ? 6 : ((C && key == KEY_EQR_BIC && !(knobs(P) & 0x4000000)) ? 7 : ((C && (key == KEY_EQR_BIC || key == KEY_LEQR_BIC)) ? 8 : 9));
+            if (lane == 0) { sh.bs.dbg[1] += (int)((t_ - tprof) >> 4); sh.bs.dbg[kind] += (int)((t_ - tprof) >> 4); if (kind == 9) sh.bs.dbg[10] += 1; if (kind == 6) sh.bs.dbg[11] += 1; }
+            tprof = t_;
+          }
+#endif
+#ifdef TB_TUNING
+          marked |= mark_successors(P, nxt, s, pr, sc, nar_all, (prof && wave == 0) ? sh.bs.dbg : nullptr);
+#else
           marked |= mark_successors(P, nxt, s, pr, sc, nar_all);
+#endif
+          TB_PROF_MARK(2);
+          TB_PROF_COUNT(4);
           if (knobs(P) & 0x1) marked |= mark_successors(P, nxt, s, pr, sc, nar_all);  // tuning: cost of the marks (idempotent)
           tc.writes += run_writes;
           {  // profiling (tuning build): 0x400000 counts slice runs instead of iterations; bits 28-31 = 1 + class to count only that class (11 = mixed slices)
@@ -709,6 +802,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             if ((want == 0 || want - 1 == cls_of_slice) && (!(knobs(P) & 0x40) || useless)) wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;  // 0x40: only the runs that narrowed nothing
           }
         }
+#if TB_EVENT_PREFETCH
+        pr_c = pr_n; sc_c = sc_n;
+#endif
         s = s_next;
       }
     }
@@ -718,6 +814,8 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       if ((rounds & 255) == 255 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
     }
     __syncthreads();  // the narrowings and the marks of this round are visible to everybody
+    TB_PROF_MARK(3);
+    TB_PROF_COUNT(5);
     if (!ld(&sh.flag[k]) || ld(&sh.bot) || ld(&sh.abort)) break;
   }
   if (lane == 0) tc.deductions += 64ull * wave_iters_total;
@@ -1256,13 +1354,11 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
 
 constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 255) / 256 * 256);
 
-// The event-driven variant is latency bound: its 256-thread form asks the register allocator for 6 waves per
-// SIMD (<= 80 VGPRs) so that 6 workgroups are resident per CU; the sweep variants are VALU bound and keep 4.
+// The event-driven variant is latency bound: its 256-thread form asks the register allocator for 7 waves per
+// SIMD (<= 72 VGPRs) so that 7 workgroups are resident per CU when their stores fit (wordpress7_500: 7 x 22.7 KB of
+// LDS; measured 17.9 / 20.5 / 22.3 / 23.4e6 nodes/s with 4 / 5 / 6 / 7); the sweep variants are VALU bound and keep 4.
 // OPT: the COMPACT store layout for the event kernels, entailed-slice removal for the sweeping ones.
 template <int MEM, int TMAX, bool EVENT, bool OPT>
-#ifndef TB_EVENT_WAVES
-#define TB_EVENT_WAVES 6
-#endif
 __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES : (TMAX == 256 ? 5 : 4)) solve_kernel(DevProblem P, Mailbox* mbox) {
   constexpr bool C = EVENT && OPT, RM = !EVENT && OPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1297,6 +1393,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     bs.eps_solved = bs.eps_skipped = bs.store_writes = bs.stolen = 0;
     bs.wait_ticks = 0;
     bs.why = 0; bs.pad_why = 0;
+    for (int i = 0; i < 24; ++i) bs.dbg[i] = 0;
     bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
     sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0;
     sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; sh.witness = -1;
