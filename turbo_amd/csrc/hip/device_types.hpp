@@ -105,7 +105,7 @@ struct BlockStats {
   int depth_max, exhaustive, num_blocks_done, best_bound;
   long long best_sub;               // subproblem index that produced best_store (-1: none)
   int why, pad_why;                 // debugging: reasons that cleared `exhaustive` (bit mask)
-  int dbg[24];                      // tuning build: first violation found by the self-check of the event fixpoint
+  int dbg[32];                      // tuning build: first violation found by the self-check of the event fixpoint
 };
 
 struct DevProblem {

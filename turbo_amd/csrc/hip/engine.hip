@@ -349,26 +349,78 @@ void pack_var_adj(const Adjacency& adj, std::vector<int4>* heads, std::vector<in
 }
 
 // Successor slices of each record's operands for the event-driven fixpoint (device_types.hpp: DevProblem::succ): x, y, z =
-// up to two OTHER slices reading the operand (16-bit ids, 0xffff = none); w = bit k: operand k has more of them (walk
-// var_adj), bits 4 + 2 (2 k + j): interest of the j-th packed successor of operand k.
-std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacency& adj) {
+// up to two OTHER slices reading the operand (16-bit ids, 0xffff = none); w: bits 4 + 2 (2 k + j) = interest of the j-th packed
+// successor of operand k; bit k = the slices interested in a RAISED LOWER bound of operand k do not all fit (walk var_adj for
+// that event), bit 16 + k = the same for a LOWERED UPPER bound.  The two slots go to the event they can cover completely: a
+// Boolean of wordpress7_500 typically has five readers, all of them interested in "became true" and one in "became false" --
+// per reader that is three slots too few, per event the common one needs no memory access at all.
+// Channelling slices (KEY_EQR_BIC, evaluated jointly by the lanes that share y): every lane of a group knows what happened to y,
+// so y's readers are dealt out over the group's lanes, two each (bit 20 of w: "y is reported by every lane of its group"), when
+// they all fit; a y with ten readers then needs no walk either.
+std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacency& adj, const std::vector<int4>& records, bool deal_groups) {
   std::vector<int4> out(((size_t)n_props + 63) / 64 * 64, make_int4(-1, -1, -1, 0));
+  std::vector<int> dealt((size_t)n_props, -1);  // index inside its group of a lane whose y slots are dealt
+  if (deal_groups)
+    for (int32_t base = 0; base < n_props; base += 64) {
+      if (((unsigned)records[(size_t)base].x >> 16) != KEY_EQR_BIC) continue;
+      const int32_t end = std::min(n_props, base + 64);
+      for (int32_t a = base; a < end;) {
+        int32_t b = a + 1;
+        while (b < end && props[b].y == props[a].y) ++b;
+        size_t others = 0;
+        for (const Reader& r : adj.lists[(size_t)props[a].y]) others += r.slice != base / 64 ? 1 : 0;
+        if (others > 2 && others <= 2 * (size_t)(b - a))
+          for (int32_t i = a; i < b; ++i) dealt[(size_t)i] = i - a;
+        a = b;
+      }
+    }
   for (int32_t i = 0; i < n_props; ++i) {
     const int s = i / 64;
     const int vs[3] = {props[i].x, props[i].y, props[i].z};
     unsigned packed[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
     int flags = 0;
     for (int k = 0; k < 3; ++k) {
+      if (k == 1 && dealt[(size_t)i] >= 0) {
+        unsigned o[2] = {0xffffu, 0xffffu};
+        int in[2] = {0, 0}, n = 0, idx = 0;
+        for (const Reader& r : adj.lists[(size_t)vs[k]]) {
+          if (r.slice == s) continue;
+          if (idx / 2 == dealt[(size_t)i]) { o[n] = (unsigned)r.slice; in[n] = r.interest; ++n; }
+          ++idx;
+        }
+        packed[k] = (o[1] << 16) | o[0];
+        flags |= (in[0] << (4 + 2 * (2 * k))) | (in[1] << (4 + 2 * (2 * k + 1))) | (1 << 20);
+        continue;
+      }
+      std::vector<Reader> others;
+      for (const Reader& r : adj.lists[(size_t)vs[k]]) if (r.slice != s) others.push_back(r);
+      int n_lb = 0, n_ub = 0;
+      for (const Reader& r : others) { n_lb += (r.interest & 1) ? 1 : 0; n_ub += (r.interest & 2) ? 1 : 0; }
+      // which event gets the slots when both do not fit: the one that fits; the upper bound if both would
+      int first = 3;
+      if (others.size() > 2) first = n_ub <= 2 ? 2 : (n_lb <= 2 ? 1 : 0);
       unsigned o[2] = {0xffffu, 0xffffu};
       int in[2] = {0, 0};
       int n = 0;
-      bool too_many = false;
-      for (const Reader& r : adj.lists[(size_t)vs[k]]) {
-        if (r.slice == s) continue;
-        if (n < 2) { o[n] = (unsigned)r.slice; in[n] = r.interest; ++n; } else too_many = true;
-      }
-      if (too_many) flags |= 1 << k;
-      else { packed[k] = (o[1] << 16) | o[0]; flags |= (in[0] << (4 + 2 * (2 * k))) | (in[1] << (4 + 2 * (2 * k + 1))); }
+      for (int pass = 0; pass < 2 && first != 0; ++pass)
+        for (const Reader& r : others) {
+          const bool wanted = (r.interest & first) != 0;
+          if ((pass == 0) != wanted || n >= 2) continue;
+          o[n] = (unsigned)r.slice; in[n] = r.interest; ++n;
+        }
+      auto covered = [&](int ev) {  // every other reader interested in `ev` sits in a slot
+        for (const Reader& r : others) {
+          if (!(r.interest & ev)) continue;
+          bool found = false;
+          for (int j = 0; j < n; ++j) found |= o[j] == (unsigned)r.slice;
+          if (!found) return false;
+        }
+        return true;
+      };
+      if (!covered(1)) flags |= 1 << k;
+      if (!covered(2)) flags |= 1 << (16 + k);
+      packed[k] = (o[1] << 16) | o[0];
+      flags |= (in[0] << (4 + 2 * (2 * k))) | (in[1] << (4 + 2 * (2 * k + 1)));
     }
     out[(size_t)i] = make_int4((int)packed[0], (int)packed[1], (int)packed[2], flags);
   }
@@ -655,7 +707,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj, lay.n_int);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
     {
-      const std::vector<int4> succ = pack_succ(n_props, net.props.data(), adj);
+      const std::vector<int4> succ = pack_succ(n_props, net.props.data(), adj, packed, !(cfg.reserved[0] & 0x4000000));
       int4* d_succ = nullptr;
       if ((rc = bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
       if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -794,7 +846,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj, lay.n_int);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
     {
-      const std::vector<int4> succ = pack_succ(n_props, net.props.data(), adj);
+      const std::vector<int4> succ = pack_succ(n_props, net.props.data(), adj, packed, !(s->cfg.reserved[0] & 0x4000000));
       int4* d_succ = nullptr;
       if ((rc = s->bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
       if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -1143,9 +1195,9 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
   long long first_idle = -1, last_idle = 0, wait_ticks = 0;
 #ifdef TB_TUNING
   if ((s->cfg.reserved[0] & 0x10000) && s->cfg.verbose) {  // wave 0's time inside the rounds of the event fixpoint (kernels.hpp: TB_PROF_MARK)
-    double d[24] = {0};
+    double d[32] = {0};
     unsigned long long nodes = 0;
-    for (size_t b = 0; b < B; ++b) { for (int i = 0; i < 24; ++i) d[i] += (double)bst[b].dbg[i]; nodes += bst[b].nodes; }
+    for (size_t b = 0; b < B; ++b) { for (int i = 0; i < 32; ++i) d[i] += (double)bst[b].dbg[i]; nodes += bst[b].nodes; }
     const double n = (double)std::max<unsigned long long>(1, nodes);
     std::fprintf(stderr, "%% event-profile (wave 0, core cycles per node): fetch %.0f body %.0f marks %.0f barrier %.0f; runs/node %.2f rounds/node %.2f\n",
                  16 * d[0] / n, 16 * d[1] / n, 16 * d[2] / n, 16 * d[3] / n, d[4] / n, d[5] / n);
@@ -1155,6 +1207,8 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
                  d[12] / n, d[15] / n, d[13] / n, d[16] / n, d[14] / n);
     std::fprintf(stderr, "%% event-profile degree (reader slices) of the variables marked through their record, per node: <=4: %.1f  5-6: %.1f  7-11: %.1f  more: %.1f\n",
                  d[17] / n, d[18] / n, d[19] / n, d[20] / n);
+    std::fprintf(stderr, "%% event-profile slices dropped as entailed when their turn came: %.2f per node\n", d[24] / n);
+    std::fprintf(stderr, "%% event-profile adjacency-record branch: %.0f cycles per node, lanes marking x %.1f, y or z %.1f\n", 16 * d[21] / n, d[22] / n, d[23] / n);
   }
 #endif
   for (size_t b = 0; b < B; ++b) {

@@ -443,14 +443,24 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* n
 #ifdef TB_TUNING
   if (census != nullptr) {  // knob 0x10000: runs with something to mark [12], lanes with something to mark [15], ... through the adjacency records [13] / lanes [16], ... with a tail [14]
     const unsigned long long m0 = __ballot((ex | ey | ez) != 0);
-    const unsigned long long m1 = __ballot((ex && (sc.w & 1)) || (ey && (sc.w & 2)) || (ez && (sc.w & 4)));
+    const unsigned long long m1 = __ballot((ex & ((sc.w & 1) | ((sc.w >> 15) & 2))) || (ey & (((sc.w >> 1) & 1) | ((sc.w >> 16) & 2))) || (ez & (((sc.w >> 2) & 1) | ((sc.w >> 17) & 2))));
     if ((threadIdx.x & 63) == 0) { census[12] += 1; census[15] += __builtin_popcountll(m0); if (m1) { census[13] += 1; census[16] += __builtin_popcountll(m1); } }
   }
 #endif
-  if (ex && !(sc.w & 1)) { did |= mark_packed(nxt, (unsigned)sc.x, sc.w >> 4, ex); ex = 0; }
-  if (ey && !(sc.w & 2)) { did |= mark_packed(nxt, (unsigned)sc.y, sc.w >> 8, ey); ey = 0; }
-  if (ez && !(sc.w & 4)) { did |= mark_packed(nxt, (unsigned)sc.z, sc.w >> 12, ez); ez = 0; }
+  // events whose interested readers all sit in the record's two slots are served from there; the others walk the variable's record
+  const int ovx = (sc.w & 1) | ((sc.w >> 15) & 2), ovy = ((sc.w >> 1) & 1) | ((sc.w >> 16) & 2), ovz = ((sc.w >> 2) & 1) | ((sc.w >> 17) & 2);
+  if (ex & ~ovx) did |= mark_packed(nxt, (unsigned)sc.x, sc.w >> 4, ex & ~ovx);
+  if (ey & ~ovy) did |= mark_packed(nxt, (unsigned)sc.y, sc.w >> 8, ey & ~ovy);
+  if (ez & ~ovz) did |= mark_packed(nxt, (unsigned)sc.z, sc.w >> 12, ez & ~ovz);
+  ex &= ovx; ey &= ovy; ez &= ovz;
   if (__any((ex | ey | ez) != 0)) {
+#ifdef TB_TUNING
+    const long long t_var = census != nullptr ? clock64() : 0;  // [21]: time in this branch; [22], [23]: lanes marking their x / their y or z through it
+    if (census != nullptr) {
+      const unsigned long long lx = __ballot(ex != 0), lyz = __ballot((ey | ez) != 0);
+      if ((threadIdx.x & 63) == 0) { census[22] += __builtin_popcountll(lx); census[23] += __builtin_popcountll(lyz); }
+    }
+#endif
     int dx = 0, dy = 0, dz = 0, ox = 0, oy = 0, oz = 0;
     const bool tx = mark_var(P, nxt, pr.y, s, ex, dx, ox, did);
     const bool ty = mark_var(P, nxt, pr.z, s, ey, dy, oy, did);
@@ -469,6 +479,9 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* n
     if (my) dt |= mark_tail(P, nxt, my, dy, oy, ey, s);
     if (mz) dt |= mark_tail(P, nxt, mz, dz, oz, ez, s);
     did |= dt;
+#ifdef TB_TUNING
+    if (census != nullptr) { const long long t_ = clock64(); if ((threadIdx.x & 63) == 0) census[21] += (int)((t_ - t_var) >> 4); }
+#endif
   }
   return __any(did);
 }
@@ -607,7 +620,8 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
         const int4 pr = props[s * 64 + lane];  // the arrays are padded to whole slices
 #endif
         if (ld(&sh.bot) | ld(&sh.abort)) break;  // the node failed in another wave
-        if (!(drop_entailed && es.unent[s] == 0)) {
+        if (drop_entailed && es.unent[s] == 0) TB_PROF_COUNT(24);  // tuning: slices dropped because they were entailed when they last ran
+        else {
           const bool act = s * 64 + lane < n;
           const RunEnv E{P, sh, nxt, es.unent, s};
           const unsigned key = (unsigned)__builtin_amdgcn_readfirstlane(pr.x) >> 16;  // wave-uniform: scalar dispatch
@@ -722,7 +736,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                   if (now.lb > now.ub) st(&sh.bot, 1);
                 }
                 run_writes += (unsigned)(set0 | set1) + (unsigned)cyl + (unsigned)cyu;
-                nar = (int)set1 | ((int)set0 << 1) | (cyl ? 4 : 0) | (cyu ? 8 : 0);  // b true / false, y.lb / y.ub
+                // (y is reported by the lane that wrote it, or by every lane of the group when y's readers are dealt out over their records)
+                const bool y_rep = writer || ((sc.w >> 20) & 1) != 0;
+                nar = (int)set1 | ((int)set0 << 1) | ((y_rep && lb != Y.lb) ? 4 : 0) | ((y_rep && ub != Y.ub) ? 8 : 0);  // b true / false, y.lb / y.ub
                 un_i = act && !(((t || set1) && hit) || ((f || set0) && outside));
               } else if (lane == 0) st(&sh.bot, 1);
               // When no truth variable occurs twice in the slice (word0 bit 11, pack_props) the joint fixpoint is reached and no
@@ -1393,7 +1409,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     bs.eps_solved = bs.eps_skipped = bs.store_writes = bs.stolen = 0;
     bs.wait_ticks = 0;
     bs.why = 0; bs.pad_why = 0;
-    for (int i = 0; i < 24; ++i) bs.dbg[i] = 0;
+    for (int i = 0; i < 32; ++i) bs.dbg[i] = 0;
     bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
     sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0;
     sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; sh.witness = -1;
