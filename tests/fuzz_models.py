@@ -80,3 +80,58 @@ def random_network(rng):
     return store, props
 
 
+
+
+def channelling_network(rng):
+    """Random network made of what the event kernel evaluates jointly: channelling propagators b = (y = k) of a few integer
+    variables y over runs of consecutive constants, runs with gaps, duplicated constants and truth variables shared between
+    two y, plus implications b1 <= b2 and sums over the Booleans (several readers per Boolean and per y, so that the
+    successor slots overflow for one bound event and not the other, and y's readers are dealt over its group's lanes).
+    More than 64 records per class, so that slices are class-pure and hold one to three groups."""
+    from turbo_amd.frontend import ITV_DTYPE, PROP_DTYPE
+    store = [(0, 0), (1, 1), (2, 2)]
+    const_of = {0: 0, 1: 1, 2: 2}
+
+    def const(k):
+        if k not in const_of:
+            const_of[k] = len(store)
+            store.append((k, k))
+        return const_of[k]
+    props = []
+    bools = []
+    n_y = int(rng.integers(4, 10))
+    for _ in range(n_y):
+        lo = int(rng.integers(-5, 6))
+        width = int(rng.integers(3, 70))
+        y = len(store)
+        store.append((lo, lo + width))
+        ks = list(range(lo - int(rng.integers(0, 3)), lo + width + 1 + int(rng.integers(0, 3))))
+        style = rng.random()
+        if style < 0.25:    # gaps
+            ks = [k for k in ks if rng.random() < 0.7]
+        elif style < 0.4:   # a duplicate
+            ks.insert(int(rng.integers(0, len(ks))), int(rng.choice(ks)))
+        for k in ks:
+            if bools and rng.random() < 0.05:
+                b = int(rng.choice(bools))  # a truth variable shared by two rules
+            else:
+                b = len(store)
+                store.append((0, 1))
+                bools.append(b)
+            props.append((6, b, y, const(k)))  # b = (y = k)
+        if rng.random() < 0.5:  # a second reader of y: b' = (y <= k)
+            b = len(store); store.append((0, 1)); bools.append(b)
+            props.append((7, b, y, const(int(rng.integers(lo, lo + width + 1)))))
+    for _ in range(int(rng.integers(20, 120))):  # implications
+        a, c = int(rng.choice(bools)), int(rng.choice(bools))
+        props.append((7, 1, a, c))
+    for _ in range(int(rng.integers(0, 12))):  # t = a + c chains
+        a, c = int(rng.choice(bools)), int(rng.choice(bools))
+        t = len(store); store.append((0, 2))
+        props.append((0, t, a, c))
+        if rng.random() < 0.5:
+            props.append((7, 1, t, 1))  # at most one of the two
+    order = rng.permutation(len(props))
+    st = np.array(store, dtype=ITV_DTYPE)
+    pr = np.array([props[i] for i in order], dtype=PROP_DTYPE)
+    return st, pr

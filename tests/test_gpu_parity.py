@@ -216,6 +216,43 @@ def test_random_networks_with_wide_and_infinite_domains(mode):
                 np.testing.assert_array_equal(got[i], exp, err_msg=f"seed {seed} store {i}")
 
 
+@pytest.mark.parametrize("mode", ["wac1", "event", "event_compact"])
+def test_channelling_networks_bit_exact(mode):
+    """Fuzz of the jointly evaluated channelling slices: consecutive constants (bit-scan walks), gaps and duplicates (stepping
+    walks), shared truth variables (confirmation pass), several groups per slice, readers dealt over a group's lanes, successor
+    slots covering one bound event only.  Root and random nodes of 60 networks against the oracle, bit for bit."""
+    from fuzz_models import channelling_network
+    cfg = {"wac1": dict(fixpoint=1), "event": dict(fixpoint=2), "event_compact": dict(fixpoint=2, debug=COMPACT)}[mode]
+    for seed in range(60):
+        rng = np.random.default_rng(1000 + seed)
+        store, props = channelling_network(rng)
+        root, failed, _, _, _ = pyoracle.propagate(store, props)
+        stores = [store]
+        for _ in range(7):
+            s = (store if failed or rng.random() < 0.3 else root).copy()
+            for v in rng.choice(np.arange(3, s.shape[0]), size=min(int(rng.integers(1, 6)), s.shape[0] - 3), replace=False):
+                lo, hi = int(s["lb"][v]), int(s["ub"][v])
+                if lo >= hi:
+                    continue
+                m = int(rng.integers(lo, hi + 1))
+                r = rng.random()
+                if r < 0.4:
+                    s["ub"][v] = m
+                elif r < 0.8:
+                    s["lb"][v] = m
+                else:
+                    s["lb"][v] = s["ub"][v] = m
+            stores.append(s)
+        stores = np.stack(stores)
+        got, gfailed, ent, _, _, _ = capi.propagate(props, stores, capi.make_config(timeout_ms=20000, **cfg))
+        for i in range(stores.shape[0]):
+            exp, efailed, eent, _, _ = pyoracle.propagate(stores[i], props)
+            assert bool(gfailed[i]) == efailed, (seed, i)
+            if not efailed:
+                assert bool(ent[i]) == eent, (seed, i)
+                np.testing.assert_array_equal(got[i], exp, err_msg=f"seed {seed} store {i}")
+
+
 def test_unsat_and_errors():
     tcn = frontend.Model.from_string("var 1..3: x; var 1..3: y; constraint int_lt(x,y); constraint int_lt(y,x); solve satisfy;").tcn()
     has, _, st = capi.solve(tcn, capi.make_config(timeout_ms=20000))
