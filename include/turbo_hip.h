@@ -193,6 +193,8 @@ int tb_session_start(tb_session* s);
 typedef struct {
   int32_t num_blocks, threads_per_block, mem_kind, shared_bytes, subproblems_power, eps_chunk_log2, snapshot_levels, decision_stack_depth;
   uint64_t eps_local_subproblems;
+  int32_t kernel_event, kernel_opt; /* which kernel start() launches: event-driven fixpoint or sweeps; its option flag (COMPACT store
+                                     * layout for the event kernels, entailed-slice removal for the sweeps) */
 } tb_plan;
 int tb_session_plan(tb_session* s, tb_plan* plan_out);
 /*

@@ -253,6 +253,29 @@ def test_channelling_networks_bit_exact(mode):
                 np.testing.assert_array_equal(got[i], exp, err_msg=f"seed {seed} store {i}")
 
 
+@pytest.mark.parametrize("cfg,event,opt", [(dict(fixpoint=1), 0, 0), (dict(fixpoint=0), 0, 0), (dict(fixpoint=1, entailed_prop_removal=1), 0, 1),
+                                           (dict(fixpoint=0, entailed_prop_removal=1), 0, 1), (dict(fixpoint=2), 1, 0), (dict(fixpoint=2, debug=COMPACT), 1, 1)],
+                         ids=["wac1", "ac1", "wac1_rm", "ac1_rm", "event", "event_compact"])
+def test_the_kernel_that_runs_is_the_one_the_configuration_names(cfg, event, opt):
+    """r02 found `sweeps + entailed-slice removal` searches launched on the event kernel (an unparenthesised macro argument in
+    the dispatch): same tree, so every parity test passed.  The plan now names the kernel flags the launch uses, and the sweeps
+    with removal must show what only they do: the same tree with fewer propagator evaluations than plain sweeps."""
+    tcn = load("test_data/pat7.fzn")
+    s = capi.Session(tcn, capi.make_config(or_nodes=1, subproblems_power=0, stop_after_n_nodes=300, timeout_ms=60000, **cfg))
+    plan = s.plan()
+    s.start()
+    while not s.poll()[1]:
+        pass
+    _, _, st = s.finish()
+    s.close()
+    assert (plan["kernel_event"], plan["kernel_opt"]) == (event, opt)
+    if not event:
+        ref = capi.solve(tcn, capi.make_config(or_nodes=1, subproblems_power=0, stop_after_n_nodes=300, timeout_ms=60000, fixpoint=cfg["fixpoint"]))[2]
+        assert st["nodes"] == ref["nodes"] and st["fails"] == ref["fails"]
+        if opt:
+            assert st["num_deductions"] < ref["num_deductions"]
+
+
 def test_unsat_and_errors():
     tcn = frontend.Model.from_string("var 1..3: x; var 1..3: y; constraint int_lt(x,y); constraint int_lt(y,x); solve satisfy;").tcn()
     has, _, st = capi.solve(tcn, capi.make_config(timeout_ms=20000))

@@ -72,7 +72,8 @@ class TbStats(C.Structure):
 class TbPlan(C.Structure):
     _fields_ = [("num_blocks", C.c_int32), ("threads_per_block", C.c_int32), ("mem_kind", C.c_int32), ("shared_bytes", C.c_int32),
                 ("subproblems_power", C.c_int32), ("eps_chunk_log2", C.c_int32), ("snapshot_levels", C.c_int32),
-                ("decision_stack_depth", C.c_int32), ("eps_local_subproblems", C.c_uint64)]
+                ("decision_stack_depth", C.c_int32), ("eps_local_subproblems", C.c_uint64),
+                ("kernel_event", C.c_int32), ("kernel_opt", C.c_int32)]
 
 
 class TbDeviceInfo(C.Structure):

@@ -77,6 +77,7 @@ struct LaunchPlan {
   int snapshot_levels = 1;
   int max_depth = 16384;
   int n_slices = 0, dirty_words = 0, vext = 0, chg_cap = 64;
+  int kernel_event = 0, kernel_opt = 0;  // template flags of the kernels this plan launches (solve and root propagation alike)
   int compact = 0, n_int = 0, unent_off = 0;  // store layout (Layout below)
 };
 
@@ -221,6 +222,8 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     L = (int)std::min<size_t>(256, std::max<size_t>(1, budget / std::max<size_t>(1, per_level)));
   }
   p.snapshot_levels = std::max(1, std::min(L, p.max_depth));
+  p.kernel_event = event ? 1 : 0;
+  p.kernel_opt = (event ? p.compact != 0 : cfg.entailed_prop_removal != 0) ? 1 : 0;
   *plan = p;
   return TB_OK;
 }
@@ -463,24 +466,29 @@ int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
 
 #define DISPATCH_MEM(FN, TM, EV, CP, mem, ...)                                          \
   do {                                                                                  \
-    if (mem == TB_MEM_GLOBAL) FN<TB_MEM_GLOBAL, TM, EV, CP> __VA_ARGS__;                \
-    else if (mem == TB_MEM_STORE_SHARED) FN<TB_MEM_STORE_SHARED, TM, EV, CP> __VA_ARGS__; \
+    if ((mem) == TB_MEM_GLOBAL) FN<TB_MEM_GLOBAL, TM, EV, CP> __VA_ARGS__;              \
+    else if ((mem) == TB_MEM_STORE_SHARED) FN<TB_MEM_STORE_SHARED, TM, EV, CP> __VA_ARGS__; \
     else FN<TB_MEM_TCN_SHARED, TM, EV, CP> __VA_ARGS__;                                 \
   } while (0)
 // Fourth template flag (`opt`): the COMPACT store layout for the event-driven kernels (the sweeps are VALU bound:
 // decoding 2-bit Booleans would cost them more than the LDS it frees), entailed-slice removal for the sweeps.
+// (The run-time selectors are evaluated ONCE into locals: callers pass expressions, and `a == 2 && a == 2 ? x : y` is not
+//  what an unparenthesised `event && opt` was meant to be -- r02 found the solve launch of "sweeps + entailed removal" going
+//  to the event kernel that way.)
 #define DISPATCH_KERNEL(FN, mem, tmax, event, opt, ...)                                 \
   do {                                                                                  \
-    if (tmax == 256) {                                                                  \
-      if (event && opt) DISPATCH_MEM(FN, 256, true, true, mem, __VA_ARGS__);            \
-      else if (event) DISPATCH_MEM(FN, 256, true, false, mem, __VA_ARGS__);             \
-      else if (opt) DISPATCH_MEM(FN, 256, false, true, mem, __VA_ARGS__);               \
-      else DISPATCH_MEM(FN, 256, false, false, mem, __VA_ARGS__);                       \
+    const int dk_mem = (mem), dk_tmax = (tmax);                                         \
+    const bool dk_event = (event), dk_opt = (opt);                                      \
+    if (dk_tmax == 256) {                                                               \
+      if (dk_event && dk_opt) DISPATCH_MEM(FN, 256, true, true, dk_mem, __VA_ARGS__);   \
+      else if (dk_event) DISPATCH_MEM(FN, 256, true, false, dk_mem, __VA_ARGS__);       \
+      else if (dk_opt) DISPATCH_MEM(FN, 256, false, true, dk_mem, __VA_ARGS__);         \
+      else DISPATCH_MEM(FN, 256, false, false, dk_mem, __VA_ARGS__);                    \
     } else {                                                                            \
-      if (event && opt) DISPATCH_MEM(FN, 1024, true, true, mem, __VA_ARGS__);           \
-      else if (event) DISPATCH_MEM(FN, 1024, true, false, mem, __VA_ARGS__);            \
-      else if (opt) DISPATCH_MEM(FN, 1024, false, true, mem, __VA_ARGS__);              \
-      else DISPATCH_MEM(FN, 1024, false, false, mem, __VA_ARGS__);                      \
+      if (dk_event && dk_opt) DISPATCH_MEM(FN, 1024, true, true, dk_mem, __VA_ARGS__);  \
+      else if (dk_event) DISPATCH_MEM(FN, 1024, true, false, dk_mem, __VA_ARGS__);      \
+      else if (dk_opt) DISPATCH_MEM(FN, 1024, false, true, dk_mem, __VA_ARGS__);        \
+      else DISPATCH_MEM(FN, 1024, false, false, dk_mem, __VA_ARGS__);                   \
     }                                                                                   \
   } while (0)
 
@@ -804,12 +812,12 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     // cap the grid by what is actually resident (registers, LDS): queued workgroups of a persistent kernel only
     // add tail latency; re-plan so that the subproblem count follows the real workgroup count
     int occ = 0;
-    if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->cfg.fixpoint == 2, s->cfg.fixpoint == 2 ? s->plan.compact != 0 : s->cfg.entailed_prop_removal != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
+    if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->plan.kernel_event != 0, s->plan.kernel_opt != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     if (occ > 0 && (long long)occ * s->caps.cus < (long long)s->plan.num_blocks) {
       tb_config capped = s->cfg;
       capped.or_nodes = (uint64_t)occ * (uint64_t)s->caps.cus;
       if ((rc = choose_layout(capped, s->caps, n_vars, 1, root_store, n_props, &s->lay, &s->plan)) != TB_OK) return rc;
-      if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->cfg.fixpoint == 2, s->cfg.fixpoint == 2 ? s->plan.compact != 0 : s->cfg.entailed_prop_removal != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
+      if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->plan.kernel_event != 0, s->plan.kernel_opt != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     }
   }
   const LaunchPlan& plan = s->plan;
@@ -944,7 +952,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   // The node is still visited and counted; it just finds nothing left to do.  (tb_config.reserved[0] & 0x2000000 keeps the
   // caller's store, for A/B runs.)  An inconsistent root is left as it is: every subproblem then fails on its first node.
   if (n_props > 0 && !(s->cfg.reserved[0] & 0x2000000)) {
-    const bool event = s->cfg.fixpoint == 2, opt = event ? plan.compact != 0 : s->cfg.entailed_prop_removal != 0;
+    const bool event = s->plan.kernel_event != 0, opt = s->plan.kernel_opt != 0;
     int occ = 0;
     if ((rc = prepare_kernel(false, plan.mem_kind, plan.tmax, event, opt, plan.shared_bytes, plan.threads, &occ)) != TB_OK) return rc;
     PropagateOut* d_out = nullptr;
@@ -977,6 +985,7 @@ int tb_session_plan(tb_session* s, tb_plan* plan_out) {
   plan_out->subproblems_power = s->plan.subproblems_power; plan_out->eps_chunk_log2 = s->P.chunk_log2;
   plan_out->snapshot_levels = s->plan.snapshot_levels; plan_out->decision_stack_depth = s->plan.max_depth;
   plan_out->eps_local_subproblems = s->local_count;
+  plan_out->kernel_event = s->plan.kernel_event; plan_out->kernel_opt = s->plan.kernel_opt;
   return TB_OK;
 }
 
@@ -1079,7 +1088,7 @@ int tb_session_start(tb_session* s) {
   s->t_start = std::chrono::steady_clock::now();
   HIP_TRY(hipEventRecord(s->ev_start, s->stream));
   const LaunchPlan& plan = s->plan;
-  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, s->cfg.fixpoint == 2, s->cfg.fixpoint == 2 ? plan.compact != 0 : s->cfg.entailed_prop_removal != 0, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->mbox_dev));
+  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, plan.kernel_event != 0, plan.kernel_opt != 0, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->mbox_dev));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev_stop, s->stream));
   s->started = true;
