@@ -91,7 +91,7 @@ struct Layout {
   std::vector<int> perm, inv;  // perm[caller's id] = internal id, inv = its inverse
   int bool_words() const { return (n_bool + 15) / 16; }
   int unent_off() const { return n_int * 8 + bool_words() * 4; }
-  int vext(int n_slices) const { return (int)((((size_t)unent_off() + (size_t)n_slices + 15) / 16) * 2); }
+  int vext(int n_slices) const { return (int)((((size_t)unent_off() + (size_t)std::max(n_slices, 4) + 15) / 16) * 2); }  // (>= one 32-bit word of entailment bits)
 };
 
 Layout make_layout(int32_t n_vars, int32_t n_stores, const tb_itv* stores, bool compact) {
@@ -1216,7 +1216,6 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
                  d[12] / n, d[15] / n, d[13] / n, d[16] / n, d[14] / n);
     std::fprintf(stderr, "%% event-profile degree (reader slices) of the variables marked through their record, per node: <=4: %.1f  5-6: %.1f  7-11: %.1f  more: %.1f\n",
                  d[17] / n, d[18] / n, d[19] / n, d[20] / n);
-    std::fprintf(stderr, "%% event-profile slices dropped as entailed when their turn came: %.2f per node\n", d[24] / n);
     std::fprintf(stderr, "%% event-profile adjacency-record branch: %.0f cycles per node, lanes marking x %.1f, y or z %.1f\n", 16 * d[21] / n, d[22] / n, d[23] / n);
   }
 #endif

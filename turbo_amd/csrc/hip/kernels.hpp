@@ -325,7 +325,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
 struct EventState {
   unsigned* dirty;        // LDS: bitmap of the slices that must (re)run
   int* list;              // LDS: variables changed outside the fixpoint (decision, bound, replay)
-  unsigned char* unent;   // one byte per slice, behind the store (LDS or HBM slab)
+  unsigned char* unent;   // behind the store (LDS or HBM slab): one byte per slice for the sweeps (entailed-slice removal), one BIT per slice (32-bit words) for the event fixpoint
   int words, cap;
 };
 
@@ -398,7 +398,7 @@ struct RunEnv {
   const DevProblem& P;
   BlockShared& sh;
   unsigned* nxt;            // dirty bitmap of the next round
-  unsigned char* unent;     // per-slice "some propagator is not entailed" bytes
+  unsigned* unent;          // per-slice "some propagator is not entailed" bits
   int s;                    // the slice
 };
 
@@ -415,7 +415,7 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
     nar_all |= nar;  // (a cooperative body reaches the slice's fixpoint in one pass: it narrows, reports nar and no change)
     if (!__any(ch)) {
       // The byte only ever goes 1 -> 0 below a node (entailment is monotone).
-      if (!__any(un_i) && lane == 0) E.unent[s] = 0;
+      if (!__any(un_i) && lane == 0) (void)__hip_atomic_fetch_and(&E.unent[s >> 5], ~(1u << (s & 31)), TB_RLX, TB_WG);
       break;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -546,12 +546,13 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   const bool root_pass = ld(&sh.ev_all) != 0;
   const bool drop_entailed = !root_pass && !(knobs(P) & 0x20000);
   unsigned* bm0 = es.dirty;
+  unsigned* ubits = reinterpret_cast<unsigned*>(es.unent);  // bit s: some propagator of slice s was not entailed when it last ran
   if (all) {
     for (int i = tid; i < W; i += T) {
       const int left = S - i * 32;
       bm0[i] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
     }
-    if (root_pass) for (int s = tid; s < S; s += T) es.unent[s] = 1;  // nothing is known to be entailed yet
+    if (root_pass) for (int i = tid; i < W; i += T) ubits[i] = bm0[i];  // nothing is known to be entailed yet (every valid bit set)
   } else {
     for (int e0 = wave * 64; e0 < cnt; e0 += T) {  // one lane per entry; long lists are finished cooperatively
       const int e = e0 + lane;
@@ -584,8 +585,10 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     bool marked = false;  // wave-uniform: this wave marked something for the next round
     for (int base = 0; base < W; base += 64) {
       const int wi = base + lane;
-      const unsigned w = wi < W ? (__hip_atomic_load(&cur[wi], TB_RLX, TB_WG) & own) : 0u;
+      unsigned w = wi < W ? (__hip_atomic_load(&cur[wi], TB_RLX, TB_WG) & own) : 0u;
       if (w != 0) (void)__hip_atomic_fetch_and(&cur[wi], ~w, TB_RLX, TB_WG);  // mine, cleared before any domain is loaded
+      // entailed-slice removal: a slice whose 64 propagators were all entailed when it last ran is not even looked at
+      if (drop_entailed && w != 0) w &= __hip_atomic_load(&ubits[wi], TB_RLX, TB_WG);
       // my slices of this round, one after the other
       unsigned long long nz = __ballot(w != 0);
       unsigned word = 0;
@@ -620,10 +623,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
         const int4 pr = props[s * 64 + lane];  // the arrays are padded to whole slices
 #endif
         if (ld(&sh.bot) | ld(&sh.abort)) break;  // the node failed in another wave
-        if (drop_entailed && es.unent[s] == 0) TB_PROF_COUNT(24);  // tuning: slices dropped because they were entailed when they last ran
-        else {
+        {
           const bool act = s * 64 + lane < n;
-          const RunEnv E{P, sh, nxt, es.unent, s};
+          const RunEnv E{P, sh, nxt, ubits, s};
           const unsigned key = (unsigned)__builtin_amdgcn_readfirstlane(pr.x) >> 16;  // wave-uniform: scalar dispatch
           unsigned wave_iters;
           unsigned run_writes = 0;  // per lane, folded into the 64-bit counter once per run
@@ -856,15 +858,17 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     };
     int wit = __builtin_amdgcn_readfirstlane(ld(&sh.witness));
     bool confirmed = wit >= 0 && unentailed_lanes(wit, false) != 0;
-    for (int base = 0; !confirmed && base < S; base += 64) {
-      const int s = base + lane;
-      unsigned long long m = __ballot(s < S && es.unent[s] != 0);
-      while (m && !confirmed) {
-        const int sl = base + __builtin_ctzll(m);
-        m &= m - 1;
-        const unsigned long long un = unentailed_lanes(sl * 64, true);
-        if (un) { wit = sl * 64 + __builtin_ctzll(un); confirmed = true; }
-        else if (lane == 0) es.unent[sl] = 0;  // every propagator of the slice is entailed now
+    for (int base = 0; !confirmed && base < W; base += 64) {
+      const int wi = base + lane;
+      const unsigned word = wi < W ? __hip_atomic_load(&ubits[wi], TB_RLX, TB_WG) : 0u;
+      for (unsigned long long m = __ballot(word != 0); m && !confirmed; m &= m - 1) {
+        const int wl = __builtin_ctzll(m);
+        for (unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)word, wl); bits && !confirmed; bits &= bits - 1) {
+          const int sl = (base + wl) * 32 + __builtin_ctz(bits);
+          const unsigned long long un = unentailed_lanes(sl * 64, true);
+          if (un) { wit = sl * 64 + __builtin_ctzll(un); confirmed = true; }
+          else if (lane == 0) (void)__hip_atomic_fetch_and(&ubits[sl >> 5], ~(1u << (sl & 31)), TB_RLX, TB_WG);  // every propagator of the slice is entailed now
+        }
       }
     }
     if (lane == 0) { st(&sh.witness, confirmed ? wit : -1); st(&sh.unent[0], confirmed ? 1 : 0); }
@@ -1274,7 +1278,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
       const bool un = act && !c.ent;
       int bad = 0;
       if (__any(narrows)) bad |= 1 << 8;
-      if (__any(un) && es.unent[s] == 0) bad |= 1 << 9;
+      if (__any(un) && !((reinterpret_cast<const unsigned*>(es.unent)[s >> 5] >> (s & 31)) & 1u)) bad |= 1 << 9;
       if (bad) {
         int zero = 0;
         bool first = false;
