@@ -322,7 +322,21 @@ std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::v
       std::sort(xs.begin(), xs.end());
       if (std::adjacent_find(xs.begin(), xs.end()) != xs.end()) distinct_x = 0;
     }
-    for (int32_t i = base; i < end; ++i) out[(size_t)i].x |= (present << 16) | (int)(kinds << 26) | (distinct_x << 11);  // same in the 64 records of a slice
+    // bit 15 (channelling slices `b = (y = k)` only): inside every group of records sharing y the constants are consecutive
+    // integers in lane order -- the bounds of y then move over excluded values with a bit scan (kernels.hpp: KEY_EQR_BIC)
+    int dense = 0;
+    if (((unsigned)present | (kinds << 10)) == KEY_EQR_BIC) {
+      dense = 1;
+      for (int32_t a = base; a < end && dense;) {
+        const long long k0 = value[(size_t)props[a].z];
+        if (k0 > 0x7fffff00ll) dense = 0;
+        int32_t b = a + 1;
+        for (; b < end && props[b].y == props[a].y; ++b)
+          if ((long long)value[(size_t)props[b].z] != k0 + (b - a)) dense = 0;
+        a = b;
+      }
+    }
+    for (int32_t i = base; i < end; ++i) out[(size_t)i].x |= (present << 16) | (int)(kinds << 26) | (distinct_x << 11) | (dense << 15);  // same in the 64 records of a slice
   }
   return out;
 }
@@ -360,7 +374,7 @@ void pack_var_adj(const Adjacency& adj, std::vector<int4>* heads, std::vector<in
 // Channelling slices (KEY_EQR_BIC, evaluated jointly by the lanes that share y): every lane of a group knows what happened to y,
 // so y's readers are dealt out over the group's lanes, two each (bit 20 of w: "y is reported by every lane of its group"), when
 // they all fit; a y with ten readers then needs no walk either.
-std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacency& adj, const std::vector<int4>& records, bool deal_groups) {
+std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacency& adj, const std::vector<int4>& records, const std::vector<int>& value, bool deal_groups) {
   std::vector<int4> out(((size_t)n_props + 63) / 64 * 64, make_int4(-1, -1, -1, 0));
   std::vector<int> dealt((size_t)n_props, -1);  // index inside its group of a lane whose y slots are dealt
   if (deal_groups)
@@ -426,6 +440,25 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
       flags |= (in[0] << (4 + 2 * (2 * k))) | (in[1] << (4 + 2 * (2 * k + 1)));
     }
     out[(size_t)i] = make_int4((int)packed[0], (int)packed[1], (int)packed[2], flags);
+  }
+  // Reified comparisons against a constant with a Boolean truth variable (KEY_EQR_BIC, KEY_LEQR_BIC: dedicated runs that never
+  // report anything about z): the z slots, useless for a constant, carry its VALUE, and in the channelling slices bits 21-26 /
+  // 27-31 + 19 of w carry the first / last lane of the record's group -- nothing left to gather or to shuffle at run time.
+  for (int32_t base = 0; base < n_props; base += 64) {
+    const unsigned key = (unsigned)records[(size_t)base].x >> 16;
+    if (key != KEY_EQR_BIC && key != KEY_LEQR_BIC) continue;
+    const int32_t end = std::min(n_props, base + 64);
+    for (int32_t a = base; a < end;) {
+      int32_t b = a + 1;
+      while (b < end && key == KEY_EQR_BIC && props[b].y == props[a].y) ++b;
+      for (int32_t i = a; i < b; ++i) {
+        int4& r = out[(size_t)i];
+        r.z = value[(size_t)props[i].z];
+        const unsigned g0 = (unsigned)(a - base), g1 = (unsigned)(b - 1 - base);
+        r.w = (int)(((unsigned)r.w & 0x0017ffffu) | (g0 << 21) | ((g1 & 31u) << 27) | ((g1 >> 5) << 19));
+      }
+      a = b;
+    }
   }
   return out;
 }
@@ -715,7 +748,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj, lay.n_int);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
     {
-      const std::vector<int4> succ = pack_succ(n_props, net.props.data(), adj, packed, !(cfg.reserved[0] & 0x4000000));
+      const std::vector<int4> succ = pack_succ(n_props, net.props.data(), adj, packed, value, !(cfg.reserved[0] & 0x4000000));
       int4* d_succ = nullptr;
       if ((rc = bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
       if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -854,7 +887,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj, lay.n_int);
     if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
     {
-      const std::vector<int4> succ = pack_succ(n_props, net.props.data(), adj, packed, !(s->cfg.reserved[0] & 0x4000000));
+      const std::vector<int4> succ = pack_succ(n_props, net.props.data(), adj, packed, value, !(s->cfg.reserved[0] & 0x4000000));
       int4* d_succ = nullptr;
       if ((rc = s->bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
       if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));

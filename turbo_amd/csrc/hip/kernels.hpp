@@ -667,26 +667,19 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             // false b_i sits on a bound, and the bounds step over the excluded values in registers -- no memory traffic; then
             // every b_i outside the new bounds becomes false and, if y is assigned, its b_i true.  Same fixpoint, one pass.
             const BoolRef rx = bool_ref(store, P.n_int, pr.y, act);
-            const int kc = load_dom<C>(store, P.n_int, act ? pr.w : 0).lb;
             const int yv = act ? pr.z : 0;
-            const bool single_pass = ((__builtin_amdgcn_readfirstlane(pr.x) >> 11) & 1) != 0;
-            // my group: the lanes between two changes of y (wave-uniform masks, per-lane selection)
-            const int y_prev = __shfl_up(yv, 1, 64);
-            const unsigned long long actm = __ballot(act);
-            const unsigned long long starts = __ballot(act && (lane == 0 || yv != y_prev));
-            const unsigned long long upto = (2ull << lane) - 1ull;                  // lanes 0..lane
-            const int g_start = 63 - __builtin_clzll((starts & upto) | 1ull);
-            const unsigned long long above = starts & ~upto;
-            const unsigned long long below_end = above ? ((above & (0ull - above)) - 1ull) : ~0ull;  // lanes before the next group's first
-            const unsigned long long gmask = act ? (below_end & ~((1ull << g_start) - 1ull) & actm) : 0ull;
+            const int w0u = __builtin_amdgcn_readfirstlane(pr.x);
+            const bool single_pass = ((w0u >> 11) & 1) != 0;
+            // Prepared by the host with the record (pack_succ): the constant's value in the z slots, the first and last lane of
+            // my group (the lanes between two changes of y), and for the slice whether every group's constants are consecutive
+            // integers in lane order -- lane g_start + (v - k0) then holds value v, and "how far do the excluded values reach from
+            // this bound" is a bit scan over the ballot of the false b_i instead of a walk.
+            const int kc = sc.z;
+            const int g_start = (sc.w >> 21) & 63, g_last = ((sc.w >> 27) & 31) | (((sc.w >> 19) & 1) << 5);
+            const unsigned long long gmask = act ? (((2ull << g_last) - 1ull) & ~((1ull << g_start) - 1ull)) : 0ull;
             const bool writer = act && lane == g_start;
-            // The records of one y are sorted by k: when the k of a group are consecutive integers (the usual channelling of a
-            // whole domain) lane g_start + (v - k0) holds value v, and "how far do the excluded values reach from this bound" is a
-            // bit scan over the ballot of the false b_i instead of a walk.
-            const int k0 = __shfl(kc, g_start, 64);
-            const int g_last = g_start + __builtin_popcountll(gmask) - 1;
-            const int k_last = k0 + (g_last - g_start);
-            const bool dense = !__any(act && (k0 > 0x7fffff00 || kc != k0 + (lane - g_start)));
+            const bool dense = ((w0u >> 15) & 1) != 0;
+            const int k0 = kc - (lane - g_start), k_last = k0 + (g_last - g_start);  // (meaningful when dense)
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               const unsigned xb = bool_bits(rx);
               const Itv Y = load_dom<false>(store, P.n_int, yv);
@@ -752,7 +745,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             const bool is_eq = key == KEY_EQR_BIC;
             const BoolRef rx = bool_ref(store, P.n_int, pr.y, act);
             const int yv = act ? pr.z : 0;
-            const int kc = load_dom<C>(store, P.n_int, act ? pr.w : 0).lb;
+            const int kc = sc.z;  // the constant's value travels in the z slots of the successor record (pack_succ)
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               const unsigned xb = bool_bits(rx);
               const Itv Y = load_dom<false>(store, P.n_int, yv);

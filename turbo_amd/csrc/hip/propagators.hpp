@@ -291,7 +291,7 @@ __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y
   }
   if (present & (1 << K_HEAVY)) {
     if (cls == K_HEAVY) {
-      c = evaluate_heavy((w0 >> 12) & 0xf, X, Y, Z);
+      c = evaluate_heavy((w0 >> 12) & 0x7, X, Y, Z);
       ent = c.ent;
     }
   }
