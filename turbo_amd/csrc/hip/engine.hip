@@ -314,6 +314,19 @@ std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::v
       const unsigned code = seen == 1 ? 1u : (seen == 2 ? 2u : (seen == 4 ? 3u : 0u));
       kinds |= code << (2 * k);
     }
+    // The joint evaluation of a channelling slice takes the lanes between two changes of y for a group (pack_succ hands every
+    // lane its group's first and last lane): records sorted by y guarantee it; a slice where some y comes back after another one
+    // (record sort disabled by a test knob) is left to the generic run.
+    if (((unsigned)present | (kinds << 10)) == KEY_EQR_BIC) {
+      std::vector<int> seen_y;
+      bool contiguous = true;
+      for (int32_t i = base; i < end && contiguous; ++i) {
+        if (i > base && props[i].y == props[i - 1].y) continue;
+        if (std::find(seen_y.begin(), seen_y.end(), props[i].y) != seen_y.end()) contiguous = false;
+        seen_y.push_back(props[i].y);
+      }
+      if (!contiguous) kinds = 0;
+    }
     // bit 11: no truth variable x occurs twice in the slice (the joint evaluation of `b_i = (y = k_i)` slices is then complete in one pass)
     int distinct_x = 1;
     {
