@@ -264,6 +264,7 @@ Adjacency build_adjacency(int32_t n_vars, int32_t n_props, const tb_prop* props,
   Adjacency a;
   a.lists.resize((size_t)n_vars);
   for (int32_t i = 0; i < n_props; ++i) {
+    if (props[i].op < 0) continue;  // idle padding (to_internal)
     const int s = i / 64;
     const bool xc = is_const[(size_t)props[i].x] != 0;
     const int cls = class_of(props[i].op, xc, xc ? value[(size_t)props[i].x] : 0);
@@ -286,7 +287,8 @@ std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::v
   // padded to whole slices with idle records (never narrow, always entailed): the kernels may load any lane of a slice
   std::vector<int4> out(((size_t)n_props + 63) / 64 * 64, make_int4(K_LEQ_T, 0, 0, 0));
   for (int32_t base = 0; base < n_props; base += 64) {
-    const int32_t end = std::min(n_props, base + 64);
+    int32_t end = std::min(n_props, base + 64);
+    for (int32_t i = base; i < end; ++i) if (props[i].op < 0) { end = i; break; }  // idle padding fills the rest of the slice
     const int s = base / 64;
     int present = 0;
     for (int32_t i = base; i < end; ++i) {
@@ -393,7 +395,8 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
   if (deal_groups)
     for (int32_t base = 0; base < n_props; base += 64) {
       if (((unsigned)records[(size_t)base].x >> 16) != KEY_EQR_BIC) continue;
-      const int32_t end = std::min(n_props, base + 64);
+      int32_t end = std::min(n_props, base + 64);
+      for (int32_t i = base; i < end; ++i) if (props[i].op < 0) { end = i; break; }
       for (int32_t a = base; a < end;) {
         int32_t b = a + 1;
         while (b < end && props[b].y == props[a].y) ++b;
@@ -405,6 +408,7 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
       }
     }
   for (int32_t i = 0; i < n_props; ++i) {
+    if (props[i].op < 0) continue;  // idle padding: nothing to wake
     const int s = i / 64;
     const int vs[3] = {props[i].x, props[i].y, props[i].z};
     unsigned packed[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
@@ -460,7 +464,8 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
   for (int32_t base = 0; base < n_props; base += 64) {
     const unsigned key = (unsigned)records[(size_t)base].x >> 16;
     if (key != KEY_EQR_BIC && key != KEY_LEQR_BIC) continue;
-    const int32_t end = std::min(n_props, base + 64);
+    int32_t end = std::min(n_props, base + 64);
+    for (int32_t i = base; i < end; ++i) if (props[i].op < 0) { end = i; break; }
     for (int32_t a = base; a < end;) {
       int32_t b = a + 1;
       while (b < end && key == KEY_EQR_BIC && props[b].y == props[a].y) ++b;
@@ -568,7 +573,23 @@ struct InternalNet {
   std::vector<tb_itv> store;  // first store of the batch, internal order
   std::vector<tb_prop> props;
 };
-InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, const tb_prop* props, bool keep_order, bool event = false) {
+// Class of a record as the record sort sees it (constants = singletons of the first store).
+inline int sort_class(const tb_prop& q, const tb_itv* store) {
+  const tb_itv d = store[q.x];
+  const bool xc = d.lb == d.ub && d.lb != TB_NINF && d.lb != TB_PINF;
+  return class_of(q.op, xc, xc ? d.lb : 0);
+}
+// Records of the class-sorted array when every class but the last is padded to whole slices (to_internal with `pad`).
+int32_t padded_count(int32_t n_props, const tb_prop* props, const tb_itv* store) {
+  long long cnt[16] = {0};
+  for (int32_t i = 0; i < n_props; ++i) cnt[sort_class(props[i], store) & 15]++;
+  int last = -1;
+  for (int c = 0; c < 16; ++c) if (cnt[c]) last = c;
+  long long total = 0;
+  for (int c = 0; c < 16; ++c) total += c == last ? cnt[c] : (cnt[c] + 63) / 64 * 64;
+  return (int32_t)std::min<long long>(total, 0x7fffffff);
+}
+InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, const tb_prop* props, bool keep_order, bool event = false, bool pad = false) {
   InternalNet n;
   n.store.resize((size_t)L.n_vars);
   for (int v = 0; v < L.n_vars; ++v) n.store[(size_t)L.perm[(size_t)v]] = store[v];
@@ -611,6 +632,20 @@ InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, c
     const long long ka = key2(a), kc = key2(c);
     return ka != kc ? ka < kc : key3(a) < key3(c);
   });
+  // Event-driven fixpoint: every class starts on a slice boundary (idle records, op < 0, fill the slice the previous class
+  // ends in), so that no slice mixes two classes: a mixed slice takes the generic run with every class body it holds --
+  // a third of trains15's runs were on its nine class-straddling slices.
+  if (pad && !n.props.empty()) {
+    std::vector<tb_prop> padded;
+    padded.reserve(n.props.size() + 64 * 12);
+    int cur = key(n.props[0]) / 16;
+    for (const tb_prop& q : n.props) {
+      const int c = key(q) / 16;
+      if (c != cur) { while (padded.size() % 64 != 0) padded.push_back(tb_prop{-1, 0, 0, 0}); cur = c; }
+      padded.push_back(q);
+    }
+    n.props.swap(padded);
+  }
   return n;
 }
 
@@ -682,6 +717,30 @@ struct tb_session {
   unsigned char* ring_data() const { return ring_host + 64 + align16((size_t)ring_slots * 8); }  // [slots] slabs of plan.vext intervals
 };
 
+// Event-driven fixpoint with sorted records: plan for the class-padded record array (to_internal) when the store stays out of
+// global memory with it.  Returns the number of records the kernels will see.
+int32_t plan_records(const tb_config& cfg, const DeviceCaps& caps, int32_t n_vars, int32_t n_stores, const tb_itv* stores, int32_t n_props,
+                     const tb_prop* props, Layout* lay, LaunchPlan* plan) {
+  if (cfg.fixpoint != 2 || n_props == 0 || plan->mem_kind == TB_MEM_GLOBAL || (cfg.reserved[0] & (0x200000 | 0x20))) return n_props;
+  const int32_t n_pad = padded_count(n_props, props, stores);
+  // Worth it where the class-straddling slices are a large share of the network (accap_a3, 16 slices: +21 % nodes/s); on a large
+  // network the few extra slices only add runs (wordpress7_500: -1 %), so the padding must be at least 1/16 of the records.
+  if (n_pad == n_props || (n_pad + 63) / 64 >= 0xfffe || ((long long)(n_pad - n_props) * 16 < n_props && !(cfg.reserved[0] & 0x10))) return n_props;
+  Layout l2;
+  LaunchPlan p2;
+  if (choose_layout(cfg, caps, n_vars, n_stores, stores, n_pad, &l2, &p2) != TB_OK || p2.mem_kind == TB_MEM_GLOBAL) return n_props;
+  *lay = std::move(l2);
+  *plan = p2;
+  return n_pad;
+}
+// Lanes of every slice that hold a propagator (DevProblem::slice_real), sized for the plan.
+std::vector<int> real_lanes(const std::vector<tb_prop>& props, int n_slices) {
+  std::vector<int> r((size_t)std::max(1, n_slices), 0);
+  for (size_t i = 0; i < props.size(); ++i)
+    if (props[i].op >= 0 && i / 64 < r.size()) r[i / 64]++;
+  return r;
+}
+
 extern "C" {
 
 const char* tb_version(void) { return "turbo-hip 0.1.0 (gfx950)"; }
@@ -743,12 +802,13 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   Layout lay;
   LaunchPlan plan;
   if ((rc = choose_layout(cfg, caps, n_vars, n_stores, stores_inout, n_props, &lay, &plan)) != TB_OK) return rc;
+  const int32_t n_rec = plan_records(cfg, caps, n_vars, n_stores, stores_inout, n_props, props, &lay, &plan);  // records the kernels see
   const size_t VX = (size_t)plan.vext, slab_bytes = VX * 8;
 
   DevBuffers bufs;
   DevProblem P{};
   int4* d_props = nullptr; int2* d_stores = nullptr; PropagateOut* d_out = nullptr;
-  if ((rc = bufs.alloc(&d_props, ((size_t)n_props + 63) / 64 * 64)) != TB_OK) return rc;
+  if ((rc = bufs.alloc(&d_props, (size_t)plan.n_slices * 64)) != TB_OK) return rc;
   if ((rc = bufs.alloc(&d_stores, (size_t)n_stores * VX)) != TB_OK) return rc;
   if ((rc = bufs.alloc(&d_out, (size_t)n_stores)) != TB_OK) return rc;
   {
@@ -756,12 +816,20 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     std::vector<int> v0, value((size_t)n_vars);
     find_constants(n_vars, n_stores, stores_inout, &c0, &v0);
     for (int v = 0; v < n_vars; ++v) { is_const[(size_t)lay.perm[(size_t)v]] = c0[(size_t)v]; value[(size_t)lay.perm[(size_t)v]] = v0[(size_t)v]; }
-    const InternalNet net = to_internal(lay, stores_inout, n_props, props, (cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL, cfg.fixpoint == 2 && !(cfg.reserved[0] & 0x8000000));
-    const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const, value, !(cfg.reserved[0] & 0x80));
-    const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj, lay.n_int);
-    if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
+    const InternalNet net = to_internal(lay, stores_inout, n_props, props, (cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL, cfg.fixpoint == 2 && !(cfg.reserved[0] & 0x8000000), n_rec != n_props);
+    if ((int32_t)net.props.size() != n_rec) return fail(TB_ERR_INVALID, "internal: record padding does not match its plan");
+    const Adjacency adj = build_adjacency(n_vars, n_rec, net.props.data(), is_const, value, !(cfg.reserved[0] & 0x80));
+    std::vector<int4> packed = pack_props(n_rec, net.props.data(), is_const, value, adj, lay.n_int);
+    packed.resize((size_t)plan.n_slices * 64, make_int4(K_LEQ_T, 0, 0, 0));
+    if (n_rec) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
     {
-      const std::vector<int4> succ = pack_succ(n_props, net.props.data(), adj, packed, value, !(cfg.reserved[0] & 0x4000000));
+      const std::vector<int> real = real_lanes(net.props, plan.n_slices);
+      int* d_real = nullptr;
+      if ((rc = bufs.alloc(&d_real, real.size())) != TB_OK) return rc;
+      HIP_TRY(hipMemcpy(d_real, real.data(), real.size() * sizeof(int), hipMemcpyHostToDevice));
+      P.slice_real = d_real;
+      std::vector<int4> succ = pack_succ(n_rec, net.props.data(), adj, packed, value, !(cfg.reserved[0] & 0x4000000));
+      succ.resize((size_t)plan.n_slices * 64, make_int4(-1, -1, -1, 0));
       int4* d_succ = nullptr;
       if ((rc = bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
       if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -781,7 +849,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   std::vector<unsigned char> slabs((size_t)n_stores * slab_bytes, 0);
   for (int32_t k = 0; k < n_stores; ++k) encode_slab(lay, stores_inout + (size_t)k * (size_t)n_vars, slabs.data() + (size_t)k * slab_bytes);
   HIP_TRY(hipMemcpy(d_stores, slabs.data(), slabs.size(), hipMemcpyHostToDevice));
-  P.n_vars = n_vars; P.n_props = n_props; P.props = d_props;
+  P.n_vars = n_vars; P.n_props = n_rec; P.props = d_props;
   P.fixpoint = cfg.fixpoint; P.wac1_threshold = (int)std::min<uint64_t>(cfg.wac1_threshold, 0x7fffffffu);
   P.mem_kind = plan.mem_kind; P.debug = cfg.reserved[0];
   const bool event = cfg.fixpoint == 2, compact = event ? plan.compact != 0 : cfg.entailed_prop_removal != 0;  // the kernels' fourth template flag
@@ -854,6 +922,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   s->n_vars = n_vars; s->obj_var = obj_var;
   if ((rc = query_caps(s->cfg.device, &s->caps)) != TB_OK) return rc;
   if ((rc = choose_layout(s->cfg, s->caps, n_vars, 1, root_store, n_props, &s->lay, &s->plan)) != TB_OK) return rc;
+  int32_t n_rec = plan_records(s->cfg, s->caps, n_vars, 1, root_store, n_props, props, &s->lay, &s->plan);  // records the kernels see
   {
     // cap the grid by what is actually resident (registers, LDS): queued workgroups of a persistent kernel only
     // add tail latency; re-plan so that the subproblem count follows the real workgroup count
@@ -862,7 +931,11 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     if (occ > 0 && (long long)occ * s->caps.cus < (long long)s->plan.num_blocks) {
       tb_config capped = s->cfg;
       capped.or_nodes = (uint64_t)occ * (uint64_t)s->caps.cus;
-      if ((rc = choose_layout(capped, s->caps, n_vars, 1, root_store, n_props, &s->lay, &s->plan)) != TB_OK) return rc;
+      if ((rc = choose_layout(capped, s->caps, n_vars, 1, root_store, n_rec, &s->lay, &s->plan)) != TB_OK) return rc;
+      if (n_rec != n_props && s->plan.mem_kind == TB_MEM_GLOBAL) {  // (the padded array no longer fits next to the capped grid: plan the plain one)
+        n_rec = n_props;
+        if ((rc = choose_layout(capped, s->caps, n_vars, 1, root_store, n_rec, &s->lay, &s->plan)) != TB_OK) return rc;
+      }
       if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->plan.kernel_event != 0, s->plan.kernel_opt != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     }
   }
@@ -885,22 +958,30 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   const int32_t i_obj = obj_var >= 0 ? lay.perm[(size_t)obj_var] : -1;
 
   int4* d_props = nullptr; int2* d_root = nullptr; int *d_vo = nullptr, *d_vl = nullptr, *d_off = nullptr, *d_sv = nullptr;
-  if ((rc = s->bufs.alloc(&d_props, ((size_t)n_props + 63) / 64 * 64)) != TB_OK) return rc;
+  if ((rc = s->bufs.alloc(&d_props, (size_t)plan.n_slices * 64)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_root, VX)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_vo, (size_t)n_strats)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_vl, (size_t)n_strats)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_off, (size_t)n_strats + 1)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_sv, (size_t)total_svars)) != TB_OK) return rc;
   {
-    const InternalNet net = to_internal(lay, root_store, n_props, props, (s->cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL, s->cfg.fixpoint == 2 && !(s->cfg.reserved[0] & 0x8000000));
+    const InternalNet net = to_internal(lay, root_store, n_props, props, (s->cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL, s->cfg.fixpoint == 2 && !(s->cfg.reserved[0] & 0x8000000), n_rec != n_props);
+    if ((int32_t)net.props.size() != n_rec) return fail(TB_ERR_INVALID, "internal: record padding does not match its plan");
     std::vector<char> is_const;
     std::vector<int> value;
     find_constants(n_vars, 1, net.store.data(), &is_const, &value);  // constants = singleton variables of the root store
-    const Adjacency adj = build_adjacency(n_vars, n_props, net.props.data(), is_const, value, !(s->cfg.reserved[0] & 0x80));
-    const std::vector<int4> packed = pack_props(n_props, net.props.data(), is_const, value, adj, lay.n_int);
-    if (n_props) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
+    const Adjacency adj = build_adjacency(n_vars, n_rec, net.props.data(), is_const, value, !(s->cfg.reserved[0] & 0x80));
+    std::vector<int4> packed = pack_props(n_rec, net.props.data(), is_const, value, adj, lay.n_int);
+    packed.resize((size_t)plan.n_slices * 64, make_int4(K_LEQ_T, 0, 0, 0));
+    if (n_rec) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
     {
-      const std::vector<int4> succ = pack_succ(n_props, net.props.data(), adj, packed, value, !(s->cfg.reserved[0] & 0x4000000));
+      const std::vector<int> real = real_lanes(net.props, plan.n_slices);
+      int* d_real = nullptr;
+      if ((rc = s->bufs.alloc(&d_real, real.size())) != TB_OK) return rc;
+      HIP_TRY(hipMemcpy(d_real, real.data(), real.size() * sizeof(int), hipMemcpyHostToDevice));
+      s->P.slice_real = d_real;
+      std::vector<int4> succ = pack_succ(n_rec, net.props.data(), adj, packed, value, !(s->cfg.reserved[0] & 0x4000000));
+      succ.resize((size_t)plan.n_slices * 64, make_int4(-1, -1, -1, 0));
       int4* d_succ = nullptr;
       if ((rc = s->bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
       if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -937,7 +1018,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   if ((rc = s->bufs.alloc(&P.ctrl, 1)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&s->d_now, 1)) != TB_OK) return rc;
 
-  P.n_vars = n_vars; P.n_props = n_props; P.n_strats = n_strats; P.obj_var = i_obj;
+  P.n_vars = n_vars; P.n_props = n_rec; P.n_strats = n_strats; P.obj_var = i_obj;
   P.props = d_props; P.root_store = d_root;
   P.strat_var_order = d_vo; P.strat_val_order = d_vl; P.strat_off = d_off; P.strat_vars = d_sv;
   P.fixpoint = s->cfg.fixpoint;

@@ -624,7 +624,8 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
 #endif
         if (ld(&sh.bot) | ld(&sh.abort)) break;  // the node failed in another wave
         {
-          const bool act = s * 64 + lane < n;
+          // (classes start on slice boundaries: a slice may end with idle padding -- records whose word0 carries no class set)
+          const bool act = ((unsigned)pr.x >> 16) != 0u;
           const RunEnv E{P, sh, nxt, ubits, s};
           const unsigned key = (unsigned)__builtin_amdgcn_readfirstlane(pr.x) >> 16;  // wave-uniform: scalar dispatch
           unsigned wave_iters;
@@ -1263,7 +1264,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
     const int lane = threadIdx.x & 63;
     for (int s = threadIdx.x >> 6; s < P.n_slices; s += blockDim.x >> 6) {
       const int i = s * 64 + lane;
-      const bool act = i < P.n_props;
+      const bool act = lane < P.slice_real[s];  // (idle padding at the end of a class is not a propagator)
       const int4 pr = props[i];
       const Itv X = load_dom<C>(store, P.n_int, pr.y), Y = load_dom<C>(store, P.n_int, pr.z), Z = load_dom<C>(store, P.n_int, pr.w);
       const Cand c = evaluate_packed(pr.x, X, Y, Z);
