@@ -68,17 +68,21 @@ def test_oracle_reproduces_the_headline_vectors(key):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["wac1", "event", "event_recompute", "wac1_rm"])
+@pytest.mark.parametrize("mode", ["wac1", "event", "event_recompute", "wac1_rm", "event_padded", "event_unpadded"])
 @pytest.mark.parametrize("key", sorted(GOLDEN))
 def test_engine_reproduces_the_headline_trees(key, mode):
-    """GPU: the same prefix of the tree through the C-ABI, without running the oracle."""
+    """GPU: the same prefix of the tree through the C-ABI, without running the oracle.
+    (event_padded / event_unpadded: every class of records padded to whole slices, or never -- the engine decides by the size of
+    the network otherwise; test knobs 0x10 / 0x20 of tb_config.reserved[0].)"""
     cfg = {"wac1": dict(fixpoint=1), "event": dict(fixpoint=2), "event_recompute": dict(fixpoint=2, snapshot_levels=1),
-           "wac1_rm": dict(fixpoint=1, entailed_prop_removal=1)}[mode]
+           "wac1_rm": dict(fixpoint=1, entailed_prop_removal=1), "event_padded": dict(fixpoint=2, debug_extra=0x10),
+           "event_unpadded": dict(fixpoint=2, debug_extra=0x20)}[mode]
+    extra = cfg.pop("debug_extra", 0)
     tcn = network(key)  # simplified: root fixpoints by the engine itself (tb_propagate) -- the network must come out identical
     check_network(tcn, GOLDEN[key])
     for case, rec in GOLDEN[key]["cases"].items():
         s = capi.Session(tcn, capi.make_config(or_nodes=1, subproblems_power=rec["subproblems_power"], stop_after_n_nodes=rec["cutnodes"],
-                                               timeout_ms=120000, debug=KEEP_LAST, **cfg))
+                                               timeout_ms=120000, debug=KEEP_LAST | extra, **cfg))
         s.start()
         while not s.poll()[1]:
             pass
