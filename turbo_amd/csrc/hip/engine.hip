@@ -682,6 +682,7 @@ struct tb_session {
   Layout lay;
   LaunchPlan plan;
   DevProblem P{};
+  DevProblem* d_P = nullptr;  // device copy of P, refreshed at every start (the search kernel reads the problem through a pointer)
   DevBuffers bufs;
   Mailbox* mbox_host = nullptr;
   Mailbox* mbox_dev = nullptr;
@@ -1213,9 +1214,11 @@ int tb_session_start(tb_session* s) {
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->P.deadline_ticks = s->cfg.timeout_ms != 0 ? now + (long long)(s->cfg.timeout_ms + 2000) * (long long)s->caps.wall_khz : 0;
   s->t_start = std::chrono::steady_clock::now();
+  if (s->d_P == nullptr) { int rc2 = s->bufs.alloc(&s->d_P, 1); if (rc2 != TB_OK) return rc2; }
+  HIP_TRY(hipMemcpyAsync(s->d_P, &s->P, sizeof(DevProblem), hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipEventRecord(s->ev_start, s->stream));
   const LaunchPlan& plan = s->plan;
-  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, plan.kernel_event != 0, plan.kernel_opt != 0, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->mbox_dev));
+  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, plan.kernel_event != 0, plan.kernel_opt != 0, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->d_P, s->mbox_dev));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev_stop, s->stream));
   s->started = true;

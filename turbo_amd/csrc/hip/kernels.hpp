@@ -1373,7 +1373,13 @@ constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 255) / 256 * 256);
 // LDS; measured 17.9 / 20.5 / 22.3 / 23.4e6 nodes/s with 4 / 5 / 6 / 7); the sweep variants are VALU bound and keep 4.
 // OPT: the COMPACT store layout for the event kernels, entailed-slice removal for the sweeping ones.
 template <int MEM, int TMAX, bool EVENT, bool OPT>
-__global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES : (TMAX == 256 ? 5 : 4)) solve_kernel(DevProblem P, Mailbox* mbox) {
+__global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES : (TMAX == 256 ? 5 : 4)) solve_kernel(DevProblem by_value, const DevProblem* __restrict__ problem, Mailbox* mbox) {
+  // The problem description is read through a pointer, not passed by value: as kernel arguments its ~70 scalars were all
+  // hoisted into SGPRs for the whole persistent loop and 260 of them spilled through VGPR lanes (v_writelane / v_readlane,
+  // VALU work on an issue-bound kernel); behind a pointer the compiler loads a field where it is used (scalar cache):
+  // 137 spills, +4 % nodes/s on wordpress7_500.  The sweeping kernels keep the by-value arguments: their loops are short and
+  // spill-free, and reloading fields inside them costs 2 %.
+  const DevProblem& P = EVENT ? *problem : by_value;
   constexpr bool C = EVENT && OPT, RM = !EVENT && OPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
