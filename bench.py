@@ -7,6 +7,12 @@ WHOLE search (all workgroups of all GPUs together, `stop_after_n_nodes_total`), 
 (tb_session_create uploads them before the timed region).  The budget does not depend on the number of GPUs, so
 `--gpus N` measures strong scaling: the same amount of search in less time.  (`--scaling weak` multiplies it by N.)
 
+`python bench.py --gpus N` started on its own (no WORLD_SIZE / RANK in the environment) launches its N ranks itself: the parent
+never touches a GPU, starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, relays
+its output and exits with its code.  Started by torch.distributed.run (the driver's way) it is one of the ranks.  A rank whose
+world size differs from --gpus, or that has no device of its own (without --share-device), exits non-zero: the line never
+says `n_gpus` != --gpus.
+
 N > 1: one process per GPU (torch.distributed; backend "nccl" is RCCL).  The 2^d subproblems are dealt block-cyclically,
 every rank's session is linked to the others' (IPC handles exchanged with an all_gather), and during a step the KERNELS
 exchange the incumbent bound and steal work from each other over xGMI; the processes only meet at the barriers around a
@@ -30,12 +36,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# instance, node budget of one step for the event / sweeping fixpoints (a little under one second of one MI355X each)
+# instance, node budget of one step for the event / sweeping fixpoints.  The budget is the same at every N (strong scaling), so
+# it is sized for the LARGEST run: at 8 GPUs a step of the headline workload still lasts >= 0.3 s (process-launch skew after the
+# arm -> barrier -> start handshake is well under that), which makes it 2-3 s on one GPU.
 WORKLOADS = {
-    "wordpress7_500": ("example_wordpress7_500.fzn", 12_000_000, 1_500_000),
-    "accap_a3": ("accap_a3.fzn", 12_000_000, 12_000_000),
-    "trains15": ("trains15.fzn", 12_000_000, 4_000_000),
-    "synthetic": ("synthetic 100k x 500k (seed 42)", 8_000, 8_000),
+    "wordpress7_500": ("example_wordpress7_500.fzn", 96_000_000, 6_000_000),
+    "accap_a3": ("accap_a3.fzn", 96_000_000, 48_000_000),
+    "trains15": ("trains15.fzn", 48_000_000, 12_000_000),
+    "synthetic": ("synthetic 100k x 500k (seed 42)", 48_000, 24_000),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_PEAK_GBPS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth (8 XCDs)
@@ -97,6 +105,43 @@ def cpu_baseline(tcn, subproblems_power: int, seconds: float) -> dict:
                            "sample": f"first {dsecs:.1f} s of the plain DFS branch-and-bound (no EPS; deep nodes only): {dfs['nodes']} nodes"}}
 
 
+def reference_invocation(seconds: float) -> dict:
+    """The reference's own example command (README.md:25: `turbo -s -v -i -t 20000 benchmarks/example_wordpress7_500.fzn`) through
+    this repo's `turbo` executable, with a shorter -t: what a user of the reference sees for the headline instance."""
+    import subprocess
+    exe = os.path.join(ROOT, "turbo_amd", "bin", "turbo")
+    cmd = [exe, "-s", "-v", "-i", "-t", str(int(seconds * 1000)), os.path.join("benchmarks", "example_wordpress7_500.fzn")]
+    rec = {"command": "turbo_amd/bin/turbo " + " ".join(cmd[1:]), "reference_command": "turbo -s -v -i -t 20000 benchmarks/example_wordpress7_500.fzn (README.md:25)"}
+    if not os.path.exists(exe):
+        return dict(rec, error="turbo_amd/bin/turbo is not built (make cli)")
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=seconds + 120)
+    except Exception as e:  # noqa: BLE001
+        return dict(rec, error=repr(e))
+    stats = {}
+    for line in p.stdout.splitlines():
+        if line.startswith("%%%mzn-stat: ") and "=" in line:
+            k, v = line[len("%%%mzn-stat: "):].split("=", 1)
+            stats[k] = v.strip().strip('"')
+    num = lambda k: (float(stats[k]) if k in stats else None)  # noqa: E731
+    rec.update({"returncode": p.returncode, "wall_s": time.perf_counter() - t0,
+                "best_objective": int(stats["objective"]) if "objective" in stats else None,
+                "solutions_printed": sum(1 for l in p.stdout.splitlines() if l == "----------"),
+                "exhaustive": any(l == "==========" for l in p.stdout.splitlines()),
+                "nodes": int(stats["nodes"]) if "nodes" in stats else None,
+                "failures": int(stats["failures"]) if "failures" in stats else None,
+                "peak_depth": int(stats["peakDepth"]) if "peakDepth" in stats else None,
+                "num_deductions": int(stats["num_deductions"]) if "num_deductions" in stats else None,
+                "solve_time_s": num("solveTime"), "init_time_s": num("initTime"), "kernel_time_s": num("kernel_time"),
+                "nodes_per_second": num("nodes_per_second"), "propagations_per_second": num("propagations_per_second"),
+                "fixpoint": stats.get("fixpoint"), "num_blocks": stats.get("num_blocks"), "memory_configuration": stats.get("memory_configuration"),
+                "eps_num_subproblems": stats.get("eps_num_subproblems"), "eps_solved_subproblems": stats.get("eps_solved_subproblems")})
+    if p.returncode != 0:
+        rec["stderr_tail"] = p.stderr[-500:]
+    return rec
+
+
 def profile_figures(workload: str, fixpoint: str) -> dict | None:
     """Counter-derived figures of the same command, collected by scripts/profile_round.sh in separate rocprofv3 --pmc
     passes and committed under profiles/ (they are NOT measured in this run: the source file is named)."""
@@ -113,6 +158,26 @@ def profile_figures(workload: str, fixpoint: str) -> dict | None:
     return None
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` on its own: run the N ranks as FRESH child processes (one per GPU, torch.distributed.run on
+    127.0.0.1) and relay what they print.  This process never imports torch and never touches a GPU; it exits with the
+    launcher's code, so a rank that fails (e.g. no device for it) makes the whole run fail."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    assert child.stdout is not None
+    for line in child.stdout:  # rank 0's JSON line (and nothing else) comes through stdout; stderr is inherited
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,7 +189,9 @@ def main() -> int:
     ap.add_argument("--cutnodes", type=int, default=0, help="additionally cap every workgroup at this many nodes (the reference's -cutnodes)")
     ap.add_argument("--or-nodes", type=int, default=0, help="workgroups per GPU (0 = fill the GPU)")
     ap.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = the engine's choice)")
-    ap.add_argument("--side-steps", type=int, default=2, help="steps of the other fixpoint (wac1 <-> event) timed beside the headline (0 = skip)")
+    ap.add_argument("--side-steps", type=int, default=2, help="steps of each of the other fixpoints (wac1, ac1, event) timed beside the headline (0 = skip)")
+    ap.add_argument("--reference-seconds", type=float, default=8.0,
+                    help="-t of the reference's README invocation run through the turbo CLI for the `reference_invocation` record (0 = skip)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: the node budget of a step does not depend on the number of GPUs; weak: it is multiplied by it")
     ap.add_argument("--exchange", default="peer", choices=["peer", "host"],
@@ -137,11 +204,22 @@ def main() -> int:
     ap.add_argument("--share-device", action="store_true", help="testing aid: every rank uses cuda:0")
     args = ap.parse_args()
 
+    # The cells the GPUs exchange through travel between processes as dmabuf IPC handles: the legacy IPC mode of the HSA runtime
+    # is not supported by the host driver (hipIpcGetMemHandle fails with "invalid argument").  Set before HIP initialises, in
+    # the launcher and in every rank.
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return launch_ranks(args.gpus)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world != 1:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` or under "
+              f"torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
+        return 2
     import torch
     from turbo_amd import capi, frontend
     from turbo_amd import distributed as tdist
@@ -150,6 +228,10 @@ def main() -> int:
         raise SystemExit("bench.py needs an MI355X: no GPU is visible and the engine has no CPU fallback")
     if args.share_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} needs device {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible "
+              f"(--share-device puts every rank on cuda:0, a testing aid)", file=sys.stderr)
+        return 3
     torch.cuda.set_device(local_rank)
     dist = None
     tdev = "cuda" if args.dist_backend == "nccl" else "cpu"
@@ -244,19 +326,25 @@ def main() -> int:
            "first_block_idle_ms": last["min_block_ns"] * 1e-6, "last_block_ms": last["max_block_ns"] * 1e-6, "workgroups": blocks}
     per_rank = tdist.gather_rank_rows(row, dist if world > 1 else None, tdev)
 
-    # the other fixpoint on the same workload, beside the headline
-    side = None
-    if args.side_steps > 0 and args.fixpoint in ("event", "wac1"):
-        other = "wac1" if args.fixpoint == "event" else "event"
-        b2 = (args.nodes_total or (budget_event if other == "event" else budget_sweep)) * scale
-        sess2, linked2 = make_session(other, b2)
-        e2, _, g2, l2 = timed(sess2, linked2, args.side_steps, 1)
-        side = {"fixpoint": other, "steps": args.side_steps, "nodes_total": b2, "nodes_per_sec": g2["nodes"] / e2,
-                "propagations_per_sec": g2["num_deductions"] / e2, "workgroups_per_gpu": l2["num_blocks"], "threads": l2["threads_per_block"],
-                "memory": capi.MEM_KINDS[l2["mem_kind"]],
-                "note": ("the reference's own GPU default (-fp wac1): every propagator is evaluated in every sweep" if other == "wac1" else
-                         "the engine's event-driven fixpoint: propagators re-evaluated only when one of their variables was narrowed") + "; same search tree"}
-        sess2.close()
+    # the reference's own fixpoints on the same workload, beside the headline: `-fp wac1` (its GPU default) and `-fp ac1` (what its
+    # CPU path runs: the like-for-like row for the AC1 CPU baseline); `event` when the headline is one of those
+    sides = []
+    if args.side_steps > 0:
+        notes = {"wac1": "the reference's own GPU default (-fp wac1): every propagator is evaluated in every sweep, a wave iterates its 64 to a local fixpoint",
+                 "ac1": "the reference's -fp ac1 (block-synchronous sweeps; the fixpoint loop of its CPU path): like-for-like with the AC1 CPU baseline",
+                 "event": "the engine's event-driven fixpoint: propagators re-evaluated only when one of their variables was narrowed"}
+        for other in ("wac1", "ac1", "event"):
+            if other == args.fixpoint:
+                continue
+            b2 = args.nodes_total or (budget_event if other == "event" else (budget_sweep if other == "wac1" else max(1, budget_sweep // 6)))
+            b2 *= scale
+            sess2, linked2 = make_session(other, b2)
+            e2, _, g2, l2 = timed(sess2, linked2, args.side_steps, 1)
+            sides.append({"fixpoint": other, "steps": args.side_steps, "nodes_total": b2, "nodes_per_sec": g2["nodes"] / e2,
+                          "propagations_per_sec": g2["num_deductions"] / e2, "ms_per_step": e2 * 1000.0 / args.side_steps,
+                          "workgroups_per_gpu": l2["num_blocks"], "threads": l2["threads_per_block"],
+                          "memory": capi.MEM_KINDS[l2["mem_kind"]], "note": notes[other] + "; same search tree"})
+            sess2.close()
 
     if rank == 0:
         kernel_s = tot["kernel_ns"] * 1e-9 / steps                 # average launch duration of solve_kernel (HIP events on its stream, rank 0)
@@ -305,17 +393,25 @@ def main() -> int:
         }
         if world > 1:
             ks = [r["kernel_ms"] for r in per_rank]
-            out["multi_gpu"] = {"exchange": "peer cells over xGMI" if linked else "host relay", "per_rank": per_rank,
+            out["multi_gpu"] = {"exchange": "peer cells over xGMI" if linked else "host relay",
+                                "dist": {"backend": dist.get_backend(), "world_size": dist.get_world_size()}, "per_rank": per_rank,
                                 "kernel_ms_max_over_mean": max(ks) / max(1e-9, sum(ks) / len(ks)),
-                                "note": "fixed node budget for all GPUs together (counted in rank 0's cell); wait_share = workgroup-time without a subproblem"}
+                                "note": "fixed node budget for all GPUs together (every device counts its own nodes, its poller folds them into rank 0's cell once per poll period); wait_share = workgroup-time without a subproblem"}
         else:
             out["balance"] = per_rank[0]
-        if side is not None:
+        for side in sides:
             out[f"{side['fixpoint']}_mode"] = side
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tcn, plan["subproblems_power"], args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = {"propagations": out["value"] / max(out["cpu_baseline"]["value"], 1e-9),
                                               "nodes": out["nodes_per_sec"] / max(out["cpu_baseline"]["nodes_per_sec"], 1e-9)}
+            ac1 = next((sd for sd in sides if sd["fixpoint"] == "ac1"), None)
+            if ac1 is not None:  # the same fixpoint loop on both sides (`-fp ac1` on the GPU, AC1 on the CPU)
+                out["speedup_vs_cpu_baseline"]["ac1_like_for_like"] = {"propagations": ac1["propagations_per_sec"] / max(out["cpu_baseline"]["value"], 1e-9),
+                                                                       "nodes": ac1["nodes_per_sec"] / max(out["cpu_baseline"]["nodes_per_sec"], 1e-9)}
+        if world == 1 and args.workload == "wordpress7_500" and args.reference_seconds > 0:
+            session.close()  # the CLI run gets the whole GPU
+            out["reference_invocation"] = reference_invocation(args.reference_seconds)
         print(json.dumps(out), flush=True)
     session.close()
     if world > 1:

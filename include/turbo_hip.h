@@ -60,8 +60,10 @@ typedef struct {
   uint64_t stop_after_n_solutions;  /* -n, satisfaction problems only; 0 = all */
   uint64_t wac1_threshold;          /* -wac1_threshold (barebones:939) */
   uint64_t stop_after_n_nodes_total;/* node budget of the whole search, all workgroups of all linked GPUs together (0 = none): fixed total
-                                       work for strong-scaling measurements.  Counted in rank 0's cell in batches of 32 nodes per workgroup */
-  int32_t subproblems_power;        /* -sub; -1 = auto */
+                                       work for strong-scaling measurements.  Every device counts its own nodes (batches of 32 per workgroup); linked
+                                       devices are summed in rank 0's cell by their pollers, once per poll period */
+  int32_t subproblems_power;        /* -sub; -1 = auto.  At most 2^28 - 65536 subproblems per GPU (its share is served through a 28-bit queue
+                                       word; the reference's 64-bit counter has no limit, its default is 300 per workgroup); at most 2^40 in all */
   int32_t fixpoint;                 /* 0 = AC1, 1 = WAC1 (config.hpp:22-25), 2 = event-driven WAC1 (this engine), 3 = automatic: event-driven from
                                        2048 propagators on, WAC1 below (a sweep over a few slices is cheaper than any bookkeeping); all of
                                        them compute the same fixpoint at every node, hence the same search tree */
@@ -82,8 +84,10 @@ typedef struct {
                                        default 0 like the reference).  The event-driven fixpoint always does it. */
   int32_t eps_chunk_log2;           /* multi-GPU: the 2^d subproblems are dealt to the GPUs in chunks of 2^k consecutive indices, k = this
                                        value (0 = one by one, the default: best balance; clamped to subproblems_power) */
-  int32_t decision_stack_depth;     /* capacity of a workgroup's decision stack; 0 = auto (16384; the reference grows its stack on demand,
-                                       barebones:401-403 -- here tb_solve retries with a deeper one when TB_ERR_DEPTH comes back) */
+  int32_t decision_stack_depth;     /* size of one segment of a workgroup's decision stack, rounded up to a power of two; 0 = auto (16384).
+                                       The reference grows a block's stack on demand (barebones:401-403); here a workgroup whose search goes
+                                       deeper takes further segments (up to 16 in all) from a per-session pool in HBM, in the kernel.  If that
+                                       is not enough the search ends with TB_ERR_DEPTH; tb_solve and the CLI then run it again with 8x larger segments */
   int32_t poll_period_us;           /* wall-clock period at which the kernel looks at the host mailbox and at the peers' words; 0 = 100 us */
   int32_t reserved[3];              /* 0 in production.  Tuning / test knobs read by the engine (the device-side ones -- ablations, timers,
                                        0x20000, 0x400000 -- only in a -DTB_TUNING build: they sit in the hot loops):
@@ -198,7 +202,7 @@ typedef struct {
 } tb_plan;
 int tb_session_plan(tb_session* s, tb_plan* plan_out);
 /*
- * Multi-GPU wiring, between create and start.  Every session owns one 256-byte cell in fine-grained device memory: its
+ * Multi-GPU wiring, between create and start.  Every session owns one 192-byte cell in fine-grained device memory: its
  * work-queue word and the incumbent bound imported from the other GPUs -- the only state another GPU touches
  * (barebones GridData::next_subproblem / appx_best_bound, :418,426).  Once the sessions of a node are linked, their
  * kernels exchange the bound (atomicMin of one int32 into every peer's cell) and rebalance work (CAS on a peer's queue
@@ -207,6 +211,8 @@ int tb_session_plan(tb_session* s, tb_plan* plan_out);
  *   same process:     tb_session_link_peer(a, b) in both directions (enables peer access between the two devices);
  *   other process:    tb_session_export_peer -> 64-byte handle (hipIpcMemHandle_t), sent by whatever means the processes
  *                     share (bench.py: torch.distributed all_gather over RCCL), tb_session_import_peer on the other side.
+ * export / link fail with TB_ERR_HIP when a cell could not be placed in fine-grained memory (cross-GPU atomics on it would not
+ * be coherent while kernels run): the caller then uses the host relay.
  * tb_session_arm resets the device-side state of a search (queue, bounds, counters); start does it itself when the
  * caller has not.  With linked sessions every rank arms, then all ranks synchronise, then every rank starts -- and all
  * ranks synchronise again after finish before the next arm: a peer must not touch a cell that is being reset.

@@ -135,8 +135,16 @@ assert s.pushed == sorted(s.pushed, reverse=True) and s.pushed[-1] == 12, s.push
 assert rounds >= 11                                                                  # nobody leaves before the slowest rank is done
 winner, gb, tot = reduce_results(True, 30 if r == 0 else 12, {"nodes": 10 * (r + 1), "num_deductions": 7}, dist)
 assert (winner, gb, tot["nodes"], tot["num_deductions"]) == (1, 12, 30, 14), (winner, gb, tot)
-winner, gb, _ = reduce_results(True, 5, {}, dist)      # tie on the bound -> lowest rank (lowest subproblem slice)
+winner, gb, _ = reduce_results(True, 5, {}, dist)      # tie on the bound, no subproblem reported -> lowest rank
 assert (winner, gb) == (0, 5)
+# tie on the bound: the LOWEST SUBPROBLEM INDEX wins, whichever rank holds it (block-cyclic shares + work stealing: rank 1
+# may well hold index 2 while rank 0 holds index 7) -- the canonical pass is only deterministic that way
+winner, gb, _ = reduce_results(True, 5, {"best_subproblem": 7 if r == 0 else 2}, dist)
+assert (winner, gb) == (1, 5), (winner, gb)
+winner, gb, _ = reduce_results(True, 5 if r == 0 else 4, {"best_subproblem": 0 if r == 0 else 9}, dist)   # the bound comes first
+assert (winner, gb) == (1, 4), (winner, gb)
+winner, gb, _ = reduce_results(r == 0, 5, {"best_subproblem": 7}, dist)   # only rank 0 has a solution
+assert (winner, gb) == (0, 5), (winner, gb)
 winner, gb, _ = reduce_results(False, 0, {}, dist)
 assert winner == -1
 dist.destroy_process_group()
@@ -242,3 +250,29 @@ def test_model_statistics_and_random_order():
         assert t.strat_var_order[0] == frontend.VAR_ORDERS["input_order"]
         orders.setdefault(seed, []).append(vars0)
     assert orders[0][0] == orders[0][1] and orders[0][0] != orders[5][0]
+
+
+# ---- bench.py as a launcher (no GPU needed: the ranks fail loudly without one, and the launcher must relay that) ----------
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], env=dict(_clean_env(), WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_launcher_starts_child_ranks_and_relays_their_failure():
+    """`python bench.py --gpus 2` without WORLD_SIZE: the parent spawns two ranks under torch.distributed.run.  Here there is no
+    GPU, so every rank stops with the engine's "no CPU fallback" message; the launcher exits non-zero and prints no result line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--no-cpu-baseline", "--side-steps", "0"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode != 0
+    assert "no GPU is visible" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

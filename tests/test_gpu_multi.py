@@ -252,3 +252,108 @@ def test_many_ranks_on_one_gpu_with_skewed_grids(rel, world, chunk):
     assert tot["eps_solved_subproblems"] + tot["eps_skipped_subproblems"] == 2 ** power
     assert tot["eps_local_subproblems"] == 2 ** power
     assert tot["eps_stolen_subproblems"] > 0
+
+
+# ---- BASELINE.json configs[4] and configs[3] with world_size = 2 on one device ------------------------------------------
+
+@pytest.fixture(scope="module")
+def synthetic():
+    from turbo_amd.synth import make_synthetic
+    return make_synthetic(100_000, 500_000, seed=42)
+
+
+def test_synthetic_100k_x_500k_two_ranks_cover_the_index_space(synthetic):
+    """The 100k x 500k network (store in GLOBAL memory: 800 KB per workgroup) dealt to two linked ranks with skewed grids: peer
+    cells + work stealing + per-workgroup HBM stores together.  The full instance cannot be searched to the end by anybody
+    (20 000 decision variables), so all base variables but the first 40 are fixed to the hidden solution in the root store:
+    same network, same sizes, same memory kind, a tree the search exhausts."""
+    import copy
+    tcn = copy.copy(synthetic)
+    store = synthetic.store.copy()
+    base = synthetic.strat_vars[: synthetic.strat_off[1]]
+    for v in base[40:]:
+        store["lb"][v] = store["ub"][v] = synthetic.hidden_solution[v]
+    tcn.store = store
+    power = 8
+    out = run_group(tcn, power=power, fixpoint=2, per_rank=[dict(or_nodes=2), dict(or_nodes=24)], snapshot_levels=4, timeout_ms=240000)
+    win, tot = merged(out, tcn)
+    assert all(st["mem_kind"] == 0 for _, _, st in out)  # GLOBAL
+    assert all(st["exhaustive"] == 1 for _, _, st in out)
+    assert tot["eps_solved_subproblems"] + tot["eps_skipped_subproblems"] == 2 ** power
+    assert tot["eps_local_subproblems"] == 2 ** power
+    assert tot["eps_stolen_subproblems"] > 0 and out[1][2]["eps_stolen_subproblems"] > 0
+    for has, best, st in out:  # every reported solution satisfies every propagator (oracle as the checker)
+        if has:
+            _, failed, ent, _, _ = pyoracle.propagate(best, tcn.props)
+            assert not failed and ent
+    has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=0)  # 29 nodes sequentially
+    assert has_o and win is not None and win[1]["best_bound"] == st_o["best_bound"]
+
+
+def test_synthetic_100k_x_500k_two_ranks_with_a_node_budget(synthetic):
+    """The unrestricted instance, two linked ranks, a node budget for the pair: both explore, the budget stops both, whatever
+    is reported satisfies the network."""
+    tcn = synthetic
+    budget = 600
+    out = run_group(tcn, power=10, fixpoint=2, stop_after_n_nodes_total=budget, per_rank=[dict(or_nodes=16), dict(or_nodes=16)], snapshot_levels=4, timeout_ms=240000)
+    nodes = sum(st["nodes"] for _, _, st in out)
+    assert all(st["mem_kind"] == 0 and st["nodes"] > 0 and st["exhaustive"] == 0 for _, _, st in out)
+    assert budget <= nodes <= budget + 32 * 64 + 32 * 40  # batches of 32 per workgroup + the nodes in flight when the stop lands
+    for has, best, st in out:
+        if has:
+            _, failed, ent, _, _ = pyoracle.propagate(best, tcn.props)
+            assert not failed and ent
+
+
+@pytest.mark.parametrize("simplified", [False, True], ids=["raw", "simplified"])
+def test_trains15_two_ranks_canonical_solution_is_the_oracles(simplified):
+    """BASELINE.json configs[3] with two ranks: the canonical pass (first solution under obj <= B in subproblem order, lowest
+    subproblem index wins across workgroups AND ranks) returns the store the sequential oracle returns, bit for bit.  B = 110 is
+    the tightest bound for which the oracle's walk ends in a fraction of a second (at 105 it does not within minutes)."""
+    path = os.path.join(BENCH, "trains15.fzn")
+    if simplified:
+        from turbo_amd import preprocess
+        _, tcn, _ = preprocess.load_fzn_simplified(path)
+    else:
+        tcn = frontend.load_fzn(path)
+    power, bound = 10, 110
+    has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power, fixed_bound=bound, timeout_ms=120000)
+    assert has_o and st_o["exhaustive"] == 1
+    out = run_group(tcn, power=power, fixpoint=2, use_fixed_bound=1, fixed_bound=bound, per_rank=[dict(or_nodes=64), dict(or_nodes=64)], snapshot_levels=8)
+    win, _ = merged(out, tcn)
+    assert win is not None
+    assert win[1]["best_subproblem"] == st_o["best_subproblem"]
+    np.testing.assert_array_equal(win[0], best_o)
+    assert tcn.objective_of(win[0]) <= bound
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent starts the two ranks itself (fresh child
+    processes under torch.distributed.run), relays rank 0's line and its exit code.  Both ranks on cuda:0, gloo as the rendezvous."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--share-device", "--dist-backend", "gloo",
+           "--workload", "accap_a3", "--or-nodes", "256", "--nodes-total", "200000", "--no-cpu-baseline", "--side-steps", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0
+    assert rec["multi_gpu"]["exchange"] == "peer cells over xGMI"
+    assert rec["multi_gpu"]["dist"] == {"backend": "gloo", "world_size": 2}
+    assert all(r["nodes"] > 0 for r in rec["multi_gpu"]["per_rank"])
+
+
+def test_bench_refuses_to_report_fewer_gpus_than_asked():
+    """Two ranks on a one-GPU box without --share-device: rank 1 has no device, the run fails -- it never prints n_gpus != --gpus."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with a single GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-backend", "gloo",
+           "--workload", "accap_a3", "--nodes-total", "100000", "--no-cpu-baseline", "--side-steps", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    # and a rank count that contradicts --gpus is refused as well
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr

@@ -29,6 +29,13 @@ struct alignas(16) Ctrl {
   unsigned long long sol_ticket;       // streaming: next sequence number of the solution ring
   int blocks_done;                     // number of workgroups that left the kernel
   int error;                           // device-side error code (1: decision stack overflow)
+  // node budget of the whole search (tb_config.stop_after_n_nodes_total): every workgroup of THIS device adds its nodes here in
+  // batches (agent scope); with linked GPUs the device's poller folds what is new into rank 0's cell once per poll period --
+  // one system-scope atomic per device and period instead of one per workgroup and batch crossing xGMI
+  unsigned long long nodes_local;
+  unsigned long long nodes_folded;     // the part of nodes_local already added to PeerCell::nodes_total of rank 0
+  int dec_pool_next;                   // next free segment of DevProblem::dec_pool (decision stacks grow on demand, barebones:401-403)
+  int steal_lock;                      // one workgroup of this device at a time looks for work on the other GPUs
 };
 constexpr int STOP_HOST = 1, STOP_GPU = 2;
 
@@ -47,7 +54,7 @@ struct QueueDesc {
 struct alignas(64) PeerCell {
   unsigned long long queue;
   int bound;
-  int stealing;   // 1 while a workgroup of this device moves a range from a peer into `queue`
+  int stealing;   // 1 while a range taken from a peer's queue is in transit to this device's `queue` (not while it merely looks around)
   int stop;       // a peer reached the solution limit / proved the objective unbounded
   int waiting;    // workgroups of this device currently waiting for work (diagnostic)
   unsigned long long stolen_in, stolen_out;  // subproblems moved into / out of this device (diagnostic)
@@ -55,6 +62,10 @@ struct alignas(64) PeerCell {
   unsigned long long pad[2];
   QueueDesc desc[8];
 };
+static_assert(sizeof(PeerCell) == 192, "PeerCell is mapped by other processes: its layout is part of the protocol");
+// 28-bit `next` / `hi`: a GPU serves at most 2^28 - 65536 subproblems of its share through one queue word (plan_launch refuses
+// more; the margin covers the workgroups that may overshoot `next` at the same moment).  The reference's 64-bit counter has no
+// such limit, but 2^28 subproblems per GPU is 500 times its own default of 300 per workgroup.
 constexpr int Q_BITS = 28;
 constexpr unsigned long long Q_MASK = (1ull << Q_BITS) - 1ull;
 __host__ __device__ inline unsigned long long q_pack(unsigned gen, unsigned long long next, unsigned long long hi) {
@@ -138,7 +149,9 @@ struct DevProblem {
   int mem_kind;            // tb_mem_kind
   int debug;               // ablation knobs for profiling (tb_config.reserved[0]); 0 in production
   int snapshot_levels;     // >= 1
-  int max_depth;           // capacity of the decision stack
+  int max_depth;           // capacity of one segment of the decision stack (a power of two); a workgroup starts with one segment
+  int max_depth_log2;
+  int dec_pool_segments;   // segments in dec_pool, handed out on demand (Ctrl::dec_pool_next)
   int rank, world;         // this device among the GPUs of the search
   int chunk_log2;          // k of the block-cyclic partition
   int poll_ticks;          // wall-clock ticks between two polls of the mailbox / peer cell
@@ -154,7 +167,8 @@ struct DevProblem {
   int2* g_snap;      // [B][L][V] snapshot stack
   int2* g_best;      // [B][V]
   int2* g_last;      // [B][V] test aid (tb_config.reserved[0] & 0x800000): the store of each workgroup when it left the kernel
-  Decision* g_dec;   // [B][max_depth]
+  Decision* g_dec;   // [B][max_depth] first segment of every workgroup's decision stack
+  Decision* dec_pool;  // [dec_pool_segments][max_depth] further segments, taken by the workgroups whose search goes deeper
   BlockStats* g_stats;
   Ctrl* ctrl;
   PeerCell* cell;            // this device's cell

@@ -214,7 +214,10 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   }
   // snapshot stack: as deep as 1/4 of the free HBM allows (288 GB per GPU makes copying cheaper than
   // recomputing from the subproblem root)
-  p.max_depth = cfg.decision_stack_depth > 0 ? std::max(16, cfg.decision_stack_depth) : 16384;
+  // one segment of a workgroup's decision stack (a power of two: dec_at splits an index with a shift); deeper searches take
+  // further segments from a pool (tb_session_create), up to 16 segments per workgroup
+  p.max_depth = 16;
+  while (p.max_depth < (cfg.decision_stack_depth > 0 ? std::min(cfg.decision_stack_depth, 1 << 26) : 16384)) p.max_depth *= 2;
   int L = cfg.snapshot_levels;
   if (L <= 0) {
     const size_t per_level = (size_t)p.num_blocks * (size_t)std::max(1, vext) * 8;
@@ -1015,6 +1018,17 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   if ((rc = s->bufs.alloc(&P.g_snap, B * (size_t)plan.snapshot_levels * VX)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&P.g_best, B * VX)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&P.g_dec, B * (size_t)plan.max_depth)) != TB_OK) return rc;
+  {
+    // Pool of further decision-stack segments, handed out on demand (the reference grows a block's stack when it is full,
+    // barebones:401-403): a quarter as many segments as workgroups, within 1/16 of the memory that is free now.
+    size_t segs = std::max<size_t>(MAX_DEC_SEGS + 1, B / 4);
+    size_t free_now = 0, total = 0;
+    if (hipMemGetInfo(&free_now, &total) != hipSuccess) { (void)hipGetLastError(); free_now = s->caps.free_mem; }
+    const size_t seg_bytes = (size_t)plan.max_depth * sizeof(Decision);
+    segs = std::min(segs, (free_now / 16) / std::max<size_t>(1, seg_bytes));
+    P.dec_pool = nullptr; P.dec_pool_segments = 0;
+    if (segs > 0 && s->bufs.alloc(&P.dec_pool, segs * (size_t)plan.max_depth) == TB_OK) P.dec_pool_segments = (int)std::min<size_t>(segs, 0x7fffffff);
+  }
   if ((rc = s->bufs.alloc(&P.g_stats, B)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&P.ctrl, 1)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&s->d_now, 1)) != TB_OK) return rc;
@@ -1028,6 +1042,8 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   P.has_eps_strategy = s->cfg.has_eps_strategy;
   P.use_fixed_bound = s->cfg.use_fixed_bound; P.fixed_bound = s->cfg.fixed_bound;
   P.mem_kind = plan.mem_kind; P.snapshot_levels = plan.snapshot_levels; P.max_depth = plan.max_depth; P.debug = s->cfg.reserved[0];
+  P.max_depth_log2 = 0;
+  while ((1 << P.max_depth_log2) < plan.max_depth) ++P.max_depth_log2;
   // this rank's block-cyclic share of the 2^d subproblems (device_types.hpp: eps_global_index)
   P.world = std::max(1, s->cfg.world_size); P.rank = P.world > 1 ? s->cfg.rank : 0;
   P.chunk_log2 = std::max(0, std::min(s->cfg.eps_chunk_log2, plan.subproblems_power));
@@ -1120,6 +1136,10 @@ int tb_session_plan(tb_session* s, tb_plan* plan_out) {
 int tb_session_export_peer(tb_session* s, tb_peer_handle* handle_out) {
   if (!s || !handle_out) return fail(TB_ERR_INVALID, "null argument");
   static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(tb_peer_handle), "tb_peer_handle is too small for hipIpcMemHandle_t");
+  // The kernels CAS / fetch_add the queue word and atomicMin the bound of this cell from other GPUs while kernels run here:
+  // that is only coherent in fine-grained memory.  Without it the cell is not handed out -- the callers fall back to the host
+  // relay with static shares (distributed.link_group, turbo -gpus).
+  if (!s->cell_fine_grained) return fail(TB_ERR_HIP, "this session's cell is not in fine-grained device memory (hipExtMallocWithFlags failed): it cannot be shared with other GPUs");
   HIP_TRY(hipSetDevice(s->cfg.device));
   hipIpcMemHandle_t h;
   HIP_TRY(hipIpcGetMemHandle(&h, s->cell));
@@ -1149,6 +1169,8 @@ int tb_session_link_peer(tb_session* s, tb_session* peer) {
   if (peer->P.world != s->P.world || peer->P.rank == s->P.rank) return fail(TB_ERR_INVALID, "the sessions do not belong to the same group");
   if (peer->plan.subproblems_power != s->plan.subproblems_power || peer->P.chunk_log2 != s->P.chunk_log2)
     return fail(TB_ERR_INVALID, "the sessions were planned with different subproblem counts: pass the same subproblems_power to every rank");
+  if (!s->cell_fine_grained || !peer->cell_fine_grained)
+    return fail(TB_ERR_HIP, "a session's cell is not in fine-grained device memory (hipExtMallocWithFlags failed): cross-GPU atomics on it would not be coherent");
   HIP_TRY(hipSetDevice(s->cfg.device));
   if (peer->cfg.device != s->cfg.device) {
     int can = 0;
@@ -1323,7 +1345,9 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
   HIP_TRY(hipMemcpy(bst.data(), s->P.g_stats, B * sizeof(BlockStats), hipMemcpyDeviceToHost));
   Ctrl c{};
   HIP_TRY(hipMemcpy(&c, s->P.ctrl, sizeof(c), hipMemcpyDeviceToHost));
-  if (c.error != 0) return fail(TB_ERR_DEPTH, "decision stack overflow: the search went deeper than " + std::to_string(s->plan.max_depth) + " decisions (tb_config.decision_stack_depth)");
+  if (c.error != 0) return fail(TB_ERR_DEPTH, "decision stack overflow: a workgroup went deeper than " + std::to_string((MAX_DEC_SEGS + 1) * (long long)s->plan.max_depth) +
+                                " decisions, or the pool of " + std::to_string(s->P.dec_pool_segments) + " extra segments of " + std::to_string(s->plan.max_depth) +
+                                " decisions ran out (tb_config.decision_stack_depth sets the segment size)");
 
   // reduce_blocks (barebones:1033-1067): sum the statistics, pick the winning workgroup.
   tb_stats st;

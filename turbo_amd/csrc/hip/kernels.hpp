@@ -33,6 +33,7 @@ namespace tb {
 #define TB_SYS __HIP_MEMORY_SCOPE_SYSTEM
 
 constexpr int MAX_WAVES = 16;          // 1024 threads
+constexpr int MAX_DEC_SEGS = 15;       // extra decision-stack segments a workgroup can take from the pool (16 x max_depth decisions in all)
 constexpr int NODE_BATCH = 32;         // nodes a workgroup explores between two updates of the node-wide node counter
 constexpr int WAVE_WATCHDOG_PERIOD = 1024;  // wave-local iterations between two looks at the deadline / abort flag
 
@@ -65,6 +66,8 @@ struct alignas(16) BlockShared {
   int sub_owner, sub_gen;      // rank whose share it belongs to; generation of the queue range it was fetched from
   int has_work, witness;       // witness: index of a propagator found un-entailed (fixpoint_event), -1 = none
   long long ticket;  // streaming: sequence number of the solution being handed to the host, -1 if none
+  Decision* dec_seg[MAX_DEC_SEGS];  // segments 1.. of this workgroup's decision stack (segment 0 is its slab in g_dec)
+  int n_dec_seg, pad_seg;
   unsigned long long red_key[MAX_WAVES];
   int red_first[MAX_WAVES];
   BlockStats bs;  // written by thread 0 only
@@ -939,11 +942,25 @@ __device__ __forceinline__ unsigned order_key(int var_order, const Itv d) {
   }
 }
 
+// Entry i of a workgroup's decision stack: segment 0 is the workgroup's slab, the others were taken from the pool when the
+// search went deeper (the reference reallocates its vector, barebones:401-403; here a segment is 16 384 decisions by default).
+__device__ __forceinline__ Decision& dec_at(const DevProblem& P, BlockShared& sh, Decision* dec, int i) {
+  const int k = i >> P.max_depth_log2;
+  return k == 0 ? dec[i] : sh.dec_seg[k - 1][i & (P.max_depth - 1)];
+}
+
 // Thread 0 only (barebones:355-405).
 template <bool C>
 __device__ __forceinline__ bool push_decision(const DevProblem& P, BlockShared& sh, Decision* dec, const int2* store, int val_order, int var) {
   const int depth = sh.depth;
-  if (depth + 1 >= P.max_depth) { __hip_atomic_store(&P.ctrl->error, 1, TB_RLX, TB_AGENT); return false; }
+  if (depth + 1 >= ((1 + sh.n_dec_seg) << P.max_depth_log2)) {  // grow: one more segment from the pool
+    bool grown = false;
+    if (sh.n_dec_seg < MAX_DEC_SEGS && P.dec_pool_segments > 0) {
+      const int idx = __hip_atomic_fetch_add(&P.ctrl->dec_pool_next, 1, TB_RLX, TB_AGENT);
+      if (idx < P.dec_pool_segments) { sh.dec_seg[sh.n_dec_seg++] = P.dec_pool + (size_t)idx * (size_t)P.max_depth; grown = true; }
+    }
+    if (!grown) { __hip_atomic_store(&P.ctrl->error, 1, TB_RLX, TB_AGENT); return false; }
+  }
   Decision d;
   const Itv dom = load_dom<C>(store, P.n_int, var);
   d.var = var;
@@ -956,8 +973,9 @@ __device__ __forceinline__ bool push_decision(const DevProblem& P, BlockShared& 
     default: d.child[0] = make_int2(mid + 1, dom.ub); d.child[1] = make_int2(dom.lb, mid); break;
   }
   d.rope[0] = depth + 1;
-  d.rope[1] = depth > 0 ? dec[depth - 1].rope[dec[depth - 1].cur] : -1;
-  dec[depth] = d;
+  if (depth > 0) { const Decision& up = dec_at(P, sh, dec, depth - 1); d.rope[1] = up.rope[up.cur]; }
+  else d.rope[1] = -1;
+  dec_at(P, sh, dec, depth) = d;
   sh.depth = depth + 1;
   return true;
 }
@@ -1059,6 +1077,8 @@ __device__ __forceinline__ void produce_solution(const DevProblem& P, BlockShare
 
 // ---- device <-> host / device <-> device words (thread 0 only) ---------------------------------------
 
+__device__ __forceinline__ void raise_gpu_stop(const DevProblem& P);
+
 struct Hot { int best, foreign, stop; unsigned next_poll; };
 // The 16 hot bytes of Ctrl: two 8-byte agent-scope loads (they bypass the non-coherent vector L1), one wait.
 __device__ __forceinline__ Hot load_hot(const Ctrl* c) {
@@ -1084,6 +1104,17 @@ __device__ __forceinline__ void poll_outside(const DevProblem& P, Mailbox* mbox,
   if (P.deadline_ticks != 0 && now > P.deadline_ticks) stop |= STOP_HOST;
   if (fb != PINF) (void)__hip_atomic_fetch_min(&c->foreign_bound, fb, TB_RLX, TB_AGENT);
   if (stop) (void)__hip_atomic_fetch_or(&c->stop, stop, TB_RLX, TB_AGENT);
+  if (P.cut_nodes_total != 0 && P.peers != nullptr) {
+    // node budget of the linked group: fold what this device explored since the last poll into rank 0's cell -- one system-scope
+    // atomic per device and poll period.  (fetch_max: two pollers overlapping in time fold disjoint parts.)
+    const unsigned long long mine = __hip_atomic_load(&c->nodes_local, TB_RLX, TB_AGENT);
+    const unsigned long long old = __hip_atomic_fetch_max(&c->nodes_folded, mine, TB_RLX, TB_AGENT);
+    PeerCell* root = P.peers[0] != nullptr ? P.peers[0] : me;
+    unsigned long long total;
+    if (mine > old) total = __hip_atomic_fetch_add(&root->nodes_total, mine - old, TB_RLX, TB_SYS) + (mine - old);
+    else total = __hip_atomic_load(&root->nodes_total, TB_RLX, TB_SYS);
+    if (total >= P.cut_nodes_total) raise_gpu_stop(P);
+  }
   // device -> host: the incumbent (two improvements may reach the host out of order; the refresh repairs it within
   // one period) and the remaining work
   __hip_atomic_store(&mbox->local_best, __hip_atomic_load(&c->best_bound, TB_RLX, TB_AGENT), TB_RLX, TB_SYS);
@@ -1128,27 +1159,45 @@ __device__ __forceinline__ void raise_gpu_stop(const DevProblem& P) {
 
 // Take the upper half of the fullest peer queue.  1: a range was installed, 0: nothing now (try again), -1: every
 // queue of the node is empty and nobody is moving work -- the search is over for this workgroup.
+// One workgroup of a device at a time (Ctrl::steal_lock, device-local).  PeerCell::stealing is raised only WHILE A RANGE IS IN
+// TRANSIT -- from just before the CAS that takes it out of the victim's queue until it is published in the thief's -- not while a
+// device merely looks around: idle devices scanning each other at the end of the search never see one another as busy.
 __device__ __forceinline__ int steal_work(const DevProblem& P, BlockStats& bs) {
   PeerCell* me = P.cell;
   int zero = 0;
-  if (!__hip_atomic_compare_exchange_strong(&me->stealing, &zero, 1, __ATOMIC_ACQUIRE, TB_RLX, TB_SYS)) return 0;  // a sibling is at it
+  if (!__hip_atomic_compare_exchange_strong(&P.ctrl->steal_lock, &zero, 1, __ATOMIC_ACQUIRE, TB_RLX, TB_AGENT)) return 0;  // a sibling is at it
   const unsigned long long mine = __hip_atomic_load(&me->queue, __ATOMIC_ACQUIRE, TB_SYS);
-  if (q_next(mine) < q_hi(mine)) { __hip_atomic_store(&me->stealing, 0, __ATOMIC_RELEASE, TB_SYS); return 1; }  // refilled meanwhile
+  if (q_next(mine) < q_hi(mine)) { __hip_atomic_store(&P.ctrl->steal_lock, 0, __ATOMIC_RELEASE, TB_AGENT); return 1; }  // refilled meanwhile
+  // Scan the peers: in-transit flags, then queues, then the flags again.  A peer that moves a range -- raises its flag, empties a
+  // third GPU's queue, publishes the range in its own, lowers the flag -- can slip between the reads of ONE pass (its own queue
+  // read before the range was published, its flag after it was lowered); "the node is out of work" therefore needs two
+  // consecutive passes that saw nothing.
   int best = -1;
   unsigned long long best_av = 0;
   bool busy = false;
-  for (int r = 0; r < P.world; ++r) {
-    PeerCell* pc = P.peers[r];
-    if (r == P.rank || pc == nullptr) continue;
-    const unsigned long long w = __hip_atomic_load(&pc->queue, TB_RLX, TB_SYS);
-    const unsigned long long av = q_hi(w) > q_next(w) ? q_hi(w) - q_next(w) : 0ull;
-    if (av > best_av) { best = r; best_av = av; }
-    if (av > 0 || __hip_atomic_load(&pc->stealing, TB_RLX, TB_SYS) != 0) busy = true;
+  for (int pass = 0; pass < 2 && !busy; ++pass) {
+    for (int r = 0; r < P.world; ++r) {
+      PeerCell* pc = P.peers[r];
+      if (r != P.rank && pc != nullptr && __hip_atomic_load(&pc->stealing, __ATOMIC_ACQUIRE, TB_SYS) != 0) busy = true;
+    }
+    for (int r = 0; r < P.world; ++r) {
+      PeerCell* pc = P.peers[r];
+      if (r == P.rank || pc == nullptr) continue;
+      const unsigned long long w = __hip_atomic_load(&pc->queue, __ATOMIC_ACQUIRE, TB_SYS);
+      const unsigned long long av = q_hi(w) > q_next(w) ? q_hi(w) - q_next(w) : 0ull;
+      if (av > best_av) { best = r; best_av = av; }
+      if (av > 0) busy = true;
+    }
+    for (int r = 0; r < P.world; ++r) {
+      PeerCell* pc = P.peers[r];
+      if (r != P.rank && pc != nullptr && __hip_atomic_load(&pc->stealing, __ATOMIC_ACQUIRE, TB_SYS) != 0) busy = true;
+    }
   }
   int result = busy ? 0 : -1;
   if (best >= 0) {
     PeerCell* v = P.peers[best];
     result = 0;
+    __hip_atomic_store(&me->stealing, 1, __ATOMIC_RELEASE, TB_SYS);  // visible before the victim's queue shrinks
     for (int tries = 0; tries < 8; ++tries) {
       unsigned long long w = __hip_atomic_load(&v->queue, __ATOMIC_ACQUIRE, TB_SYS);
       const unsigned long long nx = q_next(w), hi = q_hi(w);
@@ -1170,8 +1219,9 @@ __device__ __forceinline__ int steal_work(const DevProblem& P, BlockStats& bs) {
       result = 1;
       break;
     }
+    __hip_atomic_store(&me->stealing, 0, __ATOMIC_RELEASE, TB_SYS);
   }
-  __hip_atomic_store(&me->stealing, 0, __ATOMIC_RELEASE, TB_SYS);
+  __hip_atomic_store(&P.ctrl->steal_lock, 0, __ATOMIC_RELEASE, TB_AGENT);
   return result;
 }
 
@@ -1345,9 +1395,11 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
     // stopping conditions (barebones:1024-1029): one 16-byte look at the grid words per node; the mailbox and the peer
     // cell are polled on a wall-clock period by whichever workgroup notices that the poll is due
     bool must_stop = (P.cut_nodes != 0 && bs.nodes >= P.cut_nodes);
-    if (P.cut_nodes_total != 0 && (bs.nodes % NODE_BATCH) == 0) {  // the budget of the whole node, counted in rank 0's cell
-      PeerCell* root = (P.peers != nullptr && P.peers[0] != nullptr) ? P.peers[0] : P.cell;
-      if (__hip_atomic_fetch_add(&root->nodes_total, (unsigned long long)NODE_BATCH, TB_RLX, TB_SYS) + NODE_BATCH >= P.cut_nodes_total) raise_gpu_stop(P);
+    if (P.cut_nodes_total != 0 && (bs.nodes % NODE_BATCH) == 0) {
+      // the budget of the whole search: counted per device (agent scope); a single GPU (or one without linked peers, which was
+      // given its own share of the budget) checks its own count, linked GPUs are summed by their pollers (poll_outside)
+      const unsigned long long mine = __hip_atomic_fetch_add(&P.ctrl->nodes_local, (unsigned long long)NODE_BATCH, TB_RLX, TB_AGENT) + NODE_BATCH;
+      if (P.peers == nullptr && mine >= P.cut_nodes_total) raise_gpu_stop(P);
     }
     const Hot hot = load_hot(P.ctrl);
     maybe_poll(P, mbox, hot, t1);
@@ -1416,6 +1468,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     for (int i = 0; i < 32; ++i) bs.dbg[i] = 0;
     bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
     sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0;
+    sh.n_dec_seg = 0;
     sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; sh.witness = -1;
     t_start = t_mark = wall_clock64();
     sh.has_work = next_subproblem(P, sh, mbox) ? 1 : 0;
@@ -1502,7 +1555,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
           if (tid == 0) {
             if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; bs.why |= 2; }
             else {
-              Decision& dd = dec[sh.depth - 1];
+              Decision& dd = dec_at(P, sh, dec, sh.depth - 1);
               const int c = ++dd.cur;
               embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
             }
@@ -1513,7 +1566,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
         if (sh.leaf) {
           const int dcur = sh.depth;  // stable: last written before a barrier
           if (dcur == 0) break;
-          if (tid == 0) sh.new_depth = dec[dcur - 1].rope[dec[dcur - 1].cur];
+          if (tid == 0) { const Decision& dl = dec_at(P, sh, dec, dcur - 1); sh.new_depth = dl.rope[dl.cur]; }
           __syncthreads();
           const int depth = sh.new_depth;
           if (depth == -1) break;
@@ -1524,7 +1577,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
           // re-apply decisions[lvl .. depth-2].current(): distinct decisions may hit the same variable, the
           // atomic min/max make the order irrelevant (the reference loops to a fixpoint, barebones:839-851)
           for (int i = lvl + tid; i < depth - 1; i += blockDim.x) {
-            const Decision& di = dec[i];
+            const Decision& di = dec_at(P, sh, dec, i);
             const int2 ch = di.child[di.cur];
             raise_lb<C>(store, P.n_int, di.var, ch.x);
             lower_ub<C>(store, P.n_int, di.var, ch.y);
@@ -1532,7 +1585,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
           }
           __syncthreads();
           if (tid == 0) {
-            Decision& dd = dec[depth - 1];
+            Decision& dd = dec_at(P, sh, dec, depth - 1);
             const int c = ++dd.cur;
             embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
             sh.cur_strategy = sh.snap_strategy;

@@ -233,17 +233,50 @@ struct SolutionPrinter {
 };
 
 // N GPUs of the node (N >= 1): one session per device, this thread relays the incumbent bound and the stop flag and,
-// when streaming, prints the solutions as they arrive.
-int solve_sessions(const Options& o, const tb_config& base, const tf_model* m, std::vector<tb_itv>& best, int32_t* has, tb_stats* out, SolutionPrinter* printer) {
+// when streaming, prints the solutions as they arrive.  `segment` = tb_config.decision_stack_depth (0: the engine's default).
+int solve_sessions_once(const Options& o, const tb_config& base, const tf_model* m, int segment, std::vector<tb_itv>& best, int32_t* has, tb_stats* out, SolutionPrinter* printer) {
   const int G = std::max(1, o.gpus);
   std::vector<tb_session*> ss((size_t)G, nullptr);
   int rc = TB_OK;
-  for (int g = 0; g < G && rc == TB_OK; ++g) {
-    tb_config c = base;
-    c.device = o.devices[(size_t)g]; c.rank = g; c.world_size = G; c.deterministic = 0;
-    c.stream_solutions = printer ? 1 : 0;
-    rc = tb_session_create(&c, tf_num_vars(m), tf_store(m), tf_num_props(m), tf_props(m), tf_num_strategies(m), tf_strat_var_order(m),
-                           tf_strat_val_order(m), tf_strat_off(m), tf_strat_vars(m), tf_obj_var(m), &ss[(size_t)g]);
+  auto create_all = [&](int sub_power) {
+    for (int g = 0; g < G && rc == TB_OK; ++g) {
+      tb_config c = base;
+      c.device = o.devices[(size_t)g]; c.rank = g; c.world_size = G; c.deterministic = 0;
+      c.stream_solutions = printer ? 1 : 0;
+      c.decision_stack_depth = segment;
+      if (sub_power >= 0) c.subproblems_power = sub_power;
+      rc = tb_session_create(&c, tf_num_vars(m), tf_store(m), tf_num_props(m), tf_props(m), tf_num_strategies(m), tf_strat_var_order(m),
+                             tf_strat_val_order(m), tf_strat_off(m), tf_strat_vars(m), tf_obj_var(m), &ss[(size_t)g]);
+    }
+  };
+  create_all(-1);
+  // The block-cyclic shares only tile the 2^d index space if every rank planned the same d (and chunking): the sessions size
+  // themselves on their own device (free memory, occupancy), so compare -- and plan again with the largest d when they differ.
+  if (rc == TB_OK && G > 1) {
+    int dmin = 1 << 30, dmax = -1;
+    bool same_chunk = true;
+    tb_plan p0{};
+    for (int g = 0; g < G && rc == TB_OK; ++g) {
+      tb_plan pl{};
+      rc = tb_session_plan(ss[(size_t)g], &pl);
+      if (g == 0) p0 = pl;
+      dmin = std::min(dmin, pl.subproblems_power); dmax = std::max(dmax, pl.subproblems_power);
+      same_chunk = same_chunk && pl.eps_chunk_log2 == p0.eps_chunk_log2;
+    }
+    if (rc == TB_OK && (dmin != dmax || !same_chunk)) {
+      if (o.verbose) std::printf("%% The GPUs planned 2^%d .. 2^%d subproblems: planning again with 2^%d on every GPU.\n", dmin, dmax, dmax);
+      for (tb_session*& s : ss) { tb_session_destroy(s); s = nullptr; }
+      create_all(dmax);
+      for (int g = 0; g < G && rc == TB_OK; ++g) {
+        tb_plan pl{};
+        rc = tb_session_plan(ss[(size_t)g], &pl);
+        if (rc == TB_OK && (pl.subproblems_power != dmax || pl.eps_chunk_log2 != std::min(base.eps_chunk_log2, dmax))) {
+          std::cerr << "the GPUs of this search cannot agree on one subproblem count (2^" << pl.subproblems_power << " on GPU " << g << ", 2^" << dmax << " wanted)" << std::endl;
+          for (tb_session* s : ss) tb_session_destroy(s);
+          return TB_ERR_INVALID;
+        }
+      }
+    }
   }
   // The kernels exchange the incumbent bound and rebalance work among themselves over xGMI (include/turbo_hip.h:
   // tb_session_link_peer); without a peer path between two devices the relay below (poll / push_bound) carries the bound.
@@ -282,18 +315,37 @@ int solve_sessions(const Options& o, const tb_config& base, const tf_model* m, s
     if ((o.timeout_ms != 0 && el >= o.timeout_ms) || g_stop_flag || (printer && printer->satisfied())) for (int g = 0; g < G; ++g) tb_session_stop(ss[(size_t)g]);
     std::this_thread::sleep_for(std::chrono::microseconds(printer ? 200 : 500));
   }
+  // reduce_blocks across the GPUs (barebones:1033-1067): best bound; ties go to the lowest SUBPROBLEM INDEX -- with block-cyclic
+  // shares and work stealing the lowest rank does not hold the lowest indices
   bool first = true;
-  int32_t best_bound = TB_PINF;
+  int32_t best_bound = TB_PINF, best_sub = INT32_MAX;
+  *has = 0;
   for (int g = 0; g < G && rc == TB_OK; ++g) {
     tb_stats st;
     int32_t h = 0;
     rc = tb_session_finish(ss[(size_t)g], tmp.data(), &h, &st);
     if (rc != TB_OK) break;
-    if (h && (!*has || st.best_bound < best_bound)) { *has = 1; best_bound = st.best_bound; best = tmp; }  // ties: lowest rank = lowest subproblem slice
+    const int32_t sub = st.best_subproblem >= 0 ? st.best_subproblem : INT32_MAX;
+    if (h && (!*has || st.best_bound < best_bound || (st.best_bound == best_bound && sub < best_sub))) { *has = 1; best_bound = st.best_bound; best_sub = sub; best = tmp; }
     if (first) { *out = st; first = false; } else merge_stats(*out, st);
   }
   out->best_bound = best_bound;
+  out->best_subproblem = *has && best_sub != INT32_MAX ? best_sub : -1;
   for (tb_session* s : ss) tb_session_destroy(s);
+  return rc;
+}
+
+// The reference grows a block's decision stack on demand (barebones:401-403).  The engine does so in the kernel (segments from a
+// pool); a search that outgrows even that ends with TB_ERR_DEPTH and is run again with 8x larger segments, as tb_solve does.
+// (Not after solutions of a satisfaction problem were already printed: they would be printed twice.)
+int solve_sessions(const Options& o, const tb_config& base, const tf_model* m, std::vector<tb_itv>& best, int32_t* has, tb_stats* out, SolutionPrinter* printer) {
+  int segment = base.decision_stack_depth;
+  int rc = solve_sessions_once(o, base, m, segment, best, has, out, printer);
+  for (int depth = segment > 0 ? segment : 16384; rc == TB_ERR_DEPTH && depth < (1 << 22) && (!printer || printer->optimization || printer->printed == 0);) {
+    depth *= 8;
+    if (o.verbose) std::printf("%% A decision stack overflowed: searching again with segments of %d decisions.\n", depth);
+    rc = solve_sessions_once(o, base, m, depth, best, has, out, printer);
+  }
   return rc;
 }
 
@@ -330,7 +382,6 @@ int main(int argc, char** argv) {
     for (size_t b = 0, e; (e = lines.find('\n', b)) != std::string::npos; b = e + 1) std::printf("%%%%%%mzn-stat: %s\n", lines.substr(b, e - b).c_str());
   }
   p.s("abstract_domain", "pir_itv32_z");
-  p.s("entailed_prop_removal", (o.fixpoint == Fixpoint::EVENT || o.fixpoint == Fixpoint::AUTO || o.entailed_removal) ? "by_slice_entailment" : "deactivated");
   analyze_tcn(o, p, "tcn", m);
   if (!o.disable_simplify && !tf_trivially_unsat(m)) {
     std::string err_text;
@@ -356,6 +407,13 @@ int main(int argc, char** argv) {
     has_eps = true;
   }
   const int n_vars = tf_num_vars(m), n_props = tf_num_props(m);
+  {
+    // what the engine will run on this network (tb_config.fixpoint = 3 resolves to the event-driven fixpoint from 2048 propagators
+    // on, to WAC1 sweeps below: tb_plan.kernel_event / kernel_opt of the session): the event kernels always drop entailed slices,
+    // the sweeps only with -entailed_removal
+    const bool event = o.fixpoint == Fixpoint::EVENT || (o.fixpoint == Fixpoint::AUTO && n_props >= 2048);
+    p.s("entailed_prop_removal", (event || o.entailed_removal) ? "by_slice_entailment" : "deactivated");
+  }
   const int64_t preprocessing_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - start).count();
   p.d("preprocessing_time", to_sec(preprocessing_ns));
   p.end();

@@ -124,20 +124,24 @@ def exchange_until_done(session, dist=None, tensor_device="cpu", period_s: float
 
 
 def reduce_results(has_solution: bool, best_bound: int, stats: dict, dist=None, tensor_device="cpu"):
-    """End of search: min of bounds (ties -> lowest rank), sum of counters.
+    """End of search (reduce_blocks across ranks, barebones_dive_and_solve.hpp:1033-1067): the winner has the best bound; ties go to
+    the lowest SUBPROBLEM INDEX (`stats["best_subproblem"]`), then to the lowest rank -- with block-cyclic shares and work
+    stealing the lowest rank does not hold the lowest indices, and the canonical pass (`use_fixed_bound`) is only
+    deterministic if the lowest subproblem wins.  Counters are summed.
     Returns (winner_rank or -1, global_bound, summed_stats)."""
     keys = ["nodes", "fails", "solutions", "fixpoint_iterations", "num_deductions", "eps_solved_subproblems",
             "eps_skipped_subproblems", "num_blocks_done", "store_writes", "eps_stolen_subproblems"]
     if dist is None or dist.get_world_size() == 1:
         return (0 if has_solution else -1), (best_bound if has_solution else PINF), {k: stats.get(k, 0) for k in keys}
     import torch
-    rank, world = dist.get_rank(), dist.get_world_size()
-    # pack (bound, rank) so that MIN picks the best bound and, on ties, the lowest rank
-    key = ((int(best_bound) + 2**31) * world + rank) if has_solution else (2**62)
-    k = torch.tensor([key], dtype=torch.int64, device=tensor_device)
-    dist.all_reduce(k, op=dist.ReduceOp.MIN)
-    kmin = int(k.item())
-    winner, gbound = (-1, PINF) if kmin == 2**62 else (kmin % world, kmin // world - 2**31)
+    world = dist.get_world_size()
+    sub = int(stats.get("best_subproblem", -1))
+    mine = torch.tensor([1 if has_solution else 0, int(best_bound), sub if sub >= 0 else 2**62], dtype=torch.int64, device=tensor_device)
+    everyone = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    rows = [tuple(int(x) for x in t.tolist()) for t in everyone]
+    cands = [(b, sp, r) for r, (h, b, sp) in enumerate(rows) if h]
+    winner, gbound = (-1, PINF) if not cands else (min(cands)[2], min(cands)[0])
     s = torch.tensor([int(stats.get(x, 0)) for x in keys], dtype=torch.int64, device=tensor_device)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return winner, gbound, dict(zip(keys, (int(v) for v in s.tolist())))
