@@ -24,6 +24,27 @@
 #ifndef TB_EVENT_PREFETCH
 #define TB_EVENT_PREFETCH 0
 #endif
+// Which parts of an event kernel's node are functions of their own (bit 0: the fixpoint, bit 1: node bookkeeping, bit 2: variable
+// selection).  Measured on wordpress7_500: a call costs more than it saves here -- the callee-saved registers go through scratch
+// memory on every call and return (3.37e7 nodes/s inlined, 2.74e7 with all three outlined) -- so the default is 0.
+#ifndef TB_OUTLINE
+#define TB_OUTLINE 0
+#endif
+#if TB_OUTLINE & 1
+#define TB_FIX_ATTR __noinline__
+#else
+#define TB_FIX_ATTR __forceinline__
+#endif
+#if TB_OUTLINE & 2
+#define TB_NODE_ATTR __noinline__
+#else
+#define TB_NODE_ATTR __forceinline__
+#endif
+#if TB_OUTLINE & 4
+#define TB_SPLIT_ATTR __noinline__
+#else
+#define TB_SPLIT_ATTR __forceinline__
+#endif
 
 namespace tb {
 
@@ -53,13 +74,14 @@ struct Mailbox {
 
 // Workgroup control block, first bytes of the dynamic LDS segment.
 struct alignas(16) BlockShared {
+  int bot;        // VStore::is_bot
+  int abort;      // the watchdog fired (must follow `bot`: the hot loops read both with one 8-byte load, dead_node)
   int flag[3];    // "some domain changed during sweep k", rotating so one barrier per sweep is enough
   int unent[3];   // "some propagator is not entailed", computed in the same sweep
-  int bot;        // VStore::is_bot
   int leaf, stop, depth, remaining;
   int cur_strategy, next_unassigned, snap_strategy, snap_next_unassigned;
   int best_bound;  // best objective found by this workgroup (BlockData::best_bound, barebones:116)
-  int found, sol, skip, abort;
+  int found, sol, skip, pad_abort;
   int new_depth, ev_all, chg_count[2], ev_busy;  // event mode: "run every slice" request, change-list fill, waves running a slice
   unsigned long long sub_idx;  // global index of the current subproblem
   unsigned long long sub_j;    // its index in the local numbering of rank sub_owner (eps_global_index)
@@ -68,10 +90,16 @@ struct alignas(16) BlockShared {
   long long ticket;  // streaming: sequence number of the solution being handed to the host, -1 if none
   Decision* dec_seg[MAX_DEC_SEGS];  // segments 1.. of this workgroup's decision stack (segment 0 is its slab in g_dec)
   int n_dec_seg, pad_seg;
+  long long t_start, t_mark;  // thread 0's clocks (kernel start, last phase boundary): LDS, not registers that live through every loop
   unsigned long long red_key[MAX_WAVES];
   int red_first[MAX_WAVES];
   BlockStats bs;  // written by thread 0 only
 };
+
+__device__ __forceinline__ bool dead_node(const BlockShared& sh) {
+  static_assert(offsetof(BlockShared, abort) == offsetof(BlockShared, bot) + 4 && offsetof(BlockShared, bot) % 8 == 0, "bot and abort are read as one 8-byte word");
+  return __hip_atomic_load(reinterpret_cast<const long long*>(&sh.bot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0ll;
+}
 
 // Device-side tuning / profiling knobs (tb_config.reserved[0], see include/turbo_hip.h).  They sit in the hot loops,
 // so a production build compiles them out; build with -DTB_TUNING (make hip EXTRA_HIPFLAGS=-DTB_TUNING) for
@@ -81,6 +109,36 @@ __device__ __forceinline__ int knobs(const DevProblem& P) { return P.debug; }
 #else
 __device__ __forceinline__ constexpr int knobs(const DevProblem&) { return 0; }
 #endif
+
+// Tuning build: bits 8-15 of the knob word select ONE phase of the event kernels to execute twice (all of them are idempotent), so
+// that the difference in SQ_INSTS_VALU / SQ_INSTS_SALU to an undoubled run is that phase's instruction count
+// (scripts/phase_budget.py): 1 seeding from the change list, 2 round scan, 3 a whole slice run (fetch + dispatch + set-up + one
+// evaluation pass + the early-out of the marks), 4 witness test, 5 variable-selection scan, 6 restore copy, 7 dirty-bitmap clear,
+// 8 best-store copy.  (0x1: successor marks, 0x4: snapshot push, 0x8: one evaluation pass -- older knobs.)
+__device__ __forceinline__ int reps_of(const DevProblem& P, int phase) { return ((knobs(P) >> 8) & 0xff) == phase ? 2 : 1; }
+
+// LDS pointers across a call boundary: a pointer argument of a non-inlined function is GENERIC (flat_load / flat_atomic, both
+// counters, an aperture check per access) unless its address space travels with it.  The outlined functions below take 32-bit LDS
+// offsets and rebuild address-space-3 pointers, from which the compiler infers ds_* instructions for everything inlined under them.
+#define TB_LDS __attribute__((address_space(3)))
+template <class T> __device__ __forceinline__ unsigned lds_off(T* p) { return (unsigned)(size_t)(TB_LDS T*)p; }
+template <class T> __device__ __forceinline__ T* lds_ptr(unsigned off) { return (T*)(TB_LDS T*)(size_t)off; }
+// A pointer read from the problem description in memory is generic as well (flat_load: counted by vmcnt AND lgkmcnt, so every wait
+// for an LDS access also waits for the record fetch in flight).  glob() says "this one is global memory": global_load, vmcnt only.
+#define TB_GLB __attribute__((address_space(1)))
+#define TB_CST __attribute__((address_space(4)))
+// ... and the problem description itself is constant for the whole launch: through the constant address space its fields are
+// fetched with scalar loads (s_load_dword) where they are used, like kernel arguments.
+struct DevProblem;
+__device__ __forceinline__ const DevProblem& constant_problem(const DevProblem* p);
+template <class T> __device__ __forceinline__ T* glob(T* p) { return (T*)(TB_GLB T*)(size_t)p; }  // (through an integer: a generic -> global -> generic cast pair folds away)
+
+__device__ __forceinline__ const DevProblem& constant_problem(const DevProblem* p) { return *(const DevProblem*)(TB_CST const DevProblem*)(size_t)p; }
+
+// Wave votes straight on the lane mask a comparison leaves in an SGPR pair (HIP's __any / __ballot take an int: the bool is first
+// turned into 0/1 with a v_cndmask and compared again -- two VALU instructions per vote on an issue-bound kernel).
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 __device__ __forceinline__ int ld(const int* p) { return __hip_atomic_load(p, TB_RLX, TB_WG); }
 __device__ __forceinline__ void st(int* p, int v) { __hip_atomic_store(p, v, TB_RLX, TB_WG); }
@@ -133,9 +191,21 @@ __device__ __forceinline__ void lower_ub(int2* store, int ni, int v, int val) {
 
 // Per-thread counters kept in registers for the whole kernel and reduced once at the end.
 struct ThreadCounters {
-  unsigned long long writes = 0;      // narrowed bounds written
-  unsigned long long deductions = 0;  // deduce calls (per-wave counter held by lane 0, WAC1)
+  unsigned writes = 0;  // narrowed bounds written by this lane since the last flush (flush_writes)
 };
+// The propagation counters of a workgroup live in LDS (BlockShared::bs): a wave adds its evaluations with one DS atomic per
+// fixpoint call (lane 0), the per-lane write counters are folded in before they can wrap -- no 64-bit VALU arithmetic per run.
+__device__ __forceinline__ void add_deductions(BlockShared& sh, unsigned long long n) {
+  (void)__hip_atomic_fetch_add(&sh.bs.num_deductions, n, TB_RLX, TB_WG);
+}
+__device__ __forceinline__ void flush_writes(BlockShared& sh, ThreadCounters& tc, bool force) {
+  if (force || wave_any(tc.writes > (1u << 25))) {  // (64 lanes x 2^25 still fits the 32-bit wave sum)
+    unsigned w = tc.writes;
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
+    if ((threadIdx.x & 63) == 0) (void)__hip_atomic_fetch_add(&sh.bs.store_writes, (unsigned long long)w, TB_RLX, TB_WG);
+    tc.writes = 0;
+  }
+}
 
 // One propagator application: load 3 domains, evaluate, write the narrowed bounds.
 // `un` is only meaningful when the sweep it belongs to changed nothing.
@@ -168,7 +238,7 @@ __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store
     const bool ny = Z.ub < Y.ub, nz = Y.lb > Z.lb;                    // y.ub := z.ub, z.lb := y.lb
     const bool empty_in = (Y.lb > Y.ub) | (Z.lb > Z.ub);
     const bool touched = act & (ny | nz | empty_in);
-    if (__any(touched)) {
+    if (wave_any(touched)) {
       if (touched) {
         if (empty_in | (Y.lb > Z.ub)) st(bot, 1);                     // y.lb > new y.ub, or z.ub < new z.lb
         if (!empty_in) {
@@ -192,7 +262,7 @@ __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store
   const bool empty_in = (X.lb > X.ub) | (Y.lb > Y.ub) | (Z.lb > Z.ub);
   const bool cx = (c.xl > X.lb) | (c.xu < X.ub), cy = (c.yl > Y.lb) | (c.yu < Y.ub), cz = (c.zl > Z.lb) | (c.zu < Z.ub);
   const bool touched = act & (cx | cy | cz | empty_in);
-  if (__any(touched)) {  // wave-uniform: rare once the sweep is close to the fixpoint
+  if (wave_any(touched)) {  // wave-uniform: rare once the sweep is close to the fixpoint
     if (touched) {
       const int nxl = imax(c.xl, X.lb), nxu = imin(c.xu, X.ub);
       const int nyl = imax(c.yl, Y.lb), nyu = imin(c.yu, Y.ub);
@@ -260,7 +330,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
           apply<false, false>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
           ++wave_evals;  // iterations x active propagators (gpu_dive_and_solve.hpp:304-306)
           changed |= ch; un |= un_i;
-          if (!__any(ch) && !__any(un_i) && lane == 0) slice_unent[base >> 6] = 0;
+          if (!wave_any(ch) && !wave_any(un_i) && lane == 0) slice_unent[base >> 6] = 0;
           continue;
         }
         apply<false, false>(pr, act, store, P.n_int, &sh.bot, changed, un, tc, dbg);
@@ -278,9 +348,9 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
           bool ch = false, un_i = false;
           apply<false, false>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
           ++wave_evals;
-          if (!__any(ch)) {
+          if (!wave_any(ch)) {
             un |= un_i;
-            if (rm && !__any(un_i) && lane == 0) slice_unent[base >> 6] = 0;  // 1 -> 0 only: entailment is monotone below a node
+            if (rm && !wave_any(un_i) && lane == 0) slice_unent[base >> 6] = 0;  // 1 -> 0 only: entailment is monotone below a node
             break;
           }
           changed = true;
@@ -295,7 +365,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         }
       }
     }
-    const bool any_changed = __any(changed), any_un = __any(un);
+    const bool any_changed = wave_any(changed), any_un = wave_any(un);
     if (lane == 0) {
       if (any_changed) st(&sh.flag[k], 1);
       if (any_un) st(&sh.unent[k], 1);
@@ -309,10 +379,10 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     __syncthreads();
     ++it;
     if (force_sweeps) { if (it >= force_sweeps) break; else continue; }
-    if (!ld(&sh.flag[k]) || ld(&sh.bot) || ld(&sh.abort)) break;
+    if (!ld(&sh.flag[k]) || dead_node(sh)) break;
   }
-  if (!wac1 && !rm && tid == 0) tc.deductions += (unsigned long long)it * (unsigned long long)n;  // barebones:934
-  if (lane == 0) tc.deductions += 64ull * wave_evals;
+  if (!wac1 && !rm && tid == 0) add_deductions(sh, (unsigned long long)it * (unsigned long long)n);  // barebones:934
+  if (lane == 0 && wave_evals != 0) add_deductions(sh, 64ull * wave_evals);
   all_entailed = !ld(&sh.unent[k]);
   return it;
 }
@@ -361,12 +431,12 @@ __device__ __forceinline__ bool mark_packed(unsigned* dirty, unsigned packed, in
 // whatever the degree up to 11; returns true when the list is longer (mark_tail).
 __device__ __forceinline__ bool mark_var(const DevProblem& P, unsigned* dirty, int v, int self, int ev, int& deg_out, int& off_out, bool& did) {
   int4 a = make_int4(0, 0, 0, 0), b = a;
-  if (ev) { a = P.var_adj[2 * (size_t)v]; b = P.var_adj[2 * (size_t)v + 1]; }
+  if (ev) { a = glob(P.var_adj)[2 * (size_t)v]; b = glob(P.var_adj)[2 * (size_t)v + 1]; }
   const unsigned w[8] = {(unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w, (unsigned)b.x, (unsigned)b.y, (unsigned)b.z, (unsigned)b.w};
   const int deg = (int)(w[0] & 0xffffu);
 #pragma unroll
   for (int j = 0; j < 11; ++j) {
-    if (!__any(j < deg)) break;  // wave-uniform: most variables have four or five readers, not eleven
+    if (!wave_any(j < deg)) break;  // wave-uniform: most variables have four or five readers, not eleven
     const int hw = j + 1;
     const int t = (int)((hw & 1) ? (w[hw >> 1] >> 16) : (w[hw >> 1] & 0xffffu));
     if (j < deg && t != self && ((w[6] >> (2 * j)) & (unsigned)ev)) { mark_slice(dirty, t); did = true; }
@@ -384,7 +454,7 @@ __device__ __forceinline__ bool mark_tail(const DevProblem& P, unsigned* dirty, 
     mask &= mask - 1;
     const int d = __builtin_amdgcn_readlane(deg, l), o = __builtin_amdgcn_readlane(off, l), e = __builtin_amdgcn_readlane(ev, l);
     for (int j = lane; j < d - 11; j += 64) {
-      const int t = P.adj_rest[o + j];
+      const int t = glob(P.adj_rest)[o + j];
       if ((t & 0x3fffffff) != self && ((t >> 30) & e)) { mark_slice(dirty, t & 0x3fffffff); did = true; }
     }
   }
@@ -416,9 +486,9 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
     eval(ch, un_i, nar);
     ++wave_iters;
     nar_all |= nar;  // (a cooperative body reaches the slice's fixpoint in one pass: it narrows, reports nar and no change)
-    if (!__any(ch)) {
+    if (!wave_any(ch)) {
       // The byte only ever goes 1 -> 0 below a node (entailment is monotone).
-      if (!__any(un_i) && lane == 0) (void)__hip_atomic_fetch_and(&E.unent[s >> 5], ~(1u << (s & 31)), TB_RLX, TB_WG);
+      if (!wave_any(un_i) && lane == 0) (void)__hip_atomic_fetch_and(&E.unent[s >> 5], ~(1u << (s & 31)), TB_RLX, TB_WG);
       break;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -441,12 +511,12 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
 __device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* nxt, int s, const int4 pr, const int4 sc, int nar_all, int* census = nullptr) {
   const int priv = (pr.x >> 8) & 7;  // operands private to this slice are flagged at pack time
   int ex = (priv & 1) ? 0 : (nar_all & 3), ey = (priv & 2) ? 0 : ((nar_all >> 2) & 3), ez = (priv & 4) ? 0 : ((nar_all >> 4) & 3);
-  if (!__any((ex | ey | ez) != 0)) return false;
+  if (!wave_any((ex | ey | ez) != 0)) return false;
   bool did = false;
 #ifdef TB_TUNING
   if (census != nullptr) {  // knob 0x10000: runs with something to mark [12], lanes with something to mark [15], ... through the adjacency records [13] / lanes [16], ... with a tail [14]
-    const unsigned long long m0 = __ballot((ex | ey | ez) != 0);
-    const unsigned long long m1 = __ballot((ex & ((sc.w & 1) | ((sc.w >> 15) & 2))) || (ey & (((sc.w >> 1) & 1) | ((sc.w >> 16) & 2))) || (ez & (((sc.w >> 2) & 1) | ((sc.w >> 17) & 2))));
+    const unsigned long long m0 = wave_ballot((ex | ey | ez) != 0);
+    const unsigned long long m1 = wave_ballot((ex & ((sc.w & 1) | ((sc.w >> 15) & 2))) || (ey & (((sc.w >> 1) & 1) | ((sc.w >> 16) & 2))) || (ez & (((sc.w >> 2) & 1) | ((sc.w >> 17) & 2))));
     if ((threadIdx.x & 63) == 0) { census[12] += 1; census[15] += __builtin_popcountll(m0); if (m1) { census[13] += 1; census[16] += __builtin_popcountll(m1); } }
   }
 #endif
@@ -456,11 +526,11 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* n
   if (ey & ~ovy) did |= mark_packed(nxt, (unsigned)sc.y, sc.w >> 8, ey & ~ovy);
   if (ez & ~ovz) did |= mark_packed(nxt, (unsigned)sc.z, sc.w >> 12, ez & ~ovz);
   ex &= ovx; ey &= ovy; ez &= ovz;
-  if (__any((ex | ey | ez) != 0)) {
+  if (wave_any((ex | ey | ez) != 0)) {
 #ifdef TB_TUNING
     const long long t_var = census != nullptr ? clock64() : 0;  // [21]: time in this branch; [22], [23]: lanes marking their x / their y or z through it
     if (census != nullptr) {
-      const unsigned long long lx = __ballot(ex != 0), lyz = __ballot((ey | ez) != 0);
+      const unsigned long long lx = wave_ballot(ex != 0), lyz = wave_ballot((ey | ez) != 0);
       if ((threadIdx.x & 63) == 0) { census[22] += __builtin_popcountll(lx); census[23] += __builtin_popcountll(lyz); }
     }
 #endif
@@ -468,7 +538,7 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* n
     const bool tx = mark_var(P, nxt, pr.y, s, ex, dx, ox, did);
     const bool ty = mark_var(P, nxt, pr.z, s, ey, dy, oy, did);
     const bool tz = mark_var(P, nxt, pr.w, s, ez, dz, oz, did);
-    const unsigned long long mx = __ballot(tx), my = __ballot(ty), mz = __ballot(tz);
+    const unsigned long long mx = wave_ballot(tx), my = wave_ballot(ty), mz = wave_ballot(tz);
     bool dt = false;
 #ifdef TB_TUNING
     if (census != nullptr) {  // degree histogram of the variables marked through their adjacency record: <= 4 [17], 5-6 [18], 7-11 [19], more [20]
@@ -486,7 +556,7 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* n
     if (census != nullptr) { const long long t_ = clock64(); if ((threadIdx.x & 63) == 0) census[21] += (int)((t_ - t_var) >> 4); }
 #endif
   }
-  return __any(did);
+  return wave_any(did);
 }
 
 // A 2-bit Boolean of the COMPACT layout as an LDS word address and a bit position (computed once per run).
@@ -557,6 +627,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     }
     if (root_pass) for (int i = tid; i < W; i += T) ubits[i] = bm0[i];  // nothing is known to be entailed yet (every valid bit set)
   } else {
+    for (int rep = reps_of(P, 1); rep > 0; --rep)
     for (int e0 = wave * 64; e0 < cnt; e0 += T) {  // one lane per entry; long lists are finished cooperatively
       const int e = e0 + lane;
       const int entry = e < cnt ? es.list[e] : 0;
@@ -564,7 +635,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       int deg = 0, off = 0;
       bool did = false;
       const bool more = mark_var(P, bm0, entry & 0x3fffffff, -1, ev, deg, off, did);
-      const unsigned long long mm = __ballot(more);
+      const unsigned long long mm = wave_ballot(more);
       if (mm) (void)mark_tail(P, bm0, mm, deg, off, ev, -1);
     }
   }
@@ -586,6 +657,17 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     unsigned* cur = es.dirty + (rounds & 1) * W;
     unsigned* nxt = es.dirty + ((rounds + 1) & 1) * W;
     bool marked = false;  // wave-uniform: this wave marked something for the next round
+#ifdef TB_TUNING
+    if (reps_of(P, 2) > 1)
+      for (int base = 0; base < W; base += 64) {  // the scan once more, without clearing anything
+        const int wi = base + lane;
+        unsigned w = wi < W ? (__hip_atomic_load(&cur[wi], TB_RLX, TB_WG) & own) : 0u;
+        if (w != 0) (void)__hip_atomic_fetch_and(&cur[wi], ~0u, TB_RLX, TB_WG);
+        if (drop_entailed && w != 0) w &= __hip_atomic_load(&ubits[wi], TB_RLX, TB_WG);
+        unsigned long long nz = wave_ballot(w != 0);
+        asm volatile("" :: "s"(nz));
+      }
+#endif
     for (int base = 0; base < W; base += 64) {
       const int wi = base + lane;
       unsigned w = wi < W ? (__hip_atomic_load(&cur[wi], TB_RLX, TB_WG) & own) : 0u;
@@ -593,7 +675,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       // entailed-slice removal: a slice whose 64 propagators were all entailed when it last ran is not even looked at
       if (drop_entailed && w != 0) w &= __hip_atomic_load(&ubits[wi], TB_RLX, TB_WG);
       // my slices of this round, one after the other
-      unsigned long long nz = __ballot(w != 0);
+      unsigned long long nz = wave_ballot(w != 0);
       unsigned word = 0;
       int wl = 0;
       auto next_slice = [&]() -> int {  // wave-uniform iteration over the set bits of the words held by the lanes
@@ -610,13 +692,13 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       int s = next_slice();
 #if TB_EVENT_PREFETCH
       int4 pr_c = idle_record(), sc_c = make_int4(0, 0, 0, 0);
-      if (s >= 0) { pr_c = props[s * 64 + lane]; sc_c = P.succ[s * 64 + lane]; }
+      if (s >= 0) { pr_c = props[s * 64 + lane]; sc_c = glob(P.succ)[s * 64 + lane]; }
 #endif
       while (s >= 0) {
         const int s_next = next_slice();
 #if TB_EVENT_PREFETCH
         const int sp = s_next >= 0 ? s_next : s;
-        const int4 pr_n = props[sp * 64 + lane], sc_n = P.succ[sp * 64 + lane];
+        const int4 pr_n = props[sp * 64 + lane], sc_n = glob(P.succ)[sp * 64 + lane];
 #endif
         // (no software prefetch of the next slice's records: under the 80-register budget of this kernel the prefetched
         //  int4 lived in scratch, and the round trip cost more than the L2 latency it hid -- 15.3 -> 19.3e6 nodes/s without it)
@@ -625,8 +707,13 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
 #else
         const int4 pr = props[s * 64 + lane];  // the arrays are padded to whole slices
 #endif
-        if (ld(&sh.bot) | ld(&sh.abort)) break;  // the node failed in another wave
-        {
+        if (dead_node(sh)) break;  // the node failed in another wave
+        for (int rep = reps_of(P, 3); rep > 0; --rep) {
+#ifdef TB_TUNING
+          int4 pr_again = pr;
+          if (rep == 1 && reps_of(P, 3) > 1) { const int4* pp = props + (s * 64 + lane); asm volatile("" : "+v"(pp)); pr_again = *pp; if (dead_node(sh)) break; }
+#define pr pr_again
+#endif
           // (classes start on slice boundaries: a slice may end with idle padding -- records whose word0 carries no class set)
           const bool act = ((unsigned)pr.x >> 16) != 0u;
           const RunEnv E{P, sh, nxt, ubits, s};
@@ -637,7 +724,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
 #if TB_EVENT_PREFETCH
           const int4 sc = sc_c;
 #else
-          const int4 sc = P.succ[s * 64 + lane];  // needed after the run only: the load hides behind it
+          const int4 sc = glob(P.succ)[s * 64 + lane];  // needed after the run only: the load hides behind it
 #endif
           TB_PROF_MARK(0);
           if (C && key == KEY_LEQT_BB) {
@@ -648,7 +735,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               const unsigned yb = bool_bits(ry), zb = bool_bits(rz);
               const bool ny = (zb & 2u) && !(yb & 2u), nz = (yb & 1u) && !(zb & 1u);
               const bool empty_in = yb == 3u || zb == 3u;
-              if (__any(act & (ny | nz | empty_in))) {
+              if (wave_any(act & (ny | nz | empty_in))) {
                 if (act) {
                   if (empty_in | ((yb & 1u) && (zb & 2u))) st(&sh.bot, 1);
                   if (!empty_in) {
@@ -689,13 +776,13 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               const Itv Y = load_dom<false>(store, P.n_int, yv);
               const bool t = act && (xb & 1u), f = act && (xb & 2u), u = act && xb == 0u;
               int lb = Y.lb, ub = Y.ub;
-              for (unsigned long long tm = __ballot(t); tm; tm &= tm - 1) {  // y = k for every true b (normally at most one per group)
+              for (unsigned long long tm = wave_ballot(t); tm; tm &= tm - 1) {  // y = k for every true b (normally at most one per group)
                 const int l = __builtin_ctzll(tm);
                 const int k = __builtin_amdgcn_readlane(kc, l);
                 if ((gmask >> l) & 1ull) { lb = lb > k ? lb : k; ub = ub < k ? ub : k; }
               }
               if (dense) {
-                const unsigned long long fm = __ballot(f) & gmask;
+                const unsigned long long fm = wave_ballot(f) & gmask;
                 if (lb <= ub && lb >= k0 && lb <= k_last) {
                   const unsigned long long open_up = ~(fm >> (g_start + (lb - k0)));  // first lane from lb's upwards whose b is not false
                   lb += open_up ? __builtin_ctzll(open_up) : 64;
@@ -706,15 +793,15 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                 }
               } else {
                 for (;;) {  // excluded values on the bounds, one step at a time, every group at its own pace
-                  const unsigned long long ml = __ballot(f && kc == lb), mu = __ballot(f && kc == ub);
+                  const unsigned long long ml = wave_ballot(f && kc == lb), mu = wave_ballot(f && kc == ub);
                   const bool live = lb <= ub;
                   const bool al = live && (ml & gmask) != 0ull, au = live && (mu & gmask) != 0ull;
-                  if (!__any(al | au)) break;
+                  if (!wave_any(al | au)) break;
                   if (al) lb = sat_add(lb, 1);
                   if (au) ub = sat_sub(ub, 1);
                 }
               }
-              const bool bad = __any(act && (xb == 3u || lb > ub));
+              const bool bad = wave_any(act && (xb == 3u || lb > ub));
               un_i = act;
               if (!bad) {
                 const bool outside = kc < lb || kc > ub, hit = lb == ub && kc == lb;
@@ -771,7 +858,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                 ent = (t && le) || (f && gt);
               }
               const bool cyl = nyl != Y.lb, cyu = nyu != Y.ub;
-              if (__any(act & (set1 | set0 | cyl | cyu | empty_in))) {
+              if (wave_any(act & (set1 | set0 | cyl | cyu | empty_in))) {
                 if (act) {
                   if (empty_in | (nyl > nyu)) st(&sh.bot, 1);  // (a narrowed constant is an empty y: same condition)
                   if (!empty_in) {
@@ -813,9 +900,12 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             const int want = (knobs(P) >> 28) & 15;
             const unsigned cm = key & CLASS_SET_MASK;
             const int cls_of_slice = (cm & (cm - 1)) ? 10 : __builtin_ctz(cm | 0x400u);
-            const bool useless = !__any(nar_all != 0);  // the run narrowed nothing
-            if ((want == 0 || want - 1 == cls_of_slice) && (!(knobs(P) & 0x40) || useless)) wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;  // 0x40: only the runs that narrowed nothing
+            const bool useless = !wave_any(nar_all != 0);  // the run narrowed nothing
+            if (rep == reps_of(P, 3) && (want == 0 || want - 1 == cls_of_slice) && (!(knobs(P) & 0x40) || useless)) wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;  // 0x40: only the runs that narrowed nothing
           }
+#ifdef TB_TUNING
+#undef pr
+#endif
         }
 #if TB_EVENT_PREFETCH
         pr_c = pr_n; sc_c = sc_n;
@@ -831,12 +921,13 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     __syncthreads();  // the narrowings and the marks of this round are visible to everybody
     TB_PROF_MARK(3);
     TB_PROF_COUNT(5);
-    if (!ld(&sh.flag[k]) || ld(&sh.bot) || ld(&sh.abort)) break;
+    if (!ld(&sh.flag[k]) || dead_node(sh)) break;
   }
-  if (lane == 0) tc.deductions += 64ull * wave_iters_total;
+  if (lane == 0 && wave_iters_total != 0) add_deductions(sh, 64ull * wave_iters_total);
   if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += t - tp0; tp0 = t; }  // profiling: rounds
   // leave both bitmaps empty for the next node (they are not after a failure)
-  for (int i = tid; i < 2 * W; i += T) es.dirty[i] = 0;
+  for (int rep = reps_of(P, 7); rep > 0; --rep)
+  for (int i = tid; i < 2 * W; i += T) __hip_atomic_store(&es.dirty[i], 0u, TB_RLX, TB_WG);
   // ---- is every propagator entailed (the node is a solution, barebones:971-993)?
   // A byte says "some propagator of the slice was not entailed when the slice last ran".  With event filtering a slice may
   // sleep through a narrowing that cannot make it propagate but can make it entailed (`b1 <= b2` once b1 is false), so a
@@ -844,21 +935,22 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   // WITNESS (BlockShared::witness, a propagator index) and wave 0 re-evaluates just that one -- the common case, no scan of
   // the bytes at all.  When the witness has become entailed, the slices whose byte is set are examined one by one (their
   // byte is corrected on the way) until a new witness turns up or none is left.
-  if (wave == 0 && !ld(&sh.bot) && !ld(&sh.abort)) {
+  if (wave == 0 && !dead_node(sh)) {
     auto unentailed_lanes = [&](int first_prop, bool whole_slice) -> unsigned long long {  // wave-uniform result
       const int i = whole_slice ? first_prop + lane : first_prop;
       const bool act = i < n;
       const int4 pr = props[act ? i : 0];
       const Itv X = load_dom<C>(store, P.n_int, pr.y), Y = load_dom<C>(store, P.n_int, pr.z), Z = load_dom<C>(store, P.n_int, pr.w);
       const Cand c = evaluate_single(pr.x, X, Y, Z);
-      return __ballot(act && !c.ent);
+      return wave_ballot(act && !c.ent);
     };
     int wit = __builtin_amdgcn_readfirstlane(ld(&sh.witness));
+    if (reps_of(P, 4) > 1 && wit >= 0) { const unsigned long long again = unentailed_lanes(wit, false); asm volatile("" :: "s"(again)); }
     bool confirmed = wit >= 0 && unentailed_lanes(wit, false) != 0;
     for (int base = 0; !confirmed && base < W; base += 64) {
       const int wi = base + lane;
       const unsigned word = wi < W ? __hip_atomic_load(&ubits[wi], TB_RLX, TB_WG) : 0u;
-      for (unsigned long long m = __ballot(word != 0); m && !confirmed; m &= m - 1) {
+      for (unsigned long long m = wave_ballot(word != 0); m && !confirmed; m &= m - 1) {
         const int wl = __builtin_ctzll(m);
         for (unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)word, wl); bits && !confirmed; bits &= bits - 1) {
           const int sl = (base + wl) * 32 + __builtin_ctz(bits);
@@ -873,6 +965,31 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   __syncthreads();
   all_entailed = !ld(&sh.unent[0]);
   return rounds + 1;
+}
+
+// The event fixpoint as a function of its own: its registers are allocated for ITS loops, not for everything the persistent
+// search loop keeps alive around it.
+struct FpResult { int rounds; int all_entailed; unsigned writes; };
+// SL: the store (and the entailment bits behind it) lives in LDS, `store_ref` is then its LDS offset; otherwise the store is the
+// workgroup's slab in global memory and `gstore` points to it.
+template <bool C, int MEM>
+static __device__ TB_FIX_ATTR FpResult fixpoint_event_call(const DevProblem* Pp, unsigned sh_off, unsigned store_off, int2* gstore, unsigned props_off, const int4* gprops,
+                                                     unsigned dirty_off, unsigned list_off, unsigned writes_in) {
+  BlockShared& sh = *lds_ptr<BlockShared>(sh_off);
+  int2* store = MEM >= TB_MEM_STORE_SHARED ? lds_ptr<int2>(store_off) : glob(gstore);
+  const int4* props = MEM == TB_MEM_TCN_SHARED ? lds_ptr<const int4>(props_off) : glob(gprops);
+  EventState es;
+  es.dirty = lds_ptr<unsigned>(dirty_off); es.list = lds_ptr<int>(list_off);
+  es.unent = reinterpret_cast<unsigned char*>(store) + constant_problem(Pp).unent_off;
+  es.words = constant_problem(Pp).dirty_words; es.cap = constant_problem(Pp).chg_cap;
+  ThreadCounters tc;
+  tc.writes = writes_in;
+  bool ae = false;
+  FpResult r;
+  r.rounds = fixpoint_event<C>(constant_problem(Pp), sh, store, props, es, tc, ae);
+  r.all_entailed = ae ? 1 : 0;
+  r.writes = tc.writes;
+  return r;
 }
 
 // ---- small helpers -------------------------------------------------------------------------------
@@ -956,10 +1073,10 @@ __device__ __forceinline__ bool push_decision(const DevProblem& P, BlockShared& 
   if (depth + 1 >= ((1 + sh.n_dec_seg) << P.max_depth_log2)) {  // grow: one more segment from the pool
     bool grown = false;
     if (sh.n_dec_seg < MAX_DEC_SEGS && P.dec_pool_segments > 0) {
-      const int idx = __hip_atomic_fetch_add(&P.ctrl->dec_pool_next, 1, TB_RLX, TB_AGENT);
+      const int idx = __hip_atomic_fetch_add(&glob(P.ctrl)->dec_pool_next, 1, TB_RLX, TB_AGENT);
       if (idx < P.dec_pool_segments) { sh.dec_seg[sh.n_dec_seg++] = P.dec_pool + (size_t)idx * (size_t)P.max_depth; grown = true; }
     }
-    if (!grown) { __hip_atomic_store(&P.ctrl->error, 1, TB_RLX, TB_AGENT); return false; }
+    if (!grown) { __hip_atomic_store(&glob(P.ctrl)->error, 1, TB_RLX, TB_AGENT); return false; }
   }
   Decision d;
   const Itv dom = load_dom<C>(store, P.n_int, var);
@@ -990,13 +1107,15 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
   for (;;) {
     const int s = sh.cur_strategy;  // uniform: read after a barrier
     if (s >= P.n_strats) { if (tid == 0) sh.found = 0; __syncthreads(); return; }
-    const int off = P.strat_off[s];
-    int n = P.strat_off[s + 1] - off;
+    const int off = glob(P.strat_off)[s];
+    int n = glob(P.strat_off)[s + 1] - off;
     const bool in_store = (n == 0);
     if (in_store) n = P.n_vars;
-    const int vo = P.strat_var_order[s];
+    const int vo = glob(P.strat_var_order)[s];
     unsigned long long best = ~0ull;
     int first = n;
+    for (int rep = reps_of(P, 5); rep > 0; --rep) {
+    best = ~0ull; first = n;
     // four candidates per thread and round: the index gathers, then the domain gathers, are issued together
     // (a store in global memory costs one L2 round trip per dependent load, not per variable)
     for (int i0 = sh.next_unassigned + tid; i0 < n; i0 += 4 * T) {
@@ -1005,7 +1124,7 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int i = i0 + k * T;
-        v[k] = i < n ? (in_store ? i : P.strat_vars[off + i]) : -1;
+        v[k] = i < n ? (in_store ? i : glob(P.strat_vars)[off + i]) : -1;
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -1026,6 +1145,8 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
     first = wave_min_i32(first);
     if (lane == 0) { sh.red_key[wave] = best; sh.red_first[wave] = first; }
     __syncthreads();
+    if (rep > 1) __syncthreads();  // (tuning: the scan is about to run again and rewrite red_key)
+    }
     if (tid == 0) {
       for (int w = 1; w < nw; ++w) {
         best = sh.red_key[w] < best ? sh.red_key[w] : best;
@@ -1034,8 +1155,8 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
       sh.next_unassigned = first;
       if (best != ~0ull) {
         const int i = (int)(best & 0xffffffffu);
-        const int v = in_store ? i : P.strat_vars[off + i];
-        sh.found = push_decision<C>(P, sh, dec, store, P.strat_val_order[s], v) ? 1 : 0;
+        const int v = in_store ? i : glob(P.strat_vars)[off + i];
+        sh.found = push_decision<C>(P, sh, dec, store, glob(P.strat_val_order)[s], v) ? 1 : 0;
         if (!sh.found) sh.stop = 1;
         sh.skip = 1;  // leave the strategy loop
       } else {
@@ -1059,7 +1180,7 @@ __device__ __forceinline__ void produce_solution(const DevProblem& P, BlockShare
   if (tid == 0) {
     // wait for a free slot; a stop request (host or device) drops the solution: nobody is listening any more
     while (ticket - __hip_atomic_load(r.consumed, __ATOMIC_ACQUIRE, TB_SYS) >= (unsigned long long)r.slots) {
-      if (__hip_atomic_load(&mbox->stop, TB_RLX, TB_SYS) != 0 || __hip_atomic_load(&P.ctrl->stop, TB_RLX, TB_AGENT) != 0 ||
+      if (__hip_atomic_load(&mbox->stop, TB_RLX, TB_SYS) != 0 || __hip_atomic_load(&glob(P.ctrl)->stop, TB_RLX, TB_AGENT) != 0 ||
           (P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks)) { sh.ticket = -1; break; }
       __builtin_amdgcn_s_sleep(64);
     }
@@ -1094,8 +1215,8 @@ __device__ __forceinline__ Hot load_hot(const Ctrl* c) {
 // device's peer cell (incumbent and stop raised by the other GPUs over xGMI).  Time based: whoever notices that the
 // poll is due and wins the CAS on Ctrl::next_poll does it, every other workgroup goes on.
 __device__ __forceinline__ void poll_outside(const DevProblem& P, Mailbox* mbox, long long now) {
-  Ctrl* c = P.ctrl;
-  PeerCell* me = P.cell;
+  Ctrl* c = glob(P.ctrl);
+  PeerCell* me = glob(P.cell);
   int stop = __hip_atomic_load(&mbox->stop, TB_RLX, TB_SYS) != 0 ? STOP_HOST : 0;
   int fb = __hip_atomic_load(&mbox->foreign_bound, TB_RLX, TB_SYS);
   const int cb = __hip_atomic_load(&me->bound, TB_RLX, TB_SYS);
@@ -1109,7 +1230,7 @@ __device__ __forceinline__ void poll_outside(const DevProblem& P, Mailbox* mbox,
     // atomic per device and poll period.  (fetch_max: two pollers overlapping in time fold disjoint parts.)
     const unsigned long long mine = __hip_atomic_load(&c->nodes_local, TB_RLX, TB_AGENT);
     const unsigned long long old = __hip_atomic_fetch_max(&c->nodes_folded, mine, TB_RLX, TB_AGENT);
-    PeerCell* root = P.peers[0] != nullptr ? P.peers[0] : me;
+    PeerCell* root = glob(P.peers)[0] != nullptr ? glob(glob(P.peers)[0]) : me;
     unsigned long long total;
     if (mine > old) total = __hip_atomic_fetch_add(&root->nodes_total, mine - old, TB_RLX, TB_SYS) + (mine - old);
     else total = __hip_atomic_load(&root->nodes_total, TB_RLX, TB_SYS);
@@ -1124,7 +1245,7 @@ __device__ __forceinline__ void poll_outside(const DevProblem& P, Mailbox* mbox,
 __device__ __forceinline__ void maybe_poll(const DevProblem& P, Mailbox* mbox, const Hot& h, long long now) {
   if ((int)((unsigned)now - h.next_poll) >= 0) {
     unsigned expect = h.next_poll;
-    if (__hip_atomic_compare_exchange_strong(&P.ctrl->next_poll, &expect, (unsigned)now + (unsigned)P.poll_ticks, TB_RLX, TB_RLX, TB_AGENT))
+    if (__hip_atomic_compare_exchange_strong(&glob(P.ctrl)->next_poll, &expect, (unsigned)now + (unsigned)P.poll_ticks, TB_RLX, TB_RLX, TB_AGENT))
       poll_outside(P, mbox, now);
   }
 }
@@ -1135,16 +1256,16 @@ __device__ __forceinline__ void publish_bound(const DevProblem& P, Mailbox* mbox
   __hip_atomic_store(&mbox->local_best, obj, TB_RLX, TB_SYS);
   if (P.peers != nullptr)
     for (int r = 0; r < P.world; ++r) {
-      PeerCell* pc = P.peers[r];
+      PeerCell* pc = glob(glob(P.peers)[r]);
       if (r != P.rank && pc != nullptr) (void)__hip_atomic_fetch_min(&pc->bound, obj, TB_RLX, TB_SYS);
     }
 }
 // Solution limit reached / objective unbounded: every GPU stops.
 __device__ __forceinline__ void raise_gpu_stop(const DevProblem& P) {
-  (void)__hip_atomic_fetch_or(&P.ctrl->stop, STOP_GPU, TB_RLX, TB_AGENT);
+  (void)__hip_atomic_fetch_or(&glob(P.ctrl)->stop, STOP_GPU, TB_RLX, TB_AGENT);
   if (P.peers != nullptr)
     for (int r = 0; r < P.world; ++r) {
-      PeerCell* pc = P.peers[r];
+      PeerCell* pc = glob(glob(P.peers)[r]);
       if (r != P.rank && pc != nullptr) __hip_atomic_store(&pc->stop, 1, TB_RLX, TB_SYS);
     }
 }
@@ -1163,11 +1284,11 @@ __device__ __forceinline__ void raise_gpu_stop(const DevProblem& P) {
 // TRANSIT -- from just before the CAS that takes it out of the victim's queue until it is published in the thief's -- not while a
 // device merely looks around: idle devices scanning each other at the end of the search never see one another as busy.
 __device__ __forceinline__ int steal_work(const DevProblem& P, BlockStats& bs) {
-  PeerCell* me = P.cell;
+  PeerCell* me = glob(P.cell);
   int zero = 0;
-  if (!__hip_atomic_compare_exchange_strong(&P.ctrl->steal_lock, &zero, 1, __ATOMIC_ACQUIRE, TB_RLX, TB_AGENT)) return 0;  // a sibling is at it
+  if (!__hip_atomic_compare_exchange_strong(&glob(P.ctrl)->steal_lock, &zero, 1, __ATOMIC_ACQUIRE, TB_RLX, TB_AGENT)) return 0;  // a sibling is at it
   const unsigned long long mine = __hip_atomic_load(&me->queue, __ATOMIC_ACQUIRE, TB_SYS);
-  if (q_next(mine) < q_hi(mine)) { __hip_atomic_store(&P.ctrl->steal_lock, 0, __ATOMIC_RELEASE, TB_AGENT); return 1; }  // refilled meanwhile
+  if (q_next(mine) < q_hi(mine)) { __hip_atomic_store(&glob(P.ctrl)->steal_lock, 0, __ATOMIC_RELEASE, TB_AGENT); return 1; }  // refilled meanwhile
   // Scan the peers: in-transit flags, then queues, then the flags again.  A peer that moves a range -- raises its flag, empties a
   // third GPU's queue, publishes the range in its own, lowers the flag -- can slip between the reads of ONE pass (its own queue
   // read before the range was published, its flag after it was lowered); "the node is out of work" therefore needs two
@@ -1177,11 +1298,11 @@ __device__ __forceinline__ int steal_work(const DevProblem& P, BlockStats& bs) {
   bool busy = false;
   for (int pass = 0; pass < 2 && !busy; ++pass) {
     for (int r = 0; r < P.world; ++r) {
-      PeerCell* pc = P.peers[r];
+      PeerCell* pc = glob(glob(P.peers)[r]);
       if (r != P.rank && pc != nullptr && __hip_atomic_load(&pc->stealing, __ATOMIC_ACQUIRE, TB_SYS) != 0) busy = true;
     }
     for (int r = 0; r < P.world; ++r) {
-      PeerCell* pc = P.peers[r];
+      PeerCell* pc = glob(glob(P.peers)[r]);
       if (r == P.rank || pc == nullptr) continue;
       const unsigned long long w = __hip_atomic_load(&pc->queue, __ATOMIC_ACQUIRE, TB_SYS);
       const unsigned long long av = q_hi(w) > q_next(w) ? q_hi(w) - q_next(w) : 0ull;
@@ -1189,13 +1310,13 @@ __device__ __forceinline__ int steal_work(const DevProblem& P, BlockStats& bs) {
       if (av > 0) busy = true;
     }
     for (int r = 0; r < P.world; ++r) {
-      PeerCell* pc = P.peers[r];
+      PeerCell* pc = glob(glob(P.peers)[r]);
       if (r != P.rank && pc != nullptr && __hip_atomic_load(&pc->stealing, __ATOMIC_ACQUIRE, TB_SYS) != 0) busy = true;
     }
   }
   int result = busy ? 0 : -1;
   if (best >= 0) {
-    PeerCell* v = P.peers[best];
+    PeerCell* v = glob(glob(P.peers)[best]);
     result = 0;
     __hip_atomic_store(&me->stealing, 1, __ATOMIC_RELEASE, TB_SYS);  // visible before the victim's queue shrinks
     for (int tries = 0; tries < 8; ++tries) {
@@ -1221,14 +1342,14 @@ __device__ __forceinline__ int steal_work(const DevProblem& P, BlockStats& bs) {
     }
     __hip_atomic_store(&me->stealing, 0, __ATOMIC_RELEASE, TB_SYS);
   }
-  __hip_atomic_store(&P.ctrl->steal_lock, 0, __ATOMIC_RELEASE, TB_AGENT);
+  __hip_atomic_store(&glob(P.ctrl)->steal_lock, 0, __ATOMIC_RELEASE, TB_AGENT);
   return result;
 }
 
 // Fetch the next subproblem of this device (sh.sub_idx / sub_j / sub_owner / sub_gen).  False: there is no work left
 // anywhere (or a stop was requested while waiting for some).
 __device__ __forceinline__ bool next_subproblem(const DevProblem& P, BlockShared& sh, Mailbox* mbox) {
-  PeerCell* me = P.cell;
+  PeerCell* me = glob(P.cell);
   long long t_wait = 0;
   bool got = false;
   for (;;) {
@@ -1253,7 +1374,7 @@ __device__ __forceinline__ bool next_subproblem(const DevProblem& P, BlockShared
     const int r = steal_work(P, sh.bs);
     if (r < 0) break;
     if (r > 0) continue;
-    const Hot h = load_hot(P.ctrl);
+    const Hot h = load_hot(glob(P.ctrl));
     if (h.stop != 0) break;
     maybe_poll(P, mbox, h, now);
     __builtin_amdgcn_s_sleep(127);
@@ -1268,7 +1389,7 @@ __device__ __forceinline__ bool next_subproblem(const DevProblem& P, BlockShared
 // each subproblem is counted exactly once (solved or skipped) however the ranges were cut and moved between the GPUs;
 // with one workgroup this is the reference's `next_idx - idx`.
 __device__ __forceinline__ void skip_subtree(const DevProblem& P, BlockShared& sh) {
-  PeerCell* me = P.cell;
+  PeerCell* me = glob(P.cell);
   const int r = sh.remaining;
   const unsigned long long e = ((sh.sub_idx >> r) + 1ull) << r;  // first global index behind the subtree
   const unsigned long long je = eps_local_lower_bound(e, P.chunk_log2, sh.sub_owner, P.world);
@@ -1290,18 +1411,22 @@ __device__ __forceinline__ void skip_subtree(const DevProblem& P, BlockShared& s
 
 struct NodeTimers { long long t_last; };
 
-template <bool EVENT, bool C, bool RM>
-__device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
-                                               int2* best_store, Mailbox* mbox, ThreadCounters& tc,
-                                               long long& t_mark, long long t_start) {
+template <bool EVENT, bool C, bool RM, int MEM>
+__device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
+                                                    int2* best_store, Mailbox* mbox, ThreadCounters& tc) {
   const int tid = threadIdx.x;
   BlockStats& bs = sh.bs;
   long long t0 = 0;
-  if (tid == 0) { t0 = wall_clock64(); bs.timers[TB_T_SEARCH] += t0 - t_mark; }
+  if (tid == 0) { t0 = wall_clock64(); bs.timers[TB_T_SEARCH] += t0 - sh.t_mark; }
   bool all_entailed = false;
   int iters;
-  if constexpr (EVENT) iters = fixpoint_event<C>(P, sh, store, props, es, tc, all_entailed);
-  else iters = fixpoint<RM>(P, sh, store, props, es.unent, tc, all_entailed);
+  if constexpr (EVENT) {
+    constexpr bool SL = MEM >= TB_MEM_STORE_SHARED, PL = MEM == TB_MEM_TCN_SHARED;
+    const FpResult r = fixpoint_event_call<C, MEM>(&P, lds_off(&sh), SL ? lds_off(store) : 0u, SL ? nullptr : store, PL ? lds_off(props) : 0u, PL ? nullptr : props,
+                                                   lds_off(es.dirty), lds_off(es.list), tc.writes);
+    iters = r.rounds; all_entailed = r.all_entailed != 0; tc.writes = r.writes;
+  } else iters = fixpoint<RM>(P, sh, store, props, es.unent, tc, all_entailed);
+  flush_writes(sh, tc, false);
   const bool aborted = ld(&sh.abort) != 0;
   const bool failed = !aborted && ld(&sh.bot) != 0;
   if (aborted) all_entailed = false;
@@ -1314,15 +1439,15 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
     const int lane = threadIdx.x & 63;
     for (int s = threadIdx.x >> 6; s < P.n_slices; s += blockDim.x >> 6) {
       const int i = s * 64 + lane;
-      const bool act = lane < P.slice_real[s];  // (idle padding at the end of a class is not a propagator)
+      const bool act = lane < glob(P.slice_real)[s];  // (idle padding at the end of a class is not a propagator)
       const int4 pr = props[i];
       const Itv X = load_dom<C>(store, P.n_int, pr.y), Y = load_dom<C>(store, P.n_int, pr.z), Z = load_dom<C>(store, P.n_int, pr.w);
       const Cand c = evaluate_packed(pr.x, X, Y, Z);
       const bool narrows = act && ((c.xl > X.lb) | (c.xu < X.ub) | (c.yl > Y.lb) | (c.yu < Y.ub) | (c.zl > Z.lb) | (c.zu < Z.ub));
       const bool un = act && !c.ent;
       int bad = 0;
-      if (__any(narrows)) bad |= 1 << 8;
-      if (__any(un) && !((reinterpret_cast<const unsigned*>(es.unent)[s >> 5] >> (s & 31)) & 1u)) bad |= 1 << 9;
+      if (wave_any(narrows)) bad |= 1 << 8;
+      if (wave_any(un) && !((reinterpret_cast<const unsigned*>(es.unent)[s >> 5] >> (s & 31)) & 1u)) bad |= 1 << 9;
       if (bad) {
         int zero = 0;
         bool first = false;
@@ -1331,7 +1456,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
           first = __hip_atomic_compare_exchange_strong(&sh.bs.pad_why, &zero, s + 1, TB_RLX, TB_RLX, TB_WG);
         }
         first = __builtin_amdgcn_readfirstlane((int)first) != 0;
-        const unsigned long long m = __ballot(narrows);
+        const unsigned long long m = wave_ballot(narrows);
         if (first && m && lane == __builtin_ctzll(m)) {
           int* d = sh.bs.dbg;
           d[0] = lane; d[1] = pr.x; d[2] = pr.y; d[3] = pr.z; d[4] = pr.w; d[5] = X.lb; d[6] = X.ub; d[7] = Y.lb; d[8] = Y.ub; d[9] = Z.lb; d[10] = Z.ub; d[11] = (int)sh.bs.nodes;
@@ -1344,7 +1469,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
   if (tid == 0) {
     const long long t1 = wall_clock64();
     bs.timers[TB_T_FIXPOINT] += t1 - t0;
-    t_mark = t1;
+    sh.t_mark = t1;
     int leaf = failed ? 1 : 0, sol = 0;
     bool stream = false;
     if (!failed && all_entailed) {
@@ -1355,7 +1480,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
           sh.best_bound = obj;
           sol = 1;
           if (!P.use_fixed_bound) {
-            const int old = __hip_atomic_fetch_min(&P.ctrl->best_bound, obj, TB_RLX, TB_AGENT);  // appx_best_bound.meet
+            const int old = __hip_atomic_fetch_min(&glob(P.ctrl)->best_bound, obj, TB_RLX, TB_AGENT);  // appx_best_bound.meet
             if (obj < old) {
               publish_bound(P, mbox, obj);
               stream = P.ring.slots != 0;  // best_has_changed && is_printing_intermediate_sol (gpu_dive_and_solve.hpp:341-344)
@@ -1370,12 +1495,12 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
       if (sol) {
         bs.solutions++;
         bs.best_sub = (long long)sh.sub_idx;
-        bs.best_time = t1 - t_start;
+        bs.best_time = t1 - sh.t_start;
         if (P.use_fixed_bound) {
-          __hip_atomic_fetch_min(&P.ctrl->first_sol_idx, sh.sub_idx, TB_RLX, TB_AGENT);
+          __hip_atomic_fetch_min(&glob(P.ctrl)->first_sol_idx, sh.sub_idx, TB_RLX, TB_AGENT);
           sh.stop = 1;
         } else if (P.obj_var < 0 && (P.stop_after_n_solutions != 0 || P.ring.slots != 0)) {
-          const unsigned long long nsol = __hip_atomic_fetch_add(&P.ctrl->solutions, 1ull, TB_RLX, TB_AGENT) + 1;
+          const unsigned long long nsol = __hip_atomic_fetch_add(&glob(P.ctrl)->solutions, 1ull, TB_RLX, TB_AGENT) + 1;
           stream = P.ring.slots != 0 && (P.stop_after_n_solutions == 0 || nsol <= P.stop_after_n_solutions);
           if (P.stop_after_n_solutions != 0 && nsol >= P.stop_after_n_solutions) {  // common_solving.hpp:858-867
             bs.exhaustive = 0;
@@ -1385,7 +1510,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
         }
       }
     }
-    sh.ticket = stream ? (long long)__hip_atomic_fetch_add(&P.ctrl->sol_ticket, 1ull, TB_RLX, TB_AGENT) : -1ll;
+    sh.ticket = stream ? (long long)__hip_atomic_fetch_add(&glob(P.ctrl)->sol_ticket, 1ull, TB_RLX, TB_AGENT) : -1ll;
     sh.leaf = leaf;
     sh.sol = sol;
     bs.fixpoint_iterations += (unsigned long long)iters;
@@ -1398,22 +1523,62 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
     if (P.cut_nodes_total != 0 && (bs.nodes % NODE_BATCH) == 0) {
       // the budget of the whole search: counted per device (agent scope); a single GPU (or one without linked peers, which was
       // given its own share of the budget) checks its own count, linked GPUs are summed by their pollers (poll_outside)
-      const unsigned long long mine = __hip_atomic_fetch_add(&P.ctrl->nodes_local, (unsigned long long)NODE_BATCH, TB_RLX, TB_AGENT) + NODE_BATCH;
+      const unsigned long long mine = __hip_atomic_fetch_add(&glob(P.ctrl)->nodes_local, (unsigned long long)NODE_BATCH, TB_RLX, TB_AGENT) + NODE_BATCH;
       if (P.peers == nullptr && mine >= P.cut_nodes_total) raise_gpu_stop(P);
     }
-    const Hot hot = load_hot(P.ctrl);
+    const Hot hot = load_hot(glob(P.ctrl));
     maybe_poll(P, mbox, hot, t1);
     if (hot.stop != 0) must_stop = true;
-    if (P.use_fixed_bound && __hip_atomic_load(&P.ctrl->first_sol_idx, TB_RLX, TB_AGENT) < sh.sub_idx) { sh.stop = 1; }
-    if (aborted) { must_stop = true; (void)__hip_atomic_fetch_or(&P.ctrl->stop, STOP_HOST, TB_RLX, TB_AGENT); }
+    if (P.use_fixed_bound && __hip_atomic_load(&glob(P.ctrl)->first_sol_idx, TB_RLX, TB_AGENT) < sh.sub_idx) { sh.stop = 1; }
+    if (aborted) { must_stop = true; (void)__hip_atomic_fetch_or(&glob(P.ctrl)->stop, STOP_HOST, TB_RLX, TB_AGENT); }
     if (must_stop) { bs.exhaustive = 0; sh.stop = 1; bs.why |= 4 | (aborted ? 8 : 0) | ((P.cut_nodes != 0 && bs.nodes >= P.cut_nodes) ? 16 : 0); }
   }
   __syncthreads();
   if (sh.sol) {  // uniform
+    for (int rep = reps_of(P, 8); rep > 1; --rep) copy_store(best_store, store, P.vext);
     copy_store(best_store, store, P.vext);
     __syncthreads();
     if (sh.ticket >= 0) produce_solution(P, sh, store, mbox);
   }
+}
+
+// Event kernels: the node (fixpoint + bookkeeping + best-store copy) and the variable selection are functions of their own -- one
+// copy of each instead of one per call site, registers allocated for their own loops, and the persistent search loop keeps only
+// a handful of values alive across them.  (The sweeping kernels stay inlined: their problem description is a by-value kernel
+// argument, which a call would have to copy to memory.)
+template <bool C, int MEM>
+static __device__ TB_NODE_ATTR unsigned propagate_node_event(const DevProblem* Pp, unsigned sh_off, unsigned store_off, int2* gstore, unsigned props_off, const int4* gprops,
+                                                      unsigned dirty_off, unsigned list_off, int2* best_store, Mailbox* mbox, unsigned writes) {
+  BlockShared& sh = *lds_ptr<BlockShared>(sh_off);
+  int2* store = MEM >= TB_MEM_STORE_SHARED ? lds_ptr<int2>(store_off) : glob(gstore);
+  const int4* props = MEM == TB_MEM_TCN_SHARED ? lds_ptr<const int4>(props_off) : glob(gprops);
+  best_store = glob(best_store);
+  EventState es;
+  es.dirty = lds_ptr<unsigned>(dirty_off); es.list = lds_ptr<int>(list_off);
+  es.unent = reinterpret_cast<unsigned char*>(store) + constant_problem(Pp).unent_off;
+  es.words = constant_problem(Pp).dirty_words; es.cap = constant_problem(Pp).chg_cap;
+  ThreadCounters tc;
+  tc.writes = writes;
+  propagate_node_impl<true, C, false, MEM>(constant_problem(Pp), sh, store, props, es, best_store, glob(mbox), tc);
+  return tc.writes;
+}
+template <bool C, bool SL>
+static __device__ TB_SPLIT_ATTR void split_event(const DevProblem* Pp, unsigned sh_off, Decision* dec, unsigned store_off, const int2* gstore) {
+  split<C>(constant_problem(Pp), *lds_ptr<BlockShared>(sh_off), glob(dec), SL ? lds_ptr<const int2>(store_off) : glob(gstore));
+}
+
+template <bool EVENT, bool C, bool RM, int MEM>
+__device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
+                                               int2* best_store, Mailbox* mbox, ThreadCounters& tc) {
+  constexpr bool SL = MEM >= TB_MEM_STORE_SHARED, PL = MEM == TB_MEM_TCN_SHARED;
+  if constexpr (EVENT) tc.writes = propagate_node_event<C, MEM>(&P, lds_off(&sh), SL ? lds_off(store) : 0u, SL ? nullptr : store, PL ? lds_off(props) : 0u, PL ? nullptr : props,
+                                                                lds_off(es.dirty), lds_off(es.list), best_store, mbox, tc.writes);
+  else propagate_node_impl<EVENT, C, RM, MEM>(P, sh, store, props, es, best_store, mbox, tc);
+}
+template <bool EVENT, bool C, bool SL>
+__device__ __forceinline__ void split_node(const DevProblem& P, BlockShared& sh, Decision* dec, int2* store) {
+  if constexpr (EVENT) split_event<C, SL>(&P, lds_off(&sh), dec, SL ? lds_off(store) : 0u, SL ? nullptr : store);
+  else split<C>(P, sh, dec, store);
 }
 
 // ---- the persistent search kernel ----------------------------------------------------------------
@@ -1440,25 +1605,24 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   const int VX = P.vext;
   const size_t store_bytes = MEM >= TB_MEM_STORE_SHARED ? (((size_t)VX * 8 + 15) / 16) * 16 : 0;
   const size_t dirty_bytes = dirty_region_bytes(P.dirty_words) + (((size_t)P.chg_cap * 4 + 15) / 16) * 16;
-  int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : P.g_store + (size_t)b * VX;
+  int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : glob(P.g_store) + (size_t)b * VX;
   EventState es;
   es.dirty = reinterpret_cast<unsigned*>(smem + SH_BYTES + store_bytes);
   es.list = reinterpret_cast<int*>(smem + SH_BYTES + store_bytes + dirty_region_bytes(P.dirty_words));
   es.unent = reinterpret_cast<unsigned char*>(store) + P.unent_off;
   es.words = P.dirty_words; es.cap = P.chg_cap;
-  const int4* props = P.props;
+  const int4* props = glob(P.props);
   if (MEM == TB_MEM_TCN_SHARED) {
     int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + store_bytes + dirty_bytes);
-    for (int i = tid; i < P.n_slices * 64; i += blockDim.x) lprops[i] = P.props[i];  // whole slices: the array is padded
+    for (int i = tid; i < P.n_slices * 64; i += blockDim.x) lprops[i] = glob(P.props)[i];  // whole slices: the array is padded
     props = lprops;
   }
   for (int i = tid; i < 2 * P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
-  int2* snap = P.g_snap + (size_t)b * P.snapshot_levels * VX;
-  int2* best_store = P.g_best + (size_t)b * VX;
-  Decision* dec = P.g_dec + (size_t)b * P.max_depth;
+  int2* snap = glob(P.g_snap) + (size_t)b * P.snapshot_levels * VX;
+  int2* best_store = glob(P.g_best) + (size_t)b * VX;
+  Decision* dec = glob(P.g_dec) + (size_t)b * P.max_depth;
   BlockStats& bs = sh.bs;
   ThreadCounters tc;
-  long long t_start = 0, t_mark = 0;
   if (tid == 0) {
     for (int i = 0; i < TB_NUM_TIMERS; ++i) bs.timers[i] = 0;
     bs.nodes = bs.fails = bs.solutions = bs.fixpoint_iterations = bs.num_deductions = 0;
@@ -1470,7 +1634,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0;
     sh.n_dec_seg = 0;
     sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; sh.witness = -1;
-    t_start = t_mark = wall_clock64();
+    sh.t_start = sh.t_mark = wall_clock64();
     sh.has_work = next_subproblem(P, sh, mbox) ? 1 : 0;
   }
   __syncthreads();
@@ -1478,7 +1642,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   // B. dive-and-solve loop (barebones:656-886)
   while (sh.has_work && !sh.stop) {
     // C. restore the root
-    copy_store(store, P.root_store, VX);  // the root slab is laid out like a workgroup slab
+    copy_store(store, glob(P.root_store), VX);  // the root slab is laid out like a workgroup slab
     if (EVENT && tid == 0) { sh.ev_all = P.root_fixpoint ? 0 : 1; sh.chg_count[0] = 0; }  // a root that is not a fixpoint: every slice runs once
     if (RM && !P.root_fixpoint) {  // nothing is known to be entailed yet (the event fixpoint does this in its root pass)
       __syncthreads();
@@ -1489,14 +1653,14 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
       sh.cur_strategy = 0; sh.next_unassigned = 0; sh.depth = 0; sh.bot = 0;
       sh.remaining = P.subproblems_power; sh.leaf = 0;
       t_dive = wall_clock64();
-      if (P.use_fixed_bound && __hip_atomic_load(&P.ctrl->first_sol_idx, TB_RLX, TB_AGENT) < sh.sub_idx) sh.stop = 1;
+      if (P.use_fixed_bound && __hip_atomic_load(&glob(P.ctrl)->first_sol_idx, TB_RLX, TB_AGENT) < sh.sub_idx) sh.stop = 1;
     }
     __syncthreads();
     // D. dive: no objective bound while diving (gpu_dive_and_solve.hpp:370-372)
     while (sh.remaining > 0 && !sh.leaf && !sh.stop) {
-      propagate_node<EVENT, C, RM>(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
+      propagate_node<EVENT, C, RM, MEM>(P, sh, store, props, es, best_store, mbox, tc);
       if (!sh.leaf && !sh.stop) {
-        split<C>(P, sh, dec, store);
+        split_node<EVENT, C, (MEM >= TB_MEM_STORE_SHARED)>(P, sh, dec, store);
         if (tid == 0) {
           if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; bs.why |= 1; }  // unsplittable infinite domains (barebones:688-694)
           else {
@@ -1522,7 +1686,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
         if (tid == 0 && P.obj_var >= 0) {
           if (P.use_fixed_bound) embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, P.obj_var, NINF, P.fixed_bound);
           else {
-            const unsigned long long bf = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&P.ctrl->best_bound), TB_RLX, TB_AGENT);
+            const unsigned long long bf = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&glob(P.ctrl)->best_bound), TB_RLX, TB_AGENT);
             int g = (int)(bf & 0xffffffffull);
             const int f = (int)(bf >> 32);  // Ctrl::foreign_bound
             g = f < g ? f : g;
@@ -1536,7 +1700,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
         __syncthreads();
         if (sh.stop) break;
         // II. propagate
-        propagate_node<EVENT, C, RM>(P, sh, store, props, es, best_store, mbox, tc, t_mark, t_start);
+        propagate_node<EVENT, C, RM, MEM>(P, sh, store, props, es, best_store, mbox, tc);
         if (sh.stop) break;
         // III. branch
         if (!sh.leaf) {
@@ -1549,7 +1713,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
           if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
           __syncthreads();
           if (prof && tid == 0) { const long long t = wall_clock64(); bs.timers[TB_T_PREPROCESSING] += t - tp; tp = t; }  // profiling: snapshot push
-          split<C>(P, sh, dec, store);
+          split_node<EVENT, C, (MEM >= TB_MEM_STORE_SHARED)>(P, sh, dec, store);
           if (prof && tid == 0) bs.timers[TB_T_SELECT_FP_FUNCTIONS] += wall_clock64() - tp;  // profiling: variable selection
           if (sh.stop) break;
           if (tid == 0) {
@@ -1571,7 +1735,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
           const int depth = sh.new_depth;
           if (depth == -1) break;
           const int lvl = (depth - 1) < (P.snapshot_levels - 1) ? (depth - 1) : (P.snapshot_levels - 1);
-          copy_store(store, snap + (size_t)lvl * VX, VX);
+          for (int rep = reps_of(P, 6); rep > 0; --rep) copy_store(store, snap + (size_t)lvl * VX, VX);
           if (tid == 0) { sh.bot = 0; sh.depth = depth; }
           __syncthreads();
           // re-apply decisions[lvl .. depth-2].current(): distinct decisions may hit the same variable, the
@@ -1599,39 +1763,28 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
     // G. next subproblem (barebones:877-884)
     if (tid == 0 && !sh.stop) {
       const long long t = wall_clock64();
-      bs.timers[TB_T_SEARCH] += t - t_mark;
+      bs.timers[TB_T_SEARCH] += t - sh.t_mark;
       sh.has_work = next_subproblem(P, sh, mbox) ? 1 : 0;
-      t_mark = wall_clock64();  // time spent waiting for work is not search time (BlockStats::wait_ticks)
+      sh.t_mark = wall_clock64();  // time spent waiting for work is not search time (BlockStats::wait_ticks)
     }
     __syncthreads();
   }
-  if (P.g_last != nullptr) copy_store(P.g_last + (size_t)b * VX, store, VX);  // test aid: the store this workgroup stopped on
+  if (P.g_last != nullptr) copy_store(glob(P.g_last) + (size_t)b * VX, store, VX);  // test aid: the store this workgroup stopped on
 
-  // reduce the per-thread counters (once per kernel)
+  // fold what is left of the per-lane write counters into the workgroup's statistics
   __syncthreads();
-  if (tid == 0) { sh.red_key[0] = 0; sh.red_key[1] = 0; }
-  __syncthreads();
-  {
-    unsigned long long w = tc.writes, d = tc.deductions;
-    for (int off = 32; off > 0; off >>= 1) { w += __shfl_xor(w, off, 64); d += __shfl_xor(d, off, 64); }
-    if ((tid & 63) == 0) {
-      __hip_atomic_fetch_add(&sh.red_key[0], w, TB_RLX, TB_WG);
-      __hip_atomic_fetch_add(&sh.red_key[1], d, TB_RLX, TB_WG);
-    }
-  }
+  flush_writes(sh, tc, true);
   __syncthreads();
   if (tid == 0) {
-    bs.store_writes = sh.red_key[0];
-    bs.num_deductions = sh.red_key[1];
     bs.best_bound = sh.best_bound;
-    const int stopped = __hip_atomic_load(&P.ctrl->stop, TB_RLX, TB_AGENT) & STOP_HOST;
+    const int stopped = __hip_atomic_load(&glob(P.ctrl)->stop, TB_RLX, TB_AGENT) & STOP_HOST;
     if (!(P.cut_nodes != 0 && bs.nodes >= P.cut_nodes) && !stopped) bs.num_blocks_done = 1;  // barebones:889-891
     const long long t_end = wall_clock64();
-    bs.timers[TB_T_FIRST_BLOCK_IDLE] = t_end - t_start;
-    bs.timers[TB_T_OVERALL] = t_end - t_start;
+    bs.timers[TB_T_FIRST_BLOCK_IDLE] = t_end - sh.t_start;
+    bs.timers[TB_T_OVERALL] = t_end - sh.t_start;
     bs.timers[TB_T_LATEST_BEST_OBJ_FOUND] = bs.best_time;
-    P.g_stats[b] = bs;
-    __hip_atomic_fetch_add(&P.ctrl->blocks_done, 1, TB_RLX, TB_AGENT);
+    glob(P.g_stats)[b] = bs;
+    __hip_atomic_fetch_add(&glob(P.ctrl)->blocks_done, 1, TB_RLX, TB_AGENT);
   }
 }
 
@@ -1671,7 +1824,7 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
     int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : gstore;
     es.unent = reinterpret_cast<unsigned char*>(store) + P.unent_off;
     ThreadCounters tc;
-    if (tid == 0) { sh.bot = 0; sh.abort = 0; sh.red_key[0] = 0; sh.red_key[1] = 0; sh.witness = -1; }
+    if (tid == 0) { sh.bot = 0; sh.abort = 0; sh.bs.num_deductions = 0; sh.bs.store_writes = 0; sh.witness = -1; }
     __syncthreads();
     if (MEM >= TB_MEM_STORE_SHARED) { copy_store(store, gstore, VX); __syncthreads(); }
     if (RM) for (int q = tid; q < P.n_slices; q += blockDim.x) es.unent[q] = 1;
@@ -1685,20 +1838,15 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
       else iters = fixpoint<RM>(P, sh, store, props, es.unent, tc, all_entailed);
     }
     if (MEM >= TB_MEM_STORE_SHARED) copy_store(gstore, store, VX);
-    unsigned long long w = tc.writes, d = tc.deductions;
-    for (int off = 32; off > 0; off >>= 1) { w += __shfl_xor(w, off, 64); d += __shfl_xor(d, off, 64); }
-    if ((tid & 63) == 0) {
-      __hip_atomic_fetch_add(&sh.red_key[0], w, TB_RLX, TB_WG);
-      __hip_atomic_fetch_add(&sh.red_key[1], d, TB_RLX, TB_WG);
-    }
+    flush_writes(sh, tc, true);
     __syncthreads();
     if (tid == 0) {
       PropagateOut o;
       o.failed = ld(&sh.abort) ? -1 : ld(&sh.bot);
       o.all_entailed = (!o.failed && all_entailed) ? 1 : 0;
       o.iterations = (unsigned long long)iters;
-      o.deductions = sh.red_key[1];
-      o.writes = sh.red_key[0];
+      o.deductions = sh.bs.num_deductions;
+      o.writes = sh.bs.store_writes;
       out[s] = o;
     }
     __syncthreads();
