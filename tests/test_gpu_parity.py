@@ -351,3 +351,16 @@ def test_automatic_fixpoint_picks_by_size_and_keeps_the_tree():
     _, _, st_wac1 = capi.solve(big, capi.make_config(stop_after_n_nodes_total=50000, timeout_ms=60000, fixpoint=1))
     assert (st_auto["num_blocks"], st_auto["threads_per_block"]) == (st_event["num_blocks"], st_event["threads_per_block"])
     assert (st_auto["num_blocks"], st_auto["threads_per_block"]) != (st_wac1["num_blocks"], st_wac1["threads_per_block"])
+
+
+def test_scalar_loads_see_this_sessions_tables_not_an_earlier_ones():
+    """The event kernels read the problem description and the per-slice table with scalar loads.  Sessions of one process re-use
+    device addresses under different contents (here: a plain-layout search, then compact-layout ones), and the scalar cache is not
+    reliably invalidated between launches -- the kernels drop it themselves (s_dcache_inv at entry).  Without that, about half of
+    these searches ended with propagators skipped and `exhaustive = 0`."""
+    tcn = load("test_data/pat11.fzn")
+    capi.solve(tcn, capi.make_config(timeout_ms=60000, fixpoint=2))
+    for _ in range(12):
+        has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=60000, fixpoint=2, debug=COMPACT))
+        assert has and tcn.objective_of(best) == 18
+        assert st["exhaustive"] == 1 and st["why_not_exhaustive"] == 0

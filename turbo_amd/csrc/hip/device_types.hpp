@@ -133,6 +133,8 @@ struct DevProblem {
   const int* adj_rest;  // reader slices beyond the eleventh: slice | interest << 30
   const int4* succ;     // [padded n_props] per record {x, y, z: up to two OTHER slices reading the operand, 16 bits each, 0xffff = none;
                         //  w: bit k = operand k has more of them (walk var_adj), bits 4..15 = interests of the packed ones}
+  const int2* slice_info;  // [n_slices] event kernels, read with scalar loads: {word0 of the slice's records (class set, operand kinds, flags),
+                           //  lanes holding a propagator | 0x100: lean implication records (engine.hip: pack_succ)}
   const int* slice_real;  // [n_slices] event kernels: lanes of the slice that hold a propagator (the engine pads every class to whole slices)
   int n_slices;         // ceil(n_props / 64)
   int dirty_words;      // ceil(n_slices / 32)

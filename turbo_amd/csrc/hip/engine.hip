@@ -392,7 +392,14 @@ void pack_var_adj(const Adjacency& adj, std::vector<int4>* heads, std::vector<in
 // Channelling slices (KEY_EQR_BIC, evaluated jointly by the lanes that share y): every lane of a group knows what happened to y,
 // so y's readers are dealt out over the group's lanes, two each (bit 20 of w: "y is reported by every lane of its group"), when
 // they all fit; a y with ten readers then needs no walk either.
-std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacency& adj, const std::vector<int4>& records, const std::vector<int>& value, bool deal_groups) {
+//
+// Implication slices of the COMPACT layout (KEY_LEQT_BB: `b1 <= b2` on two 2-bit Booleans, `lean` = their store words fit 16 bits): the run
+// works from this record alone.  x = LDS word index (from the start of the store slab) of y's Boolean word | z's << 16; bits 20-23 / 24-27 of
+// w = y's / z's bit position / 2.  y can only ever be narrowed from above by such a propagator, z only from below, so the y slots hold the
+// readers interested in "upper bound lowered", the z slots those interested in "lower bound raised" -- already filtered: no interest check
+// at run time -- and bit 17 / bit 2 say that more than two were interested (walk the variable's adjacency record).
+std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacency& adj, const std::vector<int4>& records, const std::vector<int>& value, bool deal_groups,
+                            int n_int = 0, bool lean = false) {
   std::vector<int4> out(((size_t)n_props + 63) / 64 * 64, make_int4(-1, -1, -1, 0));
   std::vector<int> dealt((size_t)n_props, -1);  // index inside its group of a lane whose y slots are dealt
   if (deal_groups)
@@ -460,6 +467,26 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
       flags |= (in[0] << (4 + 2 * (2 * k))) | (in[1] << (4 + 2 * (2 * k + 1)));
     }
     out[(size_t)i] = make_int4((int)packed[0], (int)packed[1], (int)packed[2], flags);
+    if (lean && ((unsigned)records[(size_t)(i / 64) * 64].x >> 16) == KEY_LEQT_BB) {
+      unsigned slots[3] = {0, 0xffffffffu, 0xffffffffu};
+      int fl = 0;
+      for (int k = 1; k < 3; ++k) {
+        const int ev = k == 1 ? 2 : 1;  // y: upper bound lowered; z: lower bound raised
+        unsigned o[2] = {0xffffu, 0xffffu};
+        int n = 0;
+        bool over = false;
+        for (const Reader& r : adj.lists[(size_t)vs[k]]) {
+          if (r.slice == s || !(r.interest & ev)) continue;
+          if (n < 2) o[n++] = (unsigned)r.slice; else over = true;
+        }
+        if (over) { o[0] = o[1] = 0xffffu; fl |= k == 1 ? (1 << 17) : (1 << 2); }
+        slots[k] = (o[1] << 16) | o[0];
+      }
+      const int by = vs[1] - n_int, bz = vs[2] - n_int;
+      slots[0] = (unsigned)(n_int * 2 + (by >> 4)) | ((unsigned)(n_int * 2 + (bz >> 4)) << 16);
+      fl |= ((by & 15) << 20) | ((bz & 15) << 24);
+      out[(size_t)i] = make_int4((int)slots[0], (int)slots[1], (int)slots[2], fl);
+    }
   }
   // Reified comparisons against a constant with a Boolean truth variable (KEY_EQR_BIC, KEY_LEQR_BIC: dedicated runs that never
   // report anything about z): the z slots, useless for a constant, carry its VALUE, and in the channelling slices bits 21-26 /
@@ -482,6 +509,18 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
     }
   }
   return out;
+}
+
+// Per slice, for the event kernels (read with scalar loads): x = word0 of the slice's first record (its slice-uniform part: class set,
+// operand kinds, flags), y = lanes that hold a propagator | 0x100 when the slice's successor records carry the lean implication encoding.
+std::vector<int2> slice_infos(const std::vector<int4>& packed, const std::vector<int>& real, int n_slices, bool lean) {
+  std::vector<int2> info((size_t)std::max(1, n_slices), make_int2(0, 0));
+  for (int s = 0; s < n_slices; ++s) {
+    const int w0 = (size_t)s * 64 < packed.size() ? packed[(size_t)s * 64].x : 0;
+    const bool is_lean = lean && ((unsigned)w0 >> 16) == KEY_LEQT_BB;
+    info[(size_t)s] = make_int2(w0, ((size_t)s < real.size() ? real[(size_t)s] : 0) | (is_lean ? 0x100 : 0));
+  }
+  return info;
 }
 
 // Constants of a batch of stores: variables that are the same finite singleton in every store.
@@ -745,6 +784,46 @@ std::vector<int> real_lanes(const std::vector<tb_prop>& props, int n_slices) {
   return r;
 }
 
+// Tables of the event-driven fixpoint (successor records, slice infos, variable adjacency): built from the packed records and uploaded.
+int upload_event_tables(DevBuffers& bufs, DevProblem& P, const tb_config& cfg, const LaunchPlan& plan, const Layout& lay, int32_t n_rec,
+                        const std::vector<tb_prop>& net_props, const Adjacency& adj, const std::vector<int4>& packed, const std::vector<int>& value) {
+  int rc;
+  const std::vector<int> real = real_lanes(net_props, plan.n_slices);
+  int* d_real = nullptr;
+  if ((rc = bufs.alloc(&d_real, real.size())) != TB_OK) return rc;
+  HIP_TRY(hipMemcpy(d_real, real.data(), real.size() * sizeof(int), hipMemcpyHostToDevice));
+  P.slice_real = d_real;
+  // the lean implication records address Boolean words by a 16-bit word index inside the slab
+  const bool lean = lay.compact && std::getenv("TB_NO_LEAN") == nullptr && (size_t)lay.n_int * 2 + (size_t)lay.bool_words() <= 0x10000;  // (TB_NO_LEAN: A/B runs)
+  std::vector<int4> succ = pack_succ(n_rec, net_props.data(), adj, packed, value, !(cfg.reserved[0] & 0x4000000), lay.n_int, lean);
+  succ.resize((size_t)plan.n_slices * 64, make_int4(-1, -1, -1, 0));
+  int4* d_succ = nullptr;
+  if ((rc = bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
+  if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
+  P.succ = d_succ;
+  const std::vector<int2> info = slice_infos(packed, real, plan.n_slices, lean);
+  if (std::getenv("TB_DUMP_SLICES") != nullptr)  // debugging aid
+    for (int q = 0; q < plan.n_slices; ++q) {
+      int prefix = 0, classed = 0;
+      for (int l = 0; l < 64; ++l) { const bool c = ((unsigned)packed[(size_t)q * 64 + l].x >> 16) != 0u; classed += c ? 1 : 0; if (c && prefix == l) ++prefix; }
+      std::fprintf(stderr, "%% slice %d: key %#x w0 %#x real %d lean %d | lanes with a class set %d, as a prefix %d\n", q, (unsigned)info[(size_t)q].x >> 16, (unsigned)info[(size_t)q].x,
+                   info[(size_t)q].y & 0xff, (info[(size_t)q].y >> 8) & 1, classed, prefix);
+    }
+  int2* d_info = nullptr;
+  if ((rc = bufs.alloc(&d_info, info.size())) != TB_OK) return rc;
+  HIP_TRY(hipMemcpy(d_info, info.data(), info.size() * sizeof(int2), hipMemcpyHostToDevice));
+  P.slice_info = d_info;
+  std::vector<int4> heads; std::vector<int> rest;
+  pack_var_adj(adj, &heads, &rest);
+  int4* d_heads = nullptr; int* d_rest = nullptr;
+  if ((rc = bufs.alloc(&d_heads, heads.size())) != TB_OK) return rc;
+  if ((rc = bufs.alloc(&d_rest, rest.size())) != TB_OK) return rc;
+  HIP_TRY(hipMemcpy(d_heads, heads.data(), heads.size() * sizeof(int4), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_rest, rest.data(), rest.size() * sizeof(int), hipMemcpyHostToDevice));
+  P.var_adj = d_heads; P.adj_rest = d_rest;
+  return TB_OK;
+}
+
 extern "C" {
 
 const char* tb_version(void) { return "turbo-hip 0.1.0 (gfx950)"; }
@@ -826,27 +905,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     std::vector<int4> packed = pack_props(n_rec, net.props.data(), is_const, value, adj, lay.n_int);
     packed.resize((size_t)plan.n_slices * 64, make_int4(K_LEQ_T, 0, 0, 0));
     if (n_rec) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
-    {
-      const std::vector<int> real = real_lanes(net.props, plan.n_slices);
-      int* d_real = nullptr;
-      if ((rc = bufs.alloc(&d_real, real.size())) != TB_OK) return rc;
-      HIP_TRY(hipMemcpy(d_real, real.data(), real.size() * sizeof(int), hipMemcpyHostToDevice));
-      P.slice_real = d_real;
-      std::vector<int4> succ = pack_succ(n_rec, net.props.data(), adj, packed, value, !(cfg.reserved[0] & 0x4000000));
-      succ.resize((size_t)plan.n_slices * 64, make_int4(-1, -1, -1, 0));
-      int4* d_succ = nullptr;
-      if ((rc = bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
-      if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
-      P.succ = d_succ;
-      std::vector<int4> heads; std::vector<int> rest;
-      pack_var_adj(adj, &heads, &rest);
-      int4* d_heads = nullptr; int* d_rest = nullptr;
-      if ((rc = bufs.alloc(&d_heads, heads.size())) != TB_OK) return rc;
-      if ((rc = bufs.alloc(&d_rest, rest.size())) != TB_OK) return rc;
-      HIP_TRY(hipMemcpy(d_heads, heads.data(), heads.size() * sizeof(int4), hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(d_rest, rest.data(), rest.size() * sizeof(int), hipMemcpyHostToDevice));
-      P.var_adj = d_heads; P.adj_rest = d_rest;
-    }
+    if ((rc = upload_event_tables(bufs, P, cfg, plan, lay, n_rec, net.props, adj, packed, value)) != TB_OK) return rc;
   }
   P.n_slices = plan.n_slices; P.dirty_words = plan.dirty_words; P.vext = plan.vext; P.chg_cap = plan.chg_cap;
   P.n_int = plan.n_int; P.unent_off = plan.unent_off;
@@ -978,27 +1037,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     std::vector<int4> packed = pack_props(n_rec, net.props.data(), is_const, value, adj, lay.n_int);
     packed.resize((size_t)plan.n_slices * 64, make_int4(K_LEQ_T, 0, 0, 0));
     if (n_rec) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
-    {
-      const std::vector<int> real = real_lanes(net.props, plan.n_slices);
-      int* d_real = nullptr;
-      if ((rc = s->bufs.alloc(&d_real, real.size())) != TB_OK) return rc;
-      HIP_TRY(hipMemcpy(d_real, real.data(), real.size() * sizeof(int), hipMemcpyHostToDevice));
-      s->P.slice_real = d_real;
-      std::vector<int4> succ = pack_succ(n_rec, net.props.data(), adj, packed, value, !(s->cfg.reserved[0] & 0x4000000));
-      succ.resize((size_t)plan.n_slices * 64, make_int4(-1, -1, -1, 0));
-      int4* d_succ = nullptr;
-      if ((rc = s->bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
-      if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
-      s->P.succ = d_succ;
-      std::vector<int4> heads; std::vector<int> rest;
-      pack_var_adj(adj, &heads, &rest);
-      int4* d_heads = nullptr; int* d_rest = nullptr;
-      if ((rc = s->bufs.alloc(&d_heads, heads.size())) != TB_OK) return rc;
-      if ((rc = s->bufs.alloc(&d_rest, rest.size())) != TB_OK) return rc;
-      HIP_TRY(hipMemcpy(d_heads, heads.data(), heads.size() * sizeof(int4), hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(d_rest, rest.data(), rest.size() * sizeof(int), hipMemcpyHostToDevice));
-      s->P.var_adj = d_heads; s->P.adj_rest = d_rest;
-    }
+    if ((rc = upload_event_tables(s->bufs, s->P, s->cfg, s->plan, s->lay, n_rec, net.props, adj, packed, value)) != TB_OK) return rc;
   }
   s->P.n_slices = s->plan.n_slices; s->P.dirty_words = s->plan.dirty_words; s->P.vext = s->plan.vext; s->P.chg_cap = s->plan.chg_cap;
   s->P.n_int = s->plan.n_int; s->P.unent_off = s->plan.unent_off;
@@ -1371,6 +1410,8 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
     std::fprintf(stderr, "%% event-profile degree (reader slices) of the variables marked through their record, per node: <=4: %.1f  5-6: %.1f  7-11: %.1f  more: %.1f\n",
                  d[17] / n, d[18] / n, d[19] / n, d[20] / n);
     std::fprintf(stderr, "%% event-profile adjacency-record branch: %.0f cycles per node, lanes marking x %.1f, y or z %.1f\n", 16 * d[21] / n, d[22] / n, d[23] / n);
+    std::fprintf(stderr, "%% event-profile rounds per node by slices that run: 1: %.2f  2: %.2f  3-4: %.2f  5-8: %.2f  9-16: %.2f  more: %.2f; slices per node %.1f, of wave 0 %.1f\n",
+                 d[24] / n, d[25] / n, d[26] / n, d[27] / n, d[28] / n, d[29] / n, d[30] / n, d[31] / n);
   }
 #endif
   for (size_t b = 0; b < B; ++b) {

@@ -21,14 +21,17 @@
 #ifndef TB_EVENT_WAVES
 #define TB_EVENT_WAVES 7
 #endif
-#ifndef TB_EVENT_PREFETCH
-#define TB_EVENT_PREFETCH 0
-#endif
 // Which parts of an event kernel's node are functions of their own (bit 0: the fixpoint, bit 1: node bookkeeping, bit 2: variable
 // selection).  Measured on wordpress7_500: a call costs more than it saves here -- the callee-saved registers go through scratch
 // memory on every call and return (3.37e7 nodes/s inlined, 2.74e7 with all three outlined) -- so the default is 0.
 #ifndef TB_OUTLINE
 #define TB_OUTLINE 0
+#endif
+// Event kernels: fetch the next slice's successor record (4 registers) while the current slice runs.  Measured on wordpress7_500, same
+// box: 3.51e7 nodes/s without, 2.59e7 with -- loads return in order, so every `s_waitcnt vmcnt(0)` the compiler places inside a run
+// (it cannot count across the branches of the bodies) also waits for the prefetch that was just issued.  Off.
+#ifndef TB_SC_PREFETCH
+#define TB_SC_PREFETCH 0
 #endif
 #if TB_OUTLINE & 1
 #define TB_FIX_ATTR __noinline__
@@ -131,6 +134,7 @@ template <class T> __device__ __forceinline__ T* lds_ptr(unsigned off) { return 
 // fetched with scalar loads (s_load_dword) where they are used, like kernel arguments.
 struct DevProblem;
 __device__ __forceinline__ const DevProblem& constant_problem(const DevProblem* p);
+template <class T> __device__ __forceinline__ const T* cst(const T* p) { return (const T*)(TB_CST const T*)(size_t)p; }  // read-only for the whole launch: scalar loads
 template <class T> __device__ __forceinline__ T* glob(T* p) { return (T*)(TB_GLB T*)(size_t)p; }  // (through an integer: a generic -> global -> generic cast pair folds away)
 
 __device__ __forceinline__ const DevProblem& constant_problem(const DevProblem* p) { return *(const DevProblem*)(TB_CST const DevProblem*)(size_t)p; }
@@ -139,6 +143,13 @@ __device__ __forceinline__ const DevProblem& constant_problem(const DevProblem* 
 // turned into 0/1 with a v_cndmask and compared again -- two VALU instructions per vote on an issue-bound kernel).
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// The lane mask of "x != 0" as ONE v_cmp.  (A ballot of a bool that is itself a combination of lane masks is re-materialised by the
+// compiler as v_cndmask 0/1 + v_cmp to clear the lanes outside exec: the hot bodies keep their predicates as integers and vote once.)
+__device__ __forceinline__ unsigned long long mask_nz(unsigned x) {
+  unsigned long long m;
+  asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(m) : "v"(x));
+  return m;
+}
 
 __device__ __forceinline__ int ld(const int* p) { return __hip_atomic_load(p, TB_RLX, TB_WG); }
 __device__ __forceinline__ void st(int* p, int v) { __hip_atomic_store(p, v, TB_RLX, TB_WG); }
@@ -649,6 +660,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   for (int b = wave; b < 32; b += nw) own |= 1u << b;
   int rounds = 0;
   unsigned wave_iters_total = 0;  // wave-uniform
+  unsigned wave_writes = 0;       // wave-uniform: narrowed bounds counted on lane masks (s_bcnt1), credited to lane 0 at the end
 #ifdef TB_TUNING
   long long tprof = prof ? clock64() : 0;
 #endif
@@ -668,17 +680,34 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
         asm volatile("" :: "s"(nz));
       }
 #endif
+#ifdef TB_TUNING
+    if (prof && wave == 0) {  // census of the rounds by the number of slices that will run: 1, 2, 3-4, 5-8, 9-16, more -> dbg[24..29]; per wave maximum dbg[30]
+      int total = 0, mx = 0;
+      for (int base = 0; base < W; base += 64) {
+        const int wi = base + lane;
+        unsigned wa = wi < W ? __hip_atomic_load(&cur[wi], TB_RLX, TB_WG) : 0u;
+        if (drop_entailed && wi < W) wa &= __hip_atomic_load(&ubits[wi], TB_RLX, TB_WG);
+        int c = __popc(wa), c0 = __popc(wa & own);
+        for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off, 64); c0 += __shfl_xor(c0, off, 64); }
+        total += c; mx += c0;
+      }
+      if (lane == 0 && total > 0) { sh.bs.dbg[total == 1 ? 24 : (total == 2 ? 25 : (total <= 4 ? 26 : (total <= 8 ? 27 : (total <= 16 ? 28 : 29))))] += 1; sh.bs.dbg[30] += total; sh.bs.dbg[31] += mx; }
+    }
+    if (prof) __syncthreads();  // (the other waves must not clear their bits under the census)
+#endif
     for (int base = 0; base < W; base += 64) {
       const int wi = base + lane;
       unsigned w = wi < W ? (__hip_atomic_load(&cur[wi], TB_RLX, TB_WG) & own) : 0u;
       if (w != 0) (void)__hip_atomic_fetch_and(&cur[wi], ~w, TB_RLX, TB_WG);  // mine, cleared before any domain is loaded
       // entailed-slice removal: a slice whose 64 propagators were all entailed when it last ran is not even looked at
       if (drop_entailed && w != 0) w &= __hip_atomic_load(&ubits[wi], TB_RLX, TB_WG);
-      // my slices of this round, one after the other
+      // my slices of this round, one after the other: wave-uniform iteration over the set bits of the words held by the lanes.
+      // The successor record of the NEXT slice is fetched while the current one runs (4 registers; every kind of run needs that
+      // record, the lean implication runs nothing else): the L2 round trip of a run's first load was a third of its duration.
       unsigned long long nz = wave_ballot(w != 0);
       unsigned word = 0;
       int wl = 0;
-      auto next_slice = [&]() -> int {  // wave-uniform iteration over the set bits of the words held by the lanes
+      auto next_slice = [&]() -> int {
         while (word == 0) {
           if (nz == 0) return -1;
           wl = __builtin_ctzll(nz);
@@ -690,42 +719,112 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
         return (base + wl) * 32 + b;
       };
       int s = next_slice();
-#if TB_EVENT_PREFETCH
-      int4 pr_c = idle_record(), sc_c = make_int4(0, 0, 0, 0);
-      if (s >= 0) { pr_c = props[s * 64 + lane]; sc_c = glob(P.succ)[s * 64 + lane]; }
+#if TB_SC_PREFETCH
+      int4 sc_cur = make_int4(0, 0, 0, 0);
+      if (s >= 0) sc_cur = (glob(P.succ) + (size_t)s * 64)[lane];
 #endif
       while (s >= 0) {
         const int s_next = next_slice();
-#if TB_EVENT_PREFETCH
-        const int sp = s_next >= 0 ? s_next : s;
-        const int4 pr_n = props[sp * 64 + lane], sc_n = glob(P.succ)[sp * 64 + lane];
+#if TB_SC_PREFETCH
+        const int4 sc = sc_cur;
+        if (s_next >= 0) sc_cur = (glob(P.succ) + (size_t)s_next * 64)[lane];
 #endif
-        // (no software prefetch of the next slice's records: under the 80-register budget of this kernel the prefetched
-        //  int4 lived in scratch, and the round trip cost more than the L2 latency it hid -- 15.3 -> 19.3e6 nodes/s without it)
-#if TB_EVENT_PREFETCH
-        const int4 pr = pr_c;
-#else
-        const int4 pr = props[s * 64 + lane];  // the arrays are padded to whole slices
+        const int2 info = cst(P.slice_info)[s];
+#if !TB_SC_PREFETCH
+        const int4* const succ_slice = glob(P.succ) + (size_t)s * 64;  // uniform base + lane: no 64-bit VALU address arithmetic
 #endif
         if (dead_node(sh)) break;  // the node failed in another wave
         for (int rep = reps_of(P, 3); rep > 0; --rep) {
-#ifdef TB_TUNING
-          int4 pr_again = pr;
-          if (rep == 1 && reps_of(P, 3) > 1) { const int4* pp = props + (s * 64 + lane); asm volatile("" : "+v"(pp)); pr_again = *pp; if (dead_node(sh)) break; }
-#define pr pr_again
+          const bool act = lane < (info.y & 0xff);
+#if !TB_SC_PREFETCH
+          const int4 sc = succ_slice[lane];
 #endif
-          // (classes start on slice boundaries: a slice may end with idle padding -- records whose word0 carries no class set)
-          const bool act = ((unsigned)pr.x >> 16) != 0u;
+          if (C && (info.y & 0x100)) {
+            // ---- lean implication run: `y <= z` on two 2-bit Booleans (bit 0: lb raised to 1, bit 1: ub lowered to 0) from the successor
+            // record alone (engine.hip: pack_succ): z.ub = 0 forces y.ub = 0, y.lb = 1 forces z.lb = 1; entailed once y.ub = 0 or z.lb = 1.
+            unsigned* const words = reinterpret_cast<unsigned*>(store);
+            unsigned* const wy = words + ((unsigned)sc.x & 0xffffu);
+            unsigned* const wz = words + ((unsigned)sc.x >> 16);
+            const int ys = (sc.w >> 19) & 30, zs = (sc.w >> 23) & 30;
+            const unsigned am = act ? ~0u : 0u;  // idle lanes of a padded slice see nothing to do
+            unsigned long long ny_acc = 0ull, nz_acc = 0ull;  // lanes that narrowed their y / their z during the run
+            TB_PROF_MARK(0);
+            unsigned iters = 0;
+            for (;;) {
+              // predicates as integers on the raw bit pairs (bit 0 of yb / zb: lb raised, bit 1: ub lowered), one vote each
+              const unsigned yb = __hip_atomic_load(wy, TB_RLX, TB_WG) >> ys, zb = __hip_atomic_load(wz, TB_RLX, TB_WG) >> zs;
+              const unsigned ny = zb & ~yb & 2u & am, nz = yb & ~zb & 1u & am;             // y.ub := 0 / z.lb := 1
+              const unsigned bad = ((yb & (yb >> 1)) | (zb & (zb >> 1)) | (yb & (zb >> 1))) & 1u & am;  // an empty domain, or y true and z false
+              ++iters;
+              const unsigned long long m_ny = mask_nz(ny), m_nz = mask_nz(nz), m_bad = mask_nz(bad);
+              if ((m_ny | m_nz | m_bad) == 0ull) {
+                // quiet pass: the local fixpoint is reached; the slice's "not entailed" bit only ever goes 1 -> 0 below a node
+                if (mask_nz(~(yb >> 1) & ~zb & 1u & am) == 0ull && lane == 0)
+                  (void)__hip_atomic_fetch_and(&ubits[s >> 5], ~(1u << (s & 31)), TB_RLX, TB_WG);
+                break;
+              }
+              if (m_bad != 0ull) { if (lane == 0) st(&sh.bot, 1); break; }  // the node fails: what this pass would still write is moot
+              if (ny) (void)__hip_atomic_fetch_or(wy, 2u << ys, TB_RLX, TB_WG);
+              if (nz) (void)__hip_atomic_fetch_or(wz, 1u << zs, TB_RLX, TB_WG);
+              wave_writes += (unsigned)__builtin_popcountll(m_ny) + (unsigned)__builtin_popcountll(m_nz);
+              ny_acc |= m_ny; nz_acc |= m_nz;
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+              if (ld(&sh.bot)) break;
+            }
+            if (rep == reps_of(P, 3)) wave_iters_total += (knobs(P) & 0x400000) ? 1u : iters;
+#ifdef TB_TUNING
+            if (prof && wave == 0) {
+              const long long t_ = clock64();
+              if (lane == 0) { sh.bs.dbg[1] += (int)((t_ - tprof) >> 4); sh.bs.dbg[6] += (int)((t_ - tprof) >> 4); sh.bs.dbg[11] += 1; }
+              tprof = t_;
+            }
+#endif
+            if (knobs(P) & 0x8) {  // tuning: one more (quiet) pass
+              const unsigned yb = (__hip_atomic_load(wy, TB_RLX, TB_WG) >> ys) & 3u, zb = (__hip_atomic_load(wz, TB_RLX, TB_WG) >> zs) & 3u;
+              const unsigned long long again = wave_ballot(act && ((zb & ~yb & 2u) | (yb & ~zb & 1u)) != 0u);
+              asm volatile("" :: "s"(again));
+            }
+            for (int mrep = (knobs(P) & 0x1) ? 2 : 1; mrep > 0; --mrep)
+            if ((ny_acc | nz_acc) != 0ull) {
+              // successors: the slots hold the readers interested in exactly these events (y.ub lowered / z.lb raised), pre-filtered
+              const bool my_ny = ((ny_acc >> lane) & 1ull) != 0ull, my_nz = ((nz_acc >> lane) & 1ull) != 0ull;
+              const unsigned ty = my_ny ? (unsigned)sc.y : 0xffffffffu, tz = my_nz ? (unsigned)sc.z : 0xffffffffu;
+              bool did = false;
+              if ((ty & 0xffffu) != 0xffffu) { mark_slice(nxt, (int)(ty & 0xffffu)); did = true; }
+              if ((ty >> 16) != 0xffffu) { mark_slice(nxt, (int)(ty >> 16)); did = true; }
+              if ((tz & 0xffffu) != 0xffffu) { mark_slice(nxt, (int)(tz & 0xffffu)); did = true; }
+              if ((tz >> 16) != 0xffffu) { mark_slice(nxt, (int)(tz >> 16)); did = true; }
+              const int ey = (my_ny && ((sc.w >> 17) & 1)) ? EV_UB : 0, ez = (my_nz && ((sc.w >> 2) & 1)) ? EV_LB : 0;
+              if (wave_any((ey | ez) != 0)) {  // more than two interested readers: the variable's adjacency record
+                const int base_w = P.n_int * 2;
+                const int vy = P.n_int + ((((int)((unsigned)sc.x & 0xffffu)) - base_w) << 4) + (ys >> 1);
+                const int vz = P.n_int + ((((int)((unsigned)sc.x >> 16)) - base_w) << 4) + (zs >> 1);
+                int dy = 0, dz = 0, oy = 0, oz = 0;
+                const bool tly = mark_var(P, nxt, vy, s, ey, dy, oy, did);
+                const bool tlz = mark_var(P, nxt, vz, s, ez, dz, oz, did);
+                const unsigned long long my = wave_ballot(tly), mz = wave_ballot(tlz);
+                if (my) did |= mark_tail(P, nxt, my, dy, oy, ey, s);
+                if (mz) did |= mark_tail(P, nxt, mz, dz, oz, ez, s);
+              }
+              marked |= wave_any(did);
+            }
+            TB_PROF_MARK(2);
+            TB_PROF_COUNT(4);
+            continue;
+          }
+          const int4 pr_first = props[s * 64 + lane];  // the arrays are padded to whole slices
+#ifdef TB_TUNING
+          int4 pr_again = pr_first;
+          if (rep == 1 && reps_of(P, 3) > 1) { const int4* pp = props + (s * 64 + lane); asm volatile("" : "+v"(pp)); pr_again = *pp; if (dead_node(sh)) break; }
+          const int4 pr = pr_again;
+#else
+          const int4 pr = pr_first;
+#endif
           const RunEnv E{P, sh, nxt, ubits, s};
-          const unsigned key = (unsigned)__builtin_amdgcn_readfirstlane(pr.x) >> 16;  // wave-uniform: scalar dispatch
+          const unsigned key = (unsigned)info.x >> 16;  // wave-uniform: scalar dispatch
           unsigned wave_iters;
           unsigned run_writes = 0;  // per lane, folded into the 64-bit counter once per run
           int nar_all = 0;          // operands this lane narrowed during the run
-#if TB_EVENT_PREFETCH
-          const int4 sc = sc_c;
-#else
-          const int4 sc = glob(P.succ)[s * 64 + lane];  // needed after the run only: the load hides behind it
-#endif
           TB_PROF_MARK(0);
           if (C && key == KEY_LEQT_BB) {
             // y <= z on two Booleans, straight on their 2-bit encodings (bit 0: lb raised to 1, bit 1: ub lowered to 0):
@@ -759,7 +858,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             // every b_i outside the new bounds becomes false and, if y is assigned, its b_i true.  Same fixpoint, one pass.
             const BoolRef rx = bool_ref(store, P.n_int, pr.y, act);
             const int yv = act ? pr.z : 0;
-            const int w0u = __builtin_amdgcn_readfirstlane(pr.x);
+            const int w0u = info.x;
             const bool single_pass = ((w0u >> 11) & 1) != 0;
             // Prepared by the host with the record (pack_succ): the constant's value in the z slots, the first and last lane of
             // my group (the lanes between two changes of y), and for the slice whether every group's constants are consecutive
@@ -903,13 +1002,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             const bool useless = !wave_any(nar_all != 0);  // the run narrowed nothing
             if (rep == reps_of(P, 3) && (want == 0 || want - 1 == cls_of_slice) && (!(knobs(P) & 0x40) || useless)) wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;  // 0x40: only the runs that narrowed nothing
           }
-#ifdef TB_TUNING
-#undef pr
-#endif
         }
-#if TB_EVENT_PREFETCH
-        pr_c = pr_n; sc_c = sc_n;
-#endif
         s = s_next;
       }
     }
@@ -923,6 +1016,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     TB_PROF_COUNT(5);
     if (!ld(&sh.flag[k]) || dead_node(sh)) break;
   }
+  if (lane == 0) tc.writes += wave_writes;
   if (lane == 0 && wave_iters_total != 0) add_deductions(sh, 64ull * wave_iters_total);
   if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += t - tp0; tp0 = t; }  // profiling: rounds
   // leave both bitmaps empty for the next node (they are not after a failure)
@@ -1596,6 +1690,11 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   // VALU work on an issue-bound kernel); behind a pointer the compiler loads a field where it is used (scalar cache):
   // 137 spills, +4 % nodes/s on wordpress7_500.  The sweeping kernels keep the by-value arguments: their loops are short and
   // spill-free, and reloading fields inside them costs 2 %.
+  // The problem description and the per-slice table are read with scalar loads.  They were written by the host (hipMemcpy) into
+  // buffers whose addresses earlier launches of this process may have read through the scalar cache under another content; the
+  // dispatch does not reliably invalidate that cache (observed: stale per-slice words on a re-used address, 14 of 30 searches of
+  // pat11 went wrong), so every wave drops it once, here.
+  __builtin_amdgcn_s_dcache_inv();
   const DevProblem& P = EVENT ? *problem : by_value;
   constexpr bool C = EVENT && OPT, RM = !EVENT && OPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1800,6 +1899,7 @@ struct PropagateOut {
 // `stores` holds n_stores slabs of P.vext intervals each (the layout of a workgroup slab, encoded by the host).
 template <int MEM, int TMAX, bool EVENT, bool OPT>
 __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* stores, PropagateOut* out, int n_stores) {
+  __builtin_amdgcn_s_dcache_inv();  // (see solve_kernel)
   constexpr bool C = EVENT && OPT, RM = !EVENT && OPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
