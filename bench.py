@@ -41,8 +41,8 @@ if ROOT not in sys.path:
 # arm -> barrier -> start handshake is well under that), which makes it 2-3 s on one GPU.
 WORKLOADS = {
     "wordpress7_500": ("example_wordpress7_500.fzn", 96_000_000, 6_000_000),
-    "accap_a3": ("accap_a3.fzn", 96_000_000, 48_000_000),
-    "trains15": ("trains15.fzn", 48_000_000, 12_000_000),
+    "accap_a3": ("accap_a3.fzn", 24_000_000, 24_000_000),
+    "trains15": ("trains15.fzn", 24_000_000, 8_000_000),
     "synthetic": ("synthetic 100k x 500k (seed 42)", 48_000, 24_000),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

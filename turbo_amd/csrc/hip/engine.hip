@@ -175,7 +175,8 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   p.chg_cap = std::min(1024, std::max(64, n_vars / 4));
   if (cfg.reserved[1] > 0) p.chg_cap = cfg.reserved[1];  // tuning knob
   const size_t dirty_b = dirty_region_bytes(dirty_words) + align16((size_t)p.chg_cap * 4);
-  const size_t store_b = align16((size_t)vext * 8) + dirty_b, props_b = (size_t)n_slices * 64 * 16;  // padded to whole slices
+  // (event mode keeps the successor records next to the bytecodes: 32 bytes per propagator)
+  const size_t store_b = align16((size_t)vext * 8) + dirty_b, props_b = (size_t)n_slices * 64 * (event ? 32 : 16);  // padded to whole slices
   const size_t fixed = SH_BYTES;
   int bpc_max = std::min(cfg.reserved[2] > 0 ? cfg.reserved[2] : 8, 2048 / T);  // 32 waves per CU (reserved[2]: tuning knob)
   if (bpc_max < 1) bpc_max = 1;
@@ -183,12 +184,15 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
   } else if ((fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
     p.mem_kind = TB_MEM_TCN_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b + props_b);
+  // (event mode, measured on accap_a3: the records in LDS at the price of 3 workgroups per CU instead of 7 -- 1.39e7 against 4.50e7 nodes/s.
+  //  The records come out of L2 fast enough; what a CU needs is subproblems in flight.)
   } else if ((fixed + store_b) * (size_t)bpc_max <= lds) {
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b);
-  } else if (fixed + store_b <= lds && !(event && (int)(lds / (fixed + store_b)) < 3 && !(cfg.reserved[0] & 0x40000))) {
-    // (event mode: a store that leaves fewer than 3 workgroups per CU goes to global memory instead --
-    //  measured 1.2-1.5x more nodes/s on wordpress7_500 / trains15 with 6 x 256-thread workgroups per CU;
-    //  choose_layout then tries the COMPACT layout, which usually brings the store back into LDS)
+  } else if (fixed + store_b <= lds && !(event && (int)(lds / (fixed + store_b)) < 4 && !(cfg.reserved[0] & 0x40000))) {
+    // (event mode: a store that leaves fewer than 4 workgroups per CU goes to global memory instead: what a CU needs is
+    //  subproblems in flight -- trains15, compact slab of 50 KB: 1.77e7 nodes/s with 3 workgroups per CU in LDS, 2.04e7 with 7
+    //  working on slabs in global memory (L2 / Infinity Cache resident); wordpress7_500 r02: 1.2-1.5x.  choose_layout first tries
+    //  the COMPACT layout, which usually brings the store back into LDS)
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / (fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
   } else {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
@@ -513,12 +517,24 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
 
 // Per slice, for the event kernels (read with scalar loads): x = word0 of the slice's first record (its slice-uniform part: class set,
 // operand kinds, flags), y = lanes that hold a propagator | 0x100 when the slice's successor records carry the lean implication encoding.
-std::vector<int2> slice_infos(const std::vector<int4>& packed, const std::vector<int>& real, int n_slices, bool lean) {
+// 0x200: the slice has one class (not the heavy one) and every operand of every record has a finite root domain within +-2^29 -- the plain
+// layout then runs it with lean_plain_run (kernels.hpp): 32-bit sums and differences of two such bounds cannot overflow, anywhere in the tree.
+std::vector<int2> slice_infos(const std::vector<int4>& packed, const std::vector<int>& real, int n_slices, bool lean, const tb_itv* root, bool plain_lean) {
   std::vector<int2> info((size_t)std::max(1, n_slices), make_int2(0, 0));
   for (int s = 0; s < n_slices; ++s) {
     const int w0 = (size_t)s * 64 < packed.size() ? packed[(size_t)s * 64].x : 0;
     const bool is_lean = lean && ((unsigned)w0 >> 16) == KEY_LEQT_BB;
-    info[(size_t)s] = make_int2(w0, ((size_t)s < real.size() ? real[(size_t)s] : 0) | (is_lean ? 0x100 : 0));
+    const int n_real = (size_t)s < real.size() ? real[(size_t)s] : 0;
+    const unsigned classes = ((unsigned)w0 >> 16) & CLASS_SET_MASK;
+    bool finite = plain_lean && root != nullptr && n_real > 0 && classes != 0 && (classes & (classes - 1)) == 0 && classes != (1u << K_HEAVY);
+    for (int l = 0; l < n_real && finite; ++l) {
+      const int4 r = packed[(size_t)s * 64 + (size_t)l];
+      for (int v : {r.y, r.z, r.w}) {
+        const tb_itv d = root[v];
+        if (d.lb < -(1 << 29) || d.ub > (1 << 29)) finite = false;
+      }
+    }
+    info[(size_t)s] = make_int2(w0, n_real | (is_lean ? 0x100 : 0) | (finite ? 0x200 : 0));
   }
   return info;
 }
@@ -606,7 +622,10 @@ int choose_layout(const tb_config& cfg, const DeviceCaps& caps, int32_t n_vars, 
   LaunchPlan pc;
   if ((rc = plan_launch(cfg, caps, lc, n_props, &pc)) != TB_OK) return rc;
   const bool forced = (cfg.reserved[0] & 0x100000) != 0;
-  if (forced || (plan->mem_kind == TB_MEM_GLOBAL && pc.mem_kind != TB_MEM_GLOBAL)) { *lay = std::move(lc); *plan = pc; }
+  // ... and when both layouts end up in global memory, the compact slab is taken if it is at most two thirds of the plain one: the
+  // workgroups' slabs then stay closer to the CUs (trains15: 2.04e7 nodes/s against 1.93e7)
+  const bool smaller_in_global = plan->mem_kind == TB_MEM_GLOBAL && pc.mem_kind == TB_MEM_GLOBAL && !cfg.only_global_memory && pc.vext * 3 < plan->vext * 2;
+  if (forced || (plan->mem_kind == TB_MEM_GLOBAL && pc.mem_kind != TB_MEM_GLOBAL) || smaller_in_global) { *lay = std::move(lc); *plan = pc; }
   return TB_OK;
 }
 
@@ -647,7 +666,8 @@ InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, c
   // The sort is stable, so the records of one constraint stay together inside their class.
   // Not for stores in global memory: those runs are bound by the memory system, not by VALU work, and the caller's
   // order carries locality (the 100k x 500k synthetic network is emitted in topological order: sorted, a node needs
-  // 20 % more sweeps and the event worklist twice the evaluations).
+  // 20 % more sweeps and the event worklist twice the evaluations; trains15 on compact slabs in global memory: 2.03e7 nodes/s in the
+  // caller's order, 1.96e7 sorted).
   if (keep_order) return n;
   auto key = [&](const tb_prop& q) {
     const tb_itv d = n.store[(size_t)q.x];
@@ -785,8 +805,10 @@ std::vector<int> real_lanes(const std::vector<tb_prop>& props, int n_slices) {
 }
 
 // Tables of the event-driven fixpoint (successor records, slice infos, variable adjacency): built from the packed records and uploaded.
+// `root`: the first store of the batch in the internal numbering (finite-domain test of the plain lean runs).
 int upload_event_tables(DevBuffers& bufs, DevProblem& P, const tb_config& cfg, const LaunchPlan& plan, const Layout& lay, int32_t n_rec,
-                        const std::vector<tb_prop>& net_props, const Adjacency& adj, const std::vector<int4>& packed, const std::vector<int>& value) {
+                        const std::vector<tb_prop>& net_props, const Adjacency& adj, const std::vector<int4>& packed, const std::vector<int>& value,
+                        const tb_itv* root) {
   int rc;
   const std::vector<int> real = real_lanes(net_props, plan.n_slices);
   int* d_real = nullptr;
@@ -801,7 +823,7 @@ int upload_event_tables(DevBuffers& bufs, DevProblem& P, const tb_config& cfg, c
   if ((rc = bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
   if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
   P.succ = d_succ;
-  const std::vector<int2> info = slice_infos(packed, real, plan.n_slices, lean);
+  const std::vector<int2> info = slice_infos(packed, real, plan.n_slices, lean, root, std::getenv("TB_NO_LEAN") == nullptr);
   if (std::getenv("TB_DUMP_SLICES") != nullptr)  // debugging aid
     for (int q = 0; q < plan.n_slices; ++q) {
       int prefix = 0, classed = 0;
@@ -905,7 +927,14 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     std::vector<int4> packed = pack_props(n_rec, net.props.data(), is_const, value, adj, lay.n_int);
     packed.resize((size_t)plan.n_slices * 64, make_int4(K_LEQ_T, 0, 0, 0));
     if (n_rec) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
-    if ((rc = upload_event_tables(bufs, P, cfg, plan, lay, n_rec, net.props, adj, packed, value)) != TB_OK) return rc;
+    // hull of the batch, internal numbering: what "finite domains" means for a batch of stores
+    std::vector<tb_itv> hull((size_t)std::max(1, n_vars));
+    for (int v = 0; v < n_vars; ++v) {
+      tb_itv h = stores_inout[v];
+      for (int32_t k = 1; k < n_stores; ++k) { const tb_itv d = stores_inout[(size_t)k * (size_t)n_vars + (size_t)v]; h.lb = std::min(h.lb, d.lb); h.ub = std::max(h.ub, d.ub); }
+      hull[(size_t)lay.perm[(size_t)v]] = h;
+    }
+    if ((rc = upload_event_tables(bufs, P, cfg, plan, lay, n_rec, net.props, adj, packed, value, hull.data())) != TB_OK) return rc;
   }
   P.n_slices = plan.n_slices; P.dirty_words = plan.dirty_words; P.vext = plan.vext; P.chg_cap = plan.chg_cap;
   P.n_int = plan.n_int; P.unent_off = plan.unent_off;
@@ -1037,7 +1066,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     std::vector<int4> packed = pack_props(n_rec, net.props.data(), is_const, value, adj, lay.n_int);
     packed.resize((size_t)plan.n_slices * 64, make_int4(K_LEQ_T, 0, 0, 0));
     if (n_rec) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
-    if ((rc = upload_event_tables(s->bufs, s->P, s->cfg, s->plan, s->lay, n_rec, net.props, adj, packed, value)) != TB_OK) return rc;
+    if ((rc = upload_event_tables(s->bufs, s->P, s->cfg, s->plan, s->lay, n_rec, net.props, adj, packed, value, net.store.data())) != TB_OK) return rc;
   }
   s->P.n_slices = s->plan.n_slices; s->P.dirty_words = s->plan.dirty_words; s->P.vext = s->plan.vext; s->P.chg_cap = s->plan.chg_cap;
   s->P.n_int = s->plan.n_int; s->P.unent_off = s->plan.unent_off;

@@ -409,6 +409,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
 struct EventState {
   unsigned* dirty;        // LDS: bitmap of the slices that must (re)run
   int* list;              // LDS: variables changed outside the fixpoint (decision, bound, replay)
+  const int4* succ;       // successor records: DevProblem::succ, or their copy in LDS (TCN_SHARED)
   unsigned char* unent;   // behind the store (LDS or HBM slab): one byte per slice for the sweeps (entailed-slice removal), one BIT per slice (32-bit words) for the event fixpoint
   int words, cap;
 };
@@ -582,6 +583,133 @@ __device__ __forceinline__ BoolRef bool_ref(int2* store, int ni, int v, bool act
 __device__ __forceinline__ unsigned bool_bits(const BoolRef r) { return (__hip_atomic_load(r.word, TB_RLX, TB_WG) >> r.shift) & 3u; }
 __device__ __forceinline__ void bool_or(const BoolRef r, unsigned bits) { (void)__hip_atomic_fetch_or(r.word, bits << r.shift, TB_RLX, TB_WG); }
 
+// ---- lean run of a class-pure slice ----------------------------------------------------------------------------------------------------
+//
+// The generic `apply` pays for generality at every pass: infinity cases and saturation in every sum, six candidate bounds
+// whatever the class, an emptiness check of all three inputs, per-bound counters.  A slice whose 64 records have ONE class and whose
+// operands all have finite root domains within +-2^29 (engine.hip: slice_infos, bit 9 of the info word -- domains only shrink, so
+// this holds in the whole tree) needs none of that: plain 32-bit arithmetic cannot overflow, a class body touches only the bounds
+// its rule can move, and an empty input needs no test -- whoever emptied a domain raised the failure flag when it did.  Same rules,
+// same fixpoint as `evaluate_packed`; what changed is kept as six lane masks (SGPR pairs) and turned into per-lane event bits once,
+// after the run.  One pass is ~25 VALU instead of ~90.
+// Returns the wave iterations; `nar_all`: bits 2k / 2k+1 = lower bound raised / upper bound lowered of operand k (0 x, 1 y, 2 z).
+// COMPACT layout: `kinds` (2 bits per operand, word0 bits 26-31 of the slice: 1 all integer variables, 2 all 2-bit Booleans, else mixed) picks
+// the cheapest way to read an operand -- a Boolean column is one ds_read_b32 and three VALU per pass, its word address and bit position
+// computed once per run.
+template <bool C>
+struct LeanOperand {
+  int v;            // variable (idle lanes: 0)
+  BoolRef b;        // COMPACT Boolean column: word and bit position
+};
+template <bool C>
+__device__ __forceinline__ LeanOperand<C> lean_operand(int2* store, int ni, int v, bool act, int kind) {
+  LeanOperand<C> o;
+  o.v = act ? v : 0;
+  if (C && kind == 2) o.b = bool_ref(store, ni, v, act);
+  return o;
+}
+template <bool C>
+__device__ __forceinline__ Itv lean_load(int2* store, int ni, const LeanOperand<C>& o, int kind) {
+  if (C && kind == 2) { const unsigned bits = bool_bits(o.b); Itv d; d.lb = (int)(bits & 1u); d.ub = 1 - (int)(bits >> 1); return d; }
+  if (C && kind != 1) return load_dom<true>(store, ni, o.v);
+  return load_dom<false>(store, ni, o.v);
+}
+template <bool C>
+__device__ __forceinline__ unsigned lean_class_run(const RunEnv& E, const int cls, const int kinds, const int4 pr, const bool act, int2* store, const int ni, unsigned& wave_writes, int& nar_all) {
+  const int lane = threadIdx.x & 63, s = E.s;
+  const int kx = kinds & 3, ky = (kinds >> 2) & 3, kz = (kinds >> 4) & 3;  // wave-uniform
+  const LeanOperand<C> ox = lean_operand<C>(store, ni, pr.y, act, kx), oy = lean_operand<C>(store, ni, pr.z, act, ky), oz = lean_operand<C>(store, ni, pr.w, act, kz);
+  const int vx = ox.v, vy = oy.v, vz = oz.v;  // idle lanes look at variable 0 (a constant) and move nothing
+  unsigned long long mxl = 0, mxu = 0, myl = 0, myu = 0, mzl = 0, mzu = 0;  // lanes that moved each bound during the run
+  unsigned iters = 0;
+  for (;;) {
+    const Itv X = lean_load<C>(store, ni, ox, kx), Y = lean_load<C>(store, ni, oy, ky), Z = lean_load<C>(store, ni, oz, kz);
+    int xl = X.lb, xu = X.ub, yl = Y.lb, yu = Y.ub, zl = Z.lb, zu = Z.ub;  // the new bounds: start from the current ones
+    bool ent;
+    if (cls == K_ADD) {
+      xl = imax(xl, Y.lb + Z.lb); xu = imin(xu, Y.ub + Z.ub);
+      yl = imax(yl, X.lb - Z.ub); yu = imin(yu, X.ub - Z.lb);
+      zl = imax(zl, X.lb - Y.ub); zu = imin(zu, X.ub - Y.lb);
+      ent = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub;
+    } else if (cls == K_LEQ_T) {
+      yu = imin(yu, Z.ub); zl = imax(zl, Y.lb);
+      ent = Y.ub <= Z.lb;
+    } else if (cls == K_LEQ_F) {
+      yl = imax(yl, Z.lb + 1); zu = imin(zu, Y.ub - 1);
+      ent = Y.lb > Z.ub;
+    } else if (cls == K_EQ_T) {
+      yl = imax(yl, Z.lb); yu = imin(yu, Z.ub); zl = imax(zl, Y.lb); zu = imin(zu, Y.ub);
+      ent = Y.lb == Y.ub && Z.lb == Z.ub;
+    } else if (cls == K_EQ_F) {
+      const bool ys = Y.lb == Y.ub, zs = Z.lb == Z.ub;
+      yl = sel(zs && Y.lb == Z.lb, Z.lb + 1, yl); yu = sel(zs && Y.ub == Z.lb, Z.lb - 1, yu);
+      zl = sel(ys && Z.lb == Y.lb, Y.lb + 1, zl); zu = sel(ys && Z.ub == Y.lb, Y.lb - 1, zu);
+      ent = Y.ub < Z.lb || Y.lb > Z.ub;
+    } else if (cls == K_MIN) {
+      xl = imax(xl, imin(Y.lb, Z.lb)); xu = imin(xu, imin(Y.ub, Z.ub));
+      yl = imax(yl, X.lb); zl = imax(zl, X.lb);
+      yu = sel(Z.lb > X.ub, imin(yu, X.ub), yu); zu = sel(Y.lb > X.ub, imin(zu, X.ub), zu);
+      ent = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub;
+    } else if (cls == K_MAX) {
+      xl = imax(xl, imax(Y.lb, Z.lb)); xu = imin(xu, imax(Y.ub, Z.ub));
+      yu = imin(yu, X.ub); zu = imin(zu, X.ub);
+      yl = sel(Z.ub < X.lb, imax(yl, X.lb), yl); zl = sel(Y.ub < X.lb, imax(zl, X.lb), zl);
+      ent = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub;
+    } else {  // K_LEQ_R, K_EQ_R: x is the truth value of the comparison
+      const bool t = X.lb >= 1, f = X.ub <= 0, u = !t && !f;
+      if (cls == K_LEQ_R) {
+        const bool le = Y.ub <= Z.lb, gt = Y.lb > Z.ub;
+        xl = sel(u && le, 1, xl); xu = sel(u && gt, 0, xu);
+        yu = sel(t, imin(yu, Z.ub), yu); zl = sel(t, imax(zl, Y.lb), zl);
+        yl = sel(f, imax(yl, Z.lb + 1), yl); zu = sel(f, imin(zu, Y.ub - 1), zu);
+        ent = (t && le) || (f && gt);
+      } else {
+        const bool ys = Y.lb == Y.ub, zs = Z.lb == Z.ub;
+        const bool disjoint = Y.ub < Z.lb || Y.lb > Z.ub, same = ys && zs && Y.lb == Z.lb;
+        xl = sel(u && same, 1, xl); xu = sel(u && disjoint, 0, xu);
+        yl = sel(t, imax(yl, Z.lb), sel(f && zs && Y.lb == Z.lb, Z.lb + 1, yl));
+        yu = sel(t, imin(yu, Z.ub), sel(f && zs && Y.ub == Z.lb, Z.lb - 1, yu));
+        zl = sel(t, imax(zl, Y.lb), sel(f && ys && Z.lb == Y.lb, Y.lb + 1, zl));
+        zu = sel(t, imin(zu, Y.ub), sel(f && ys && Z.ub == Y.lb, Y.lb - 1, zu));
+        ent = (t && same) || (f && disjoint);
+      }
+    }
+    ++iters;
+    const bool cxl = xl != X.lb, cxu = xu != X.ub, cyl = yl != Y.lb, cyu = yu != Y.ub, czl = zl != Z.lb, czu = zu != Z.ub;
+    const bool moved = act && (cxl | cxu | cyl | cyu | czl | czu);
+    if (!wave_any(moved)) {
+      // quiet pass: the local fixpoint is reached; the slice's "not entailed" bit only ever goes 1 -> 0 below a node
+      if (!wave_any(act && !ent) && lane == 0) (void)__hip_atomic_fetch_and(&E.unent[s >> 5], ~(1u << (s & 31)), TB_RLX, TB_WG);
+      break;
+    }
+    if (moved) {
+      if ((xl > xu) | (yl > yu) | (zl > zu)) st(&E.sh.bot, 1);
+      if (cxl) raise_lb<C>(store, ni, vx, xl);
+      if (cxu) lower_ub<C>(store, ni, vx, xu);
+      if (cyl) raise_lb<C>(store, ni, vy, yl);
+      if (cyu) lower_ub<C>(store, ni, vy, yu);
+      if (czl) raise_lb<C>(store, ni, vz, zl);
+      if (czu) lower_ub<C>(store, ni, vz, zu);
+    }
+    const unsigned long long bxl = wave_ballot(act && cxl), bxu = wave_ballot(act && cxu), byl = wave_ballot(act && cyl), byu = wave_ballot(act && cyu),
+                             bzl = wave_ballot(act && czl), bzu = wave_ballot(act && czu);
+    mxl |= bxl; mxu |= bxu; myl |= byl; myu |= byu; mzl |= bzl; mzu |= bzu;
+    wave_writes += (unsigned)(__builtin_popcountll(bxl) + __builtin_popcountll(bxu) + __builtin_popcountll(byl) + __builtin_popcountll(byu) +
+                              __builtin_popcountll(bzl) + __builtin_popcountll(bzu));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (ld(&E.sh.bot)) break;
+    if ((iters % WAVE_WATCHDOG_PERIOD) == 0) {  // watchdog inside the wave-local loop (see fixpoint)
+      if (lane == 0 && E.P.deadline_ticks != 0 && wall_clock64() > E.P.deadline_ticks) st(&E.sh.abort, 1);
+      if (ld(&E.sh.abort)) break;
+    }
+  }
+  if ((mxl | mxu | myl | myu | mzl | mzu) != 0ull) {
+    const unsigned long long me = 1ull << lane;
+    nar_all = ((mxl & me) ? 1 : 0) | ((mxu & me) ? 2 : 0) | ((myl & me) ? 4 : 0) | ((myu & me) ? 8 : 0) | ((mzl & me) ? 16 : 0) | ((mzu & me) ? 32 : 0);
+  }
+  return iters;
+}
+
 // Slice signatures with a dedicated run (word0 >> 16 of the slice's records: class set | operand kinds << 10; see pack_props).
 // kinds per operand: 0 mixed, 1 integer variables, 2 Booleans of the COMPACT layout, 3 constants.
 constexpr unsigned kinds(unsigned kx, unsigned ky, unsigned kz) { return (kx | (ky << 2) | (kz << 4)) << 10; }
@@ -721,17 +849,17 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       int s = next_slice();
 #if TB_SC_PREFETCH
       int4 sc_cur = make_int4(0, 0, 0, 0);
-      if (s >= 0) sc_cur = (glob(P.succ) + (size_t)s * 64)[lane];
+      if (s >= 0) sc_cur = (es.succ + (size_t)s * 64)[lane];
 #endif
       while (s >= 0) {
         const int s_next = next_slice();
 #if TB_SC_PREFETCH
         const int4 sc = sc_cur;
-        if (s_next >= 0) sc_cur = (glob(P.succ) + (size_t)s_next * 64)[lane];
+        if (s_next >= 0) sc_cur = (es.succ + (size_t)s_next * 64)[lane];
 #endif
         const int2 info = cst(P.slice_info)[s];
 #if !TB_SC_PREFETCH
-        const int4* const succ_slice = glob(P.succ) + (size_t)s * 64;  // uniform base + lane: no 64-bit VALU address arithmetic
+        const int4* const succ_slice = es.succ + (size_t)s * 64;  // uniform base + lane: no 64-bit VALU address arithmetic
 #endif
         if (dead_node(sh)) break;  // the node failed in another wave
         for (int rep = reps_of(P, 3); rep > 0; --rep) {
@@ -973,6 +1101,8 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               }
               un_i = act & !ent;
             });
+          } else if (info.y & 0x200) {
+            wave_iters = lean_class_run<C>(E, __builtin_ctz(key & CLASS_SET_MASK), (int)(key >> 10), pr, act, store, P.n_int, wave_writes, nar_all);
           } else {
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               apply<true, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, 0, &nar);
@@ -1074,6 +1204,7 @@ static __device__ TB_FIX_ATTR FpResult fixpoint_event_call(const DevProblem* Pp,
   const int4* props = MEM == TB_MEM_TCN_SHARED ? lds_ptr<const int4>(props_off) : glob(gprops);
   EventState es;
   es.dirty = lds_ptr<unsigned>(dirty_off); es.list = lds_ptr<int>(list_off);
+  es.succ = glob(constant_problem(Pp).succ);  // (outlined variants keep the successor records in global memory)
   es.unent = reinterpret_cast<unsigned char*>(store) + constant_problem(Pp).unent_off;
   es.words = constant_problem(Pp).dirty_words; es.cap = constant_problem(Pp).chg_cap;
   ThreadCounters tc;
@@ -1649,6 +1780,7 @@ static __device__ TB_NODE_ATTR unsigned propagate_node_event(const DevProblem* P
   best_store = glob(best_store);
   EventState es;
   es.dirty = lds_ptr<unsigned>(dirty_off); es.list = lds_ptr<int>(list_off);
+  es.succ = glob(constant_problem(Pp).succ);  // (outlined variants keep the successor records in global memory)
   es.unent = reinterpret_cast<unsigned char*>(store) + constant_problem(Pp).unent_off;
   es.words = constant_problem(Pp).dirty_words; es.cap = constant_problem(Pp).chg_cap;
   ThreadCounters tc;
@@ -1711,10 +1843,16 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   es.unent = reinterpret_cast<unsigned char*>(store) + P.unent_off;
   es.words = P.dirty_words; es.cap = P.chg_cap;
   const int4* props = glob(P.props);
+  es.succ = glob(P.succ);
   if (MEM == TB_MEM_TCN_SHARED) {
     int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + store_bytes + dirty_bytes);
     for (int i = tid; i < P.n_slices * 64; i += blockDim.x) lprops[i] = glob(P.props)[i];  // whole slices: the array is padded
     props = lprops;
+    if (EVENT) {  // the successor records too: a run then starts without a trip to L2
+      int4* lsucc = lprops + (size_t)P.n_slices * 64;
+      for (int i = tid; i < P.n_slices * 64; i += blockDim.x) lsucc[i] = glob(P.succ)[i];
+      es.succ = lsucc;
+    }
   }
   for (int i = tid; i < 2 * P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
   int2* snap = glob(P.g_snap) + (size_t)b * P.snapshot_levels * VX;
@@ -1913,10 +2051,16 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
   es.words = P.dirty_words; es.cap = P.chg_cap;
   for (int i = tid; i < 2 * P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
   const int4* props = P.props;
+  es.succ = P.succ;
   if (MEM == TB_MEM_TCN_SHARED) {
     int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + store_bytes + dirty_bytes);
     for (int i = tid; i < P.n_slices * 64; i += blockDim.x) lprops[i] = P.props[i];  // whole slices: the array is padded
     props = lprops;
+    if (EVENT) {
+      int4* lsucc = lprops + (size_t)P.n_slices * 64;
+      for (int i = tid; i < P.n_slices * 64; i += blockDim.x) lsucc[i] = P.succ[i];
+      es.succ = lsucc;
+    }
   }
   for (int s = blockIdx.x; s < n_stores; s += gridDim.x) {
     int2* gstore = stores + (size_t)s * VX;
