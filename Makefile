@@ -44,6 +44,14 @@ $(LIBDIR)/libturbo_hip_tuning.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DTB_TUNING -shared -o $@ $(HIP_SRC)
 
+# one library per phase of the event kernels, each the production kernels with exactly that phase executed twice (compile-time choice:
+# scripts/phase_budget.py measures the difference in SQ_INSTS_* to the production library)
+PHASES := 1 2 3 4 5 6 7 8 9 10 11 12 13 14
+phases: $(foreach n,$(PHASES),$(LIBDIR)/phases/phase_$(n).so)
+$(LIBDIR)/phases/phase_%.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)/phases
+	$(HIPCC) $(HIPFLAGS) -DTB_DOUBLE_PHASE=$* -shared -o $@ $(HIP_SRC)
+
 $(BINDIR)/turbo: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libturbo_front.so $(LIBDIR)/libturbo_hip.so
 	@mkdir -p $(BINDIR)
 	$(CXX) $(CXXFLAGS) -fPIE -o $@ $(HOST_SRC) -Iinclude -L$(LIBDIR) -lturbo_front -lturbo_hip -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(ROCM)/lib -lpthread
@@ -63,4 +71,4 @@ clean:
 	rm -rf $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all front hip cli oracle sanitize clean tuning
+.PHONY: all front hip cli oracle sanitize clean tuning phases

@@ -145,7 +145,7 @@ def reference_invocation(seconds: float) -> dict:
 def profile_figures(workload: str, fixpoint: str) -> dict | None:
     """Counter-derived figures of the same command, collected by scripts/profile_round.sh in separate rocprofv3 --pmc
     passes and committed under profiles/ (they are NOT measured in this run: the source file is named)."""
-    for name in ("r02_counters.json",):
+    for name in ("r03_counters.json", "r02_counters.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue

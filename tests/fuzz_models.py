@@ -135,3 +135,95 @@ def channelling_network(rng):
     st = np.array(store, dtype=ITV_DTYPE)
     pr = np.array([props[i] for i in order], dtype=PROP_DTYPE)
     return st, pr
+
+
+def finite_class_network(rng):
+    """Random SATISFIABLE network for the lean class runs of the event kernels (kernels.hpp: lean_class_run): a hidden solution, and a
+    few classes of constraints that hold in it, each with more than 64 records -- so that the engine's class sort (and padding) makes
+    class-pure slices -- over small finite integer domains, Booleans and constants: sums x = y + z (also with a constant sum,
+    `0 = y + z`, and with Boolean terms), min / max (also the clause `1 = max(b1, b2)`), y <= z, y > z, y = z, y != z, reified
+    comparisons between two variables and against constants, implications between Booleans.  Records share variables (defined
+    variables feed later records), so successor slots overflow and slices re-run each other."""
+    from turbo_amd.frontend import ITV_DTYPE, PROP_DTYPE
+    store = [(0, 0), (1, 1), (2, 2)]
+    val = [0, 1, 2]
+    const_of = {0: 0, 1: 1, 2: 2}
+
+    def new_var(lo, hi, v):
+        store.append((lo, hi)); val.append(v)
+        return len(store) - 1
+
+    def const(k):
+        if k not in const_of:
+            const_of[k] = new_var(k, k, k)
+        return const_of[k]
+    ints, bools = [], []
+    for _ in range(int(rng.integers(12, 40))):
+        lo = int(rng.integers(-20, 30)); hi = lo + int(rng.integers(0, 40))
+        ints.append(new_var(lo, hi, int(rng.integers(lo, hi + 1))))
+    for _ in range(int(rng.integers(10, 40))):
+        bools.append(new_var(0, 1, int(rng.integers(0, 2))))
+
+    def iv():
+        return int(rng.choice(ints))
+
+    def bv():
+        return int(rng.choice(bools))
+
+    def anyv():
+        r = rng.random()
+        return iv() if r < 0.6 else (bv() if r < 0.9 else const(int(rng.integers(-3, 8))))
+
+    def defined(v):  # a fresh integer variable whose hidden value is v
+        x = new_var(v - int(rng.integers(0, 12)), v + int(rng.integers(0, 12)), v)
+        ints.append(x)
+        return x
+
+    def truth(t):  # a fresh Boolean whose hidden value is t (sometimes an existing one that happens to agree)
+        if rng.random() < 0.2:
+            for _ in range(4):
+                b = bv()
+                if val[b] == int(t):
+                    return b
+        b = new_var(0, 1, int(t)); bools.append(b)
+        return b
+    props = []
+    kinds = rng.choice(["add", "add0", "addb", "minmax", "clause", "leq", "eq", "neq", "gt", "leq_r", "eq_r", "leq_rc", "impl"], size=int(rng.integers(2, 6)), replace=False)
+    for kind in kinds:
+        for _ in range(int(rng.integers(66, 150))):
+            if kind == "add":
+                y, z = anyv(), anyv(); props.append((0, defined(val[y] + val[z]), y, z))
+            elif kind == "add0":
+                y = iv(); props.append((0, 0, y, defined(-val[y])))            # 0 = y + z
+            elif kind == "addb":
+                y, z = bv(), bv(); props.append((0, defined(val[y] + val[z]), y, z))  # i = b1 + b2
+            elif kind == "minmax":
+                y, z = anyv(), anyv(); mx = int(rng.random() < 0.5)
+                props.append((5 if mx else 4, defined(max(val[y], val[z]) if mx else min(val[y], val[z])), y, z))
+            elif kind == "clause":
+                y, z = bv(), bv()
+                if val[y] or val[z]: props.append((5, 1, y, z))                 # 1 = max(b1, b2)
+            elif kind in ("leq", "gt", "impl"):
+                y, z = (bv(), bv()) if kind == "impl" else (anyv(), anyv())
+                if kind == "gt":
+                    if val[y] == val[z]: continue
+                    if val[y] < val[z]: y, z = z, y
+                    props.append((7, 0, y, z))
+                else:
+                    if val[y] > val[z]: y, z = z, y
+                    props.append((7, 1, y, z))
+            elif kind == "eq":
+                y = anyv(); props.append((6, 1, y, defined(val[y])))
+            elif kind == "neq":
+                y, z = anyv(), anyv()
+                if val[y] != val[z]: props.append((6, 0, y, z))
+            elif kind == "leq_r":
+                y, z = iv(), iv(); props.append((7, truth(val[y] <= val[z]), y, z))
+            elif kind == "eq_r":
+                y, z = iv(), anyv(); props.append((6, truth(val[y] == val[z]), y, z))
+            else:  # leq_rc
+                y = iv(); k = int(rng.integers(-20, 60)); props.append((7, truth(val[y] <= k), y, const(k)))
+    order = rng.permutation(len(props))
+    st = np.array(store, dtype=ITV_DTYPE)
+    pr = np.array([props[i] for i in order], dtype=PROP_DTYPE)
+    return st, pr

@@ -256,6 +256,44 @@ def test_channelling_networks_bit_exact(mode):
                 np.testing.assert_array_equal(got[i], exp, err_msg=f"seed {seed} store {i}")
 
 
+@pytest.mark.parametrize("mode", ["wac1", "event", "event_compact", "event_globalmem", "event_compact_globalmem"])
+def test_class_pure_finite_networks_bit_exact(mode):
+    """Fuzz of the lean runs of the event kernels: class-pure slices over finite domains in the plain and in the compact layout
+    (lean_class_run), Boolean implication slices read from their successor records alone (compact), stores in LDS and in
+    global memory.  Root and random nodes of 60 networks against the oracle, bit for bit."""
+    from fuzz_models import finite_class_network
+    cfg = {"wac1": dict(fixpoint=1), "event": dict(fixpoint=2), "event_compact": dict(fixpoint=2, debug=COMPACT),
+           "event_globalmem": dict(fixpoint=2, only_global_memory=1), "event_compact_globalmem": dict(fixpoint=2, debug=COMPACT, only_global_memory=1)}[mode]
+    for seed in range(60):
+        rng = np.random.default_rng(5000 + seed)
+        store, props = finite_class_network(rng)
+        root, failed, _, _, _ = pyoracle.propagate(store, props)
+        stores = [store]
+        for _ in range(7):
+            s = (store if failed or rng.random() < 0.3 else root).copy()
+            for v in rng.choice(np.arange(3, s.shape[0]), size=min(int(rng.integers(1, 8)), s.shape[0] - 3), replace=False):
+                lo, hi = int(s["lb"][v]), int(s["ub"][v])
+                if lo >= hi:
+                    continue
+                m = int(rng.integers(lo, hi + 1))
+                r = rng.random()
+                if r < 0.4:
+                    s["ub"][v] = m
+                elif r < 0.8:
+                    s["lb"][v] = m
+                else:
+                    s["lb"][v] = s["ub"][v] = m
+            stores.append(s)
+        stores = np.stack(stores)
+        got, gfailed, ent, _, _, _ = capi.propagate(props, stores, capi.make_config(timeout_ms=20000, **cfg))
+        for i in range(stores.shape[0]):
+            exp, efailed, eent, _, _ = pyoracle.propagate(stores[i], props)
+            assert bool(gfailed[i]) == efailed, (seed, i)
+            if not efailed:
+                assert bool(ent[i]) == eent, (seed, i)
+                np.testing.assert_array_equal(got[i], exp, err_msg=f"seed {seed} store {i}")
+
+
 @pytest.mark.parametrize("cfg,event,opt", [(dict(fixpoint=1), 0, 0), (dict(fixpoint=0), 0, 0), (dict(fixpoint=1, entailed_prop_removal=1), 0, 1),
                                            (dict(fixpoint=0, entailed_prop_removal=1), 0, 1), (dict(fixpoint=2), 1, 0), (dict(fixpoint=2, debug=COMPACT), 1, 1)],
                          ids=["wac1", "ac1", "wac1_rm", "ac1_rm", "event", "event_compact"])

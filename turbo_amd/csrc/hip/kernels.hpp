@@ -117,8 +117,22 @@ __device__ __forceinline__ constexpr int knobs(const DevProblem&) { return 0; }
 // that the difference in SQ_INSTS_VALU / SQ_INSTS_SALU to an undoubled run is that phase's instruction count
 // (scripts/phase_budget.py): 1 seeding from the change list, 2 round scan, 3 a whole slice run (fetch + dispatch + set-up + one
 // evaluation pass + the early-out of the marks), 4 witness test, 5 variable-selection scan, 6 restore copy, 7 dirty-bitmap clear,
-// 8 best-store copy.  (0x1: successor marks, 0x4: snapshot push, 0x8: one evaluation pass -- older knobs.)
-__device__ __forceinline__ int reps_of(const DevProblem& P, int phase) { return ((knobs(P) >> 8) & 0xff) == phase ? 2 : 1; }
+// 8 best-store copy, 9 the prologue of a run outside the doubled part (scalar info load, record base, failure check), 10 the end of a round.  (0x1: successor marks, 0x4: snapshot push, 0x8: one evaluation pass -- older knobs.)
+// For the instruction budget of profiles/ the doubled phase is chosen at COMPILE time (-DTB_DOUBLE_PHASE=n, `make phases`: one library per
+// phase, each the production kernels with exactly that phase executed twice): run-time knobs in the hot loops changed the kernel they were
+// meant to measure (14.5k VALU per node with them against 11.3k without).  Phases 11 / 12 / 13 / 14 = the older knobs 0x1 (marks), 0x4
+// (snapshot push), 0x8 (one evaluation pass), 0x400000 (count slice runs instead of wave iterations).
+#ifndef TB_DOUBLE_PHASE
+#define TB_DOUBLE_PHASE 0
+#endif
+#ifdef TB_TUNING
+__device__ __forceinline__ int pk(const DevProblem& P) { return P.debug; }
+#else
+__device__ __forceinline__ constexpr int pk(const DevProblem&) {
+  return TB_DOUBLE_PHASE == 11 ? 0x1 : (TB_DOUBLE_PHASE == 12 ? 0x4 : (TB_DOUBLE_PHASE == 13 ? 0x8 : (TB_DOUBLE_PHASE == 14 ? 0x400000 : (TB_DOUBLE_PHASE << 8))));
+}
+#endif
+__device__ __forceinline__ int reps_of(const DevProblem& P, int phase) { return ((pk(P) >> 8) & 0xff) == phase ? 2 : 1; }
 
 // LDS pointers across a call boundary: a pointer argument of a non-inlined function is GENERIC (flat_load / flat_atomic, both
 // counters, an aperture check per access) unless its address space travels with it.  The outlined functions below take 32-bit LDS
@@ -510,7 +524,7 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
       if (ld(&E.sh.abort)) break;
     }
   }
-  if (knobs(P) & 0x8) { bool ch = false, un_i = false; int nar = 0; eval(ch, un_i, nar); nar_all |= nar; }  // tuning: cost of one iteration
+  if (pk(P) & 0x8) { bool ch = false, un_i = false; int nar = 0; eval(ch, un_i, nar); nar_all |= nar; }  // tuning: cost of one iteration
   return wave_iters;
 }
 
@@ -797,7 +811,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     unsigned* cur = es.dirty + (rounds & 1) * W;
     unsigned* nxt = es.dirty + ((rounds + 1) & 1) * W;
     bool marked = false;  // wave-uniform: this wave marked something for the next round
-#ifdef TB_TUNING
+#if defined(TB_TUNING) || TB_DOUBLE_PHASE
     if (reps_of(P, 2) > 1)
       for (int base = 0; base < W; base += 64) {  // the scan once more, without clearing anything
         const int wi = base + lane;
@@ -862,6 +876,15 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
         const int4* const succ_slice = es.succ + (size_t)s * 64;  // uniform base + lane: no 64-bit VALU address arithmetic
 #endif
         if (dead_node(sh)) break;  // the node failed in another wave
+#if defined(TB_TUNING) || TB_DOUBLE_PHASE
+        if (reps_of(P, 9) > 1) {  // (tuning: the part of a run's prologue that sits outside the doubled run -- scalar info load, record base, failure check)
+          const DevProblem* p2 = &P; asm volatile("" : "+s"(p2));
+          const int2 i2 = cst(p2->slice_info)[s];
+          const int4* b2 = es.succ + (size_t)s * 64;
+          asm volatile("" :: "s"(i2.x), "s"(i2.y), "s"(b2));
+          if (dead_node(sh)) break;
+        }
+#endif
         for (int rep = reps_of(P, 3); rep > 0; --rep) {
           const bool act = lane < (info.y & 0xff);
 #if !TB_SC_PREFETCH
@@ -899,7 +922,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
               if (ld(&sh.bot)) break;
             }
-            if (rep == reps_of(P, 3)) wave_iters_total += (knobs(P) & 0x400000) ? 1u : iters;
+            if (rep == reps_of(P, 3)) wave_iters_total += (pk(P) & 0x400000) ? 1u : iters;
 #ifdef TB_TUNING
             if (prof && wave == 0) {
               const long long t_ = clock64();
@@ -907,12 +930,12 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               tprof = t_;
             }
 #endif
-            if (knobs(P) & 0x8) {  // tuning: one more (quiet) pass
+            if (pk(P) & 0x8) {  // tuning: one more (quiet) pass
               const unsigned yb = (__hip_atomic_load(wy, TB_RLX, TB_WG) >> ys) & 3u, zb = (__hip_atomic_load(wz, TB_RLX, TB_WG) >> zs) & 3u;
               const unsigned long long again = wave_ballot(act && ((zb & ~yb & 2u) | (yb & ~zb & 1u)) != 0u);
               asm volatile("" :: "s"(again));
             }
-            for (int mrep = (knobs(P) & 0x1) ? 2 : 1; mrep > 0; --mrep)
+            for (int mrep = (pk(P) & 0x1) ? 2 : 1; mrep > 0; --mrep)
             if ((ny_acc | nz_acc) != 0ull) {
               // successors: the slots hold the readers interested in exactly these events (y.ub lowered / z.lb raised), pre-filtered
               const bool my_ny = ((ny_acc >> lane) & 1ull) != 0ull, my_nz = ((nz_acc >> lane) & 1ull) != 0ull;
@@ -941,7 +964,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             continue;
           }
           const int4 pr_first = props[s * 64 + lane];  // the arrays are padded to whole slices
-#ifdef TB_TUNING
+#if defined(TB_TUNING) || TB_DOUBLE_PHASE
           int4 pr_again = pr_first;
           if (rep == 1 && reps_of(P, 3) > 1) { const int4* pp = props + (s * 64 + lane); asm volatile("" : "+v"(pp)); pr_again = *pp; if (dead_node(sh)) break; }
           const int4 pr = pr_again;
@@ -1123,25 +1146,27 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
 #endif
           TB_PROF_MARK(2);
           TB_PROF_COUNT(4);
-          if (knobs(P) & 0x1) marked |= mark_successors(P, nxt, s, pr, sc, nar_all);  // tuning: cost of the marks (idempotent)
+          if (pk(P) & 0x1) marked |= mark_successors(P, nxt, s, pr, sc, nar_all);  // tuning: cost of the marks (idempotent)
           tc.writes += run_writes;
           {  // profiling (tuning build): 0x400000 counts slice runs instead of iterations; bits 28-31 = 1 + class to count only that class (11 = mixed slices)
             const int want = (knobs(P) >> 28) & 15;
             const unsigned cm = key & CLASS_SET_MASK;
             const int cls_of_slice = (cm & (cm - 1)) ? 10 : __builtin_ctz(cm | 0x400u);
             const bool useless = !wave_any(nar_all != 0);  // the run narrowed nothing
-            if (rep == reps_of(P, 3) && (want == 0 || want - 1 == cls_of_slice) && (!(knobs(P) & 0x40) || useless)) wave_iters_total += (knobs(P) & 0x400000) ? 1u : wave_iters;  // 0x40: only the runs that narrowed nothing
+            if (rep == reps_of(P, 3) && (want == 0 || want - 1 == cls_of_slice) && (!(knobs(P) & 0x40) || useless)) wave_iters_total += (pk(P) & 0x400000) ? 1u : wave_iters;  // 0x40: only the runs that narrowed nothing
           }
         }
         s = s_next;
       }
     }
+    for (int rep = reps_of(P, 10); rep > 0; --rep) {  // (tuning: the end of a round twice -- flag, reset, barrier)
     if (lane == 0 && marked) st(&sh.flag[k], 1);
     if (tid == 0) {
       st(&sh.flag[(k + 1) % 3], 0);
       if ((rounds & 255) == 255 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
     }
     __syncthreads();  // the narrowings and the marks of this round are visible to everybody
+    }
     TB_PROF_MARK(3);
     TB_PROF_COUNT(5);
     if (!ld(&sh.flag[k]) || dead_node(sh)) break;
@@ -1946,7 +1971,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
           long long tp = 0;
           if (prof && tid == 0) tp = wall_clock64();
           if (d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * VX, store, VX);  // d0 == 0: barebones:785-791
-          if ((knobs(P) & 0x4) && d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * VX, store, VX);  // tuning: cost of the snapshot
+          if ((pk(P) & 0x4) && d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * VX, store, VX);  // tuning: cost of the snapshot
           if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
           __syncthreads();
           if (prof && tid == 0) { const long long t = wall_clock64(); bs.timers[TB_T_PREPROCESSING] += t - tp; tp = t; }  // profiling: snapshot push
