@@ -137,6 +137,96 @@ def test_solution_counts_match_brute_force(name, xml, expected):
     assert n == expected
 
 
+def _regular_ok(word):  # the automaton of the test below: a+ b+ over {0 (a), 1 (b)}, ending in state f
+    st = "s"
+    for c in word:
+        st = {("s", 0): "a", ("a", 0): "a", ("a", 1): "f", ("f", 1): "f"}.get((st, c))
+        if st is None:
+            return False
+    return st == "f"
+
+
+def _circuit_ok(x):  # sub-circuit: x_i = i are loops outside; the others form one cycle
+    n = len(x)
+    if sorted(x) != list(range(n)):
+        return False
+    inside = [i for i in range(n) if x[i] != i]
+    if not inside:
+        return False
+    seen, i = set(), inside[0]
+    while i not in seen:
+        seen.add(i); i = x[i]
+    return seen == set(inside)
+
+
+@pytest.mark.parametrize("name,xml,expected", [
+    ("alldiff_except", inst('<array id="a" size="[3]"> 0..3 </array>', "<allDifferent><list> a[] </list><except> 0 </except></allDifferent>"),
+     count(lambda a, b, c: all(p != q or p == 0 for p, q in ((a, b), (a, c), (b, c))), *[range(4)] * 3)),
+    ("alldiff_lists", inst('<array id="m" size="[2][2]"> 0..1 </array><array id="r" size="[2]"> 0..1 </array>',
+                           "<allDifferent><list> m[0][] </list><list> m[1][] </list><list> r[] </list></allDifferent>"),
+     count(lambda a, b, c, d, e, f: len({(a, b), (c, d), (e, f)}) == 3, *[range(2)] * 6)),
+    ("alldiff_matrix", inst('<array id="m" size="[2][3]"> 0..2 </array>', "<allDifferent><matrix> m[][] </matrix></allDifferent>"),
+     count(lambda a, b, c, d, e, f: len({a, b, c}) == 3 and len({d, e, f}) == 3 and a != d and b != e and c != f, *[range(3)] * 6)),
+    ("ordered_lengths", inst('<array id="s" size="[3]"> 0..6 </array>', "<ordered><list> s[] </list><lengths> 2 3 </lengths><operator> le </operator></ordered>"),
+     count(lambda a, b, c: a + 2 <= b and b + 3 <= c, *[range(7)] * 3)),
+    ("lex_lists", inst('<array id="x" size="[2]"> 0..2 </array><array id="y" size="[2]"> 0..2 </array><array id="z" size="[2]"> 0..2 </array>',
+                       "<lex><list> x[] </list><list> y[] </list><list> z[] </list><operator> lt </operator></lex>"),
+     count(lambda a, b, c, d, e, f: (a, b) < (c, d) < (e, f), *[range(3)] * 6)),
+    ("lex_matrix", inst('<array id="m" size="[2][2]"> 0..2 </array>', "<lex><matrix> m[][] </matrix><operator> ge </operator></lex>"),
+     count(lambda a, b, c, d: (a, b) >= (c, d) and (a, c) >= (b, d), *[range(3)] * 4)),
+    ("sum_var_coeffs_in", inst('<array id="a" size="[2]"> 0..3 </array><array id="w" size="[2]"> 1..2 </array>',
+                               "<sum><list> a[] </list><coeffs> w[] </coeffs><condition> (in,3..5) </condition></sum>"
+                               "<sum><list> a[0] a[1] </list><condition> (notin,{1,4}) </condition></sum>"),
+     count(lambda a, b, u, v: 3 <= a * u + b * v <= 5 and a + b not in (1, 4), range(4), range(4), range(1, 3), range(1, 3))),
+    ("nvalues", inst('<array id="a" size="[4]"> 0..3 </array><var id="k"> 1..4 </var>',
+                     "<nValues><list> a[] </list><condition> (eq,k) </condition></nValues>"
+                     "<nValues><list> a[0..2] </list><except> 0 </except><condition> (le,1) </condition></nValues>"),
+     count(lambda a, b, c, d, k: len({a, b, c, d}) == k and len({a, b, c} - {0}) <= 1, *([range(4)] * 4 + [range(1, 5)]))),
+    ("cardinality", inst('<array id="a" size="[4]"> 0..3 </array><var id="o"> 0..4 </var>',
+                         '<cardinality><list> a[] </list><values closed="true"> 0 1 2 </values><occurs> 1..2 o 1 </occurs></cardinality>'),
+     count(lambda a, b, c, d, o: all(v in (0, 1, 2) for v in (a, b, c, d)) and 1 <= [a, b, c, d].count(0) <= 2 and [a, b, c, d].count(1) == o and [a, b, c, d].count(2) == 1,
+           *([range(4)] * 4 + [range(5)]))),
+    ("element_matrix", inst('<var id="i"> 0..2 </var><var id="j"> 0..2 </var><var id="v"> 0..9 </var>',
+                            "<element><matrix> (1,2,3)(4,5,6) </matrix><index> i j </index><value> v </value></element>"),
+     count(lambda i, j, v: i < 2 and [[1, 2, 3], [4, 5, 6]][i][j] == v, range(3), range(3), range(10))),
+    ("nooverlap_2d", inst('<array id="x" size="[2]"> 0..3 </array><array id="y" size="[2]"> 0..3 </array>',
+                          "<noOverlap><origins> (x[0],y[0])(x[1],y[1]) </origins><lengths> (2,1)(1,3) </lengths></noOverlap>"),
+     count(lambda a, b, c, d: a + 2 <= b or b + 1 <= a or c + 1 <= d or d + 3 <= c, *[range(4)] * 4)),
+    ("cumulative_variable", inst('<array id="s" size="[2]"> 0..3 </array><array id="l" size="[2]"> 1..2 </array><var id="h"> 1..3 </var><array id="e" size="[2]"> 0..5 </array>',
+                                 "<cumulative><origins> s[] </origins><lengths> l[] </lengths><ends> e[] </ends><heights> 2 h </heights><condition> (le,3) </condition></cumulative>"),
+     count(lambda s0, s1, l0, l1, h, e0, e1: e0 == s0 + l0 and e1 == s1 + l1 and all((2 if s0 <= t < s0 + l0 else 0) + (h if s1 <= t < s1 + l1 else 0) <= 3 for t in range(6)),
+           range(4), range(4), range(1, 3), range(1, 3), range(1, 4), range(6), range(6))),
+    ("binpacking_condition", inst('<array id="b" size="[3]"> 0..1 </array>', "<binPacking><list> b[] </list><sizes> 2 3 4 </sizes><condition> (le,5) </condition></binPacking>"),
+     count(lambda a, b, c: all(sum(sz for sz, bn in zip((2, 3, 4), (a, b, c)) if bn == k) <= 5 for k in (0, 1)), *[range(2)] * 3)),
+    ("binpacking_loads", inst('<array id="b" size="[3]"> 0..1 </array><array id="ld" size="[2]"> 0..9 </array>',
+                              "<binPacking><list> b[] </list><sizes> 2 3 4 </sizes><loads> ld[] </loads></binPacking>"),
+     count(lambda a, b, c, l0, l1: sum(sz for sz, bn in zip((2, 3, 4), (a, b, c)) if bn == 0) == l0 and sum(sz for sz, bn in zip((2, 3, 4), (a, b, c)) if bn == 1) == l1,
+           *([range(2)] * 3 + [range(10)] * 2))),
+    ("knapsack", inst('<array id="q" size="[3]"> 0..2 </array><var id="p"> 0..20 </var>',
+                      "<knapsack><list> q[] </list><weights> 2 3 4 </weights><condition> (le,7) </condition><profits> 3 4 6 </profits><condition> (eq,p) </condition></knapsack>"),
+     count(lambda a, b, c, p: 2 * a + 3 * b + 4 * c <= 7 and 3 * a + 4 * b + 6 * c == p, *([range(3)] * 3 + [range(21)]))),
+    ("regular", inst('<array id="w" size="[4]"> 0..1 </array>',
+                     "<regular><list> w[] </list><transitions> (s,0,a)(a,0,a)(a,1,f)(f,1,f) </transitions><start> s </start><final> f </final></regular>"),
+     count(lambda a, b, c, d: _regular_ok((a, b, c, d)), *[range(2)] * 4)),
+    ("mdd", inst('<array id="w" size="[3]"> 0..2 </array>',
+                 "<mdd><list> w[] </list><transitions> (r,0,n1)(r,1,n2)(n1,2,n3)(n2,0,n3)(n2,1,n4)(n3,1,t)(n4,2,t) </transitions></mdd>"),
+     count(lambda a, b, c: (a, b, c) in {(0, 2, 1), (1, 0, 1), (1, 1, 2)}, *[range(3)] * 3)),
+    ("clause_slide", inst('<array id="b" size="[4]"> 0..1 </array>',
+                          "<clause> b[0] not(b[1]) b[2] </clause><slide><list> b[] </list><intension> le(%0,%1) </intension></slide>"),
+     count(lambda a, b, c, d: (a or not b or c) and a <= b <= c <= d, *[range(2)] * 4)),
+    ("circuit", inst('<array id="x" size="[4]"> 0..3 </array>', "<circuit> x[] </circuit>"),
+     count(lambda a, b, c, d: _circuit_ok((a, b, c, d)), *[range(4)] * 4)),
+    ("circuit_size", inst('<array id="x" size="[4]"> 0..3 </array>', "<circuit><list> x[] </list><size> 3 </size></circuit>"),
+     count(lambda a, b, c, d: _circuit_ok((a, b, c, d)) and sum(v != i for i, v in enumerate((a, b, c, d))) == 3, *[range(4)] * 4)),
+    ("array_cell_domains", inst('<array id="a" size="[3]"><domain for="a[0]"> 1 3 </domain><domain for="others"> 0..1 </domain></array>',
+                                "<intension> lt(a[1],a[0]) </intension>"),
+     count(lambda a, b, c: b < a, (1, 3), range(2), range(2))),
+])
+def test_solution_counts_of_the_wider_constraint_set(name, xml, expected):
+    n, m, tcn = solutions(xml)
+    assert n == expected
+
+
 def test_objectives():
     v = '<array id="a" size="[3]"> 0..4 </array>'
     c = "<allDifferent> a[] </allDifferent><sum><list> a[] </list><condition> (ge,7) </condition></sum>"
@@ -148,10 +238,15 @@ def test_objectives():
         min(max(t) for t in itertools.permutations(range(5), 3) if sum(t) >= 7)
     assert optimum(inst(v, c, '<objectives><maximize type="minimum"> a[0] a[1] </maximize></objectives>'))[0] == \
         max(min(t[0], t[1]) for t in itertools.permutations(range(5), 3) if sum(t) >= 7)
+    assert optimum(inst(v, c, '<objectives><minimize type="product"> a[0] a[1] </minimize></objectives>'))[0] == \
+        min(t[0] * t[1] for t in itertools.permutations(range(5), 3) if sum(t) >= 7)
+    c2 = "<sum><list> a[] </list><condition> (ge,7) </condition></sum>"
+    assert optimum(inst(v, c2, '<objectives><minimize type="nValues"> a[] </minimize></objectives>'))[0] == \
+        min(len(set(t)) for t in itertools.product(range(5), repeat=3) if sum(t) >= 7)
 
 
 def test_unsupported_and_malformed_inputs_are_reported():
-    for bad in ["<instance><variables><var id='x'> 0..2 </var></variables><constraints><circuit> x </circuit></constraints></instance>",
+    for bad in ["<instance><variables><var id='x'> 0..2 </var></variables><constraints><precedence> x </precedence></constraints></instance>",
                 "<instance><variables><var id='x'> 0..2 </var></variables><constraints><intension> eq(y,1) </intension></constraints></instance>",
                 "<instance><variables><var id='x'> 0..2 </variables></instance>",
                 "<nothing/>"]:
