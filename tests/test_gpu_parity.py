@@ -21,6 +21,7 @@ FAST = [r for r in ROWS if r[0] not in SLOW_FOR_ORACLE]
 HEADLINE = ["example_wordpress7_500.fzn", "accap_a3.fzn", "trains15.fzn",
             "unsolved_bugs_data/bigdom.fzn"]  # bigdom: objective near 2^31 (the reference lists it as an unsolved 32-bit hazard)
 COMPACT = 0x100000  # tb_config.reserved[0]: force the 2-bit Boolean store layout of the event kernels
+COMPACT16 = COMPACT | 0x10000000  # ... and its 16-bit integer tier when every non-Boolean variable fits (COMPACT otherwise)
 
 
 def load(rel):
@@ -73,7 +74,7 @@ def check_batch(tcn, stores, **cfg):
 
 
 @pytest.mark.parametrize("rel", [r[0] for r in ROWS] + HEADLINE)
-@pytest.mark.parametrize("fixpoint,debug", [(0, 0), (1, 0), (2, 0), (2, COMPACT)], ids=["ac1", "wac1", "event", "event_compact"])
+@pytest.mark.parametrize("fixpoint,debug", [(0, 0), (1, 0), (2, 0), (2, COMPACT), (2, COMPACT16)], ids=["ac1", "wac1", "event", "event_compact", "event_compact16"])
 def test_root_fixpoint_bit_exact(rel, fixpoint, debug):
     tcn = load(rel)
     check_batch(tcn, tcn.store[None, :], fixpoint=fixpoint, debug=debug)
@@ -106,7 +107,7 @@ def test_wordpress_nodes_bit_exact():
     check_batch(tcn, stores, fixpoint=2, debug=0x80000)  # the same without it
 
 
-@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT), (1, "rm"), (0, "rm")], ids=["wac1", "event", "event_compact", "wac1_rm", "ac1_rm"])
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT), (1, "rm"), (0, "rm"), (2, COMPACT16)], ids=["wac1", "event", "event_compact", "wac1_rm", "ac1_rm", "event_compact16"])
 @pytest.mark.parametrize("rel,expected", FAST)
 def test_sequential_tree_identical(rel, expected, fixpoint, debug):
     rm, debug = (1, 0) if debug == "rm" else (0, debug)
@@ -138,7 +139,7 @@ def test_sequential_eps_identical(rel, power, fixpoint, levels, debug):
     np.testing.assert_array_equal(best_g, best_o)
 
 
-@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT), (1, "rm")], ids=["wac1", "event", "event_compact", "wac1_rm"])
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT), (1, "rm"), (2, COMPACT16)], ids=["wac1", "event", "event_compact", "wac1_rm", "event_compact16"])
 @pytest.mark.parametrize("rel,expected", ROWS)
 def test_parallel_objective_matches_known_answer(rel, expected, fixpoint, debug):
     rm, debug = (1, 0) if debug == "rm" else (0, debug)
@@ -216,7 +217,7 @@ def test_random_networks_with_wide_and_infinite_domains(mode):
                 np.testing.assert_array_equal(got[i], exp, err_msg=f"seed {seed} store {i}")
 
 
-@pytest.mark.parametrize("mode", ["wac1", "event", "event_compact", "event_compact_unsorted"])
+@pytest.mark.parametrize("mode", ["wac1", "event", "event_compact", "event_compact_unsorted", "event_compact16"])
 def test_channelling_networks_bit_exact(mode):
     """Fuzz of the jointly evaluated channelling slices: consecutive constants (bit-scan walks), gaps and duplicates (stepping
     walks), shared truth variables (confirmation pass), several groups per slice, readers dealt over a group's lanes, successor
@@ -225,7 +226,7 @@ def test_channelling_networks_bit_exact(mode):
     # (unsorted: the records keep the caller's order inside a class, test knob 0x8000000 -- a y may come back after another one
     #  inside a slice, which the joint evaluation does not handle: such slices must fall back to the generic run)
     cfg = {"wac1": dict(fixpoint=1), "event": dict(fixpoint=2), "event_compact": dict(fixpoint=2, debug=COMPACT),
-           "event_compact_unsorted": dict(fixpoint=2, debug=COMPACT | 0x8000000)}[mode]
+           "event_compact_unsorted": dict(fixpoint=2, debug=COMPACT | 0x8000000), "event_compact16": dict(fixpoint=2, debug=COMPACT16)}[mode]
     for seed in range(60):
         rng = np.random.default_rng(1000 + seed)
         store, props = channelling_network(rng)
@@ -256,14 +257,15 @@ def test_channelling_networks_bit_exact(mode):
                 np.testing.assert_array_equal(got[i], exp, err_msg=f"seed {seed} store {i}")
 
 
-@pytest.mark.parametrize("mode", ["wac1", "event", "event_compact", "event_globalmem", "event_compact_globalmem"])
+@pytest.mark.parametrize("mode", ["wac1", "event", "event_compact", "event_globalmem", "event_compact_globalmem", "event_compact16", "event_compact16_globalmem"])
 def test_class_pure_finite_networks_bit_exact(mode):
     """Fuzz of the lean runs of the event kernels: class-pure slices over finite domains in the plain and in the compact layout
     (lean_class_run), Boolean implication slices read from their successor records alone (compact), stores in LDS and in
     global memory.  Root and random nodes of 60 networks against the oracle, bit for bit."""
     from fuzz_models import finite_class_network
     cfg = {"wac1": dict(fixpoint=1), "event": dict(fixpoint=2), "event_compact": dict(fixpoint=2, debug=COMPACT),
-           "event_globalmem": dict(fixpoint=2, only_global_memory=1), "event_compact_globalmem": dict(fixpoint=2, debug=COMPACT, only_global_memory=1)}[mode]
+           "event_globalmem": dict(fixpoint=2, only_global_memory=1), "event_compact_globalmem": dict(fixpoint=2, debug=COMPACT, only_global_memory=1),
+           "event_compact16": dict(fixpoint=2, debug=COMPACT16), "event_compact16_globalmem": dict(fixpoint=2, debug=COMPACT16, only_global_memory=1)}[mode]
     for seed in range(60):
         rng = np.random.default_rng(5000 + seed)
         store, props = finite_class_network(rng)

@@ -87,14 +87,17 @@ struct LaunchPlan {
 // converted at the boundary (encode_slab / decode_slab).  Without COMPACT the numbering is the caller's.
 struct Layout {
   bool compact = false;
+  bool c16 = false;  // COMPACT16: the non-Boolean variables as two 16-bit bounds in one word (kernels.hpp: load_dom<2>)
   int n_vars = 0, n_int = 0, n_bool = 0;
   std::vector<int> perm, inv;  // perm[caller's id] = internal id, inv = its inverse
   int bool_words() const { return (n_bool + 15) / 16; }
-  int unent_off() const { return n_int * 8 + bool_words() * 4; }
+  int int_bytes() const { return c16 ? 4 : 8; }
+  int bool_word0() const { return c16 ? n_int : 2 * n_int; }  // first Boolean word, in 32-bit words from the start of the slab
+  int unent_off() const { return n_int * int_bytes() + bool_words() * 4; }
   int vext(int n_slices) const { return (int)((((size_t)unent_off() + (size_t)std::max(n_slices, 4) + 15) / 16) * 2); }  // (>= one 32-bit word of entailment bits)
 };
 
-Layout make_layout(int32_t n_vars, int32_t n_stores, const tb_itv* stores, bool compact) {
+Layout make_layout(int32_t n_vars, int32_t n_stores, const tb_itv* stores, bool compact, bool want_c16 = false) {
   Layout L;
   L.n_vars = n_vars; L.compact = compact;
   L.perm.resize((size_t)n_vars); L.inv.resize((size_t)n_vars);
@@ -113,16 +116,29 @@ Layout make_layout(int32_t n_vars, int32_t n_stores, const tb_itv* stores, bool 
   L.n_bool = n_vars - L.n_int;
   for (int32_t v = 0; v < n_vars; ++v) L.inv[(size_t)L.perm[(size_t)v]] = v;
   if (L.n_bool == 0) L.compact = false;
+  if (L.compact && want_c16) {  // every non-Boolean variable within -32768..32767 in every store of the batch
+    bool ok = true;
+    for (int32_t v = 0; v < n_vars && ok; ++v) {
+      if (is_bool[(size_t)v]) continue;
+      for (int32_t k = 0; k < n_stores && ok; ++k) { const tb_itv d = stores[(size_t)k * (size_t)n_vars + (size_t)v]; ok = d.lb >= -32768 && d.ub <= 32767; }
+    }
+    L.c16 = ok;
+  }
   return L;
 }
 
 // caller's store -> slab (zero-initialised by the caller of this function, `vext * 8` bytes)
 void encode_slab(const Layout& L, const tb_itv* orig, unsigned char* slab) {
   tb_itv* ints = reinterpret_cast<tb_itv*>(slab);
-  unsigned* words = reinterpret_cast<unsigned*>(slab + (size_t)L.n_int * 8);
+  unsigned* ints16 = reinterpret_cast<unsigned*>(slab);
+  unsigned* words = reinterpret_cast<unsigned*>(slab + (size_t)L.n_int * (size_t)L.int_bytes());
   for (int v = 0; v < L.n_vars; ++v) {
     const int i = L.perm[(size_t)v];
-    if (i < L.n_int) { ints[i] = orig[v]; continue; }
+    if (i < L.n_int) {
+      if (L.c16) ints16[i] = ((unsigned)orig[v].lb & 0xffffu) | ((unsigned)orig[v].ub << 16);
+      else ints[i] = orig[v];
+      continue;
+    }
     const int b = i - L.n_int;
     const unsigned bits = (orig[v].lb >= 1 ? 1u : 0u) | (orig[v].ub <= 0 ? 2u : 0u);
     words[b >> 4] |= bits << ((b & 15) * 2);
@@ -130,10 +146,11 @@ void encode_slab(const Layout& L, const tb_itv* orig, unsigned char* slab) {
 }
 void decode_slab(const Layout& L, const unsigned char* slab, tb_itv* orig_out) {
   const tb_itv* ints = reinterpret_cast<const tb_itv*>(slab);
-  const unsigned* words = reinterpret_cast<const unsigned*>(slab + (size_t)L.n_int * 8);
+  const unsigned* ints16 = reinterpret_cast<const unsigned*>(slab);
+  const unsigned* words = reinterpret_cast<const unsigned*>(slab + (size_t)L.n_int * (size_t)L.int_bytes());
   for (int i = 0; i < L.n_vars; ++i) {
     tb_itv d;
-    if (i < L.n_int) d = ints[i];
+    if (i < L.n_int) { if (L.c16) { d.lb = (int)(short)(ints16[i] & 0xffffu); d.ub = (int)ints16[i] >> 16; } else d = ints[i]; }
     else { const int b = i - L.n_int; const unsigned bits = (words[b >> 4] >> ((b & 15) * 2)) & 3u; d.lb = (int)(bits & 1u); d.ub = 1 - (int)(bits >> 1); }
     orig_out[L.inv[(size_t)i]] = d;
   }
@@ -169,10 +186,12 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   // stack (stores, snapshots) starts 16-byte aligned and copies as 16-byte words
   const int n_slices = (n_props + 63) / 64, dirty_words = (n_slices + 31) / 32, vext = lay.vext(n_slices);
   p.n_slices = n_slices; p.dirty_words = dirty_words; p.vext = vext;
-  p.compact = lay.compact ? 1 : 0; p.n_int = lay.n_int; p.unent_off = lay.unent_off();
+  p.compact = lay.compact ? (lay.c16 ? 2 : 1) : 0; p.n_int = lay.n_int; p.unent_off = lay.unent_off();
   // store slab = domains + one entailment byte per 64-propagator slice; the dirty bitmap and the change list of the
   // event-driven fixpoint always live in LDS (an overflowing change list falls back to running every slice)
-  p.chg_cap = std::min(1024, std::max(64, n_vars / 4));
+  // (256 entries: a node is entered with a handful of changed variables -- the decision, the objective bound, the decisions replayed
+  //  above the deepest snapshot; a longer list only costs LDS that a sixth workgroup per CU can use, trains15)
+  p.chg_cap = std::min(256, std::max(64, n_vars / 4));
   if (cfg.reserved[1] > 0) p.chg_cap = cfg.reserved[1];  // tuning knob
   const size_t dirty_b = dirty_region_bytes(dirty_words) + align16((size_t)p.chg_cap * 4);
   // (event mode keeps the successor records next to the bytecodes: 32 bytes per propagator)
@@ -230,7 +249,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   }
   p.snapshot_levels = std::max(1, std::min(L, p.max_depth));
   p.kernel_event = event ? 1 : 0;
-  p.kernel_opt = (event ? p.compact != 0 : cfg.entailed_prop_removal != 0) ? 1 : 0;
+  p.kernel_opt = event ? p.compact : (cfg.entailed_prop_removal != 0 ? 1 : 0);
   *plan = p;
   return TB_OK;
 }
@@ -403,7 +422,7 @@ void pack_var_adj(const Adjacency& adj, std::vector<int4>* heads, std::vector<in
 // readers interested in "upper bound lowered", the z slots those interested in "lower bound raised" -- already filtered: no interest check
 // at run time -- and bit 17 / bit 2 say that more than two were interested (walk the variable's adjacency record).
 std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacency& adj, const std::vector<int4>& records, const std::vector<int>& value, bool deal_groups,
-                            int n_int = 0, bool lean = false) {
+                            int n_int = 0, bool lean = false, int bool_word0 = 0) {
   std::vector<int4> out(((size_t)n_props + 63) / 64 * 64, make_int4(-1, -1, -1, 0));
   std::vector<int> dealt((size_t)n_props, -1);  // index inside its group of a lane whose y slots are dealt
   if (deal_groups)
@@ -487,7 +506,7 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
         slots[k] = (o[1] << 16) | o[0];
       }
       const int by = vs[1] - n_int, bz = vs[2] - n_int;
-      slots[0] = (unsigned)(n_int * 2 + (by >> 4)) | ((unsigned)(n_int * 2 + (bz >> 4)) << 16);
+      slots[0] = (unsigned)(bool_word0 + (by >> 4)) | ((unsigned)(bool_word0 + (bz >> 4)) << 16);
       fl |= ((by & 15) << 20) | ((bz & 15) << 24);
       out[(size_t)i] = make_int4((int)slots[0], (int)slots[1], (int)slots[2], fl);
     }
@@ -554,7 +573,7 @@ void find_constants(int32_t n_vars, int32_t n_stores, const tb_itv* stores, std:
   }
 }
 
-template <int MEM, int TMAX, bool EVENT, bool C>
+template <int MEM, int TMAX, bool EVENT, int C>
 int prepare_solve(int bytes, int threads, int* max_blocks_per_cu) {
   const void* k = reinterpret_cast<const void*>(&solve_kernel<MEM, TMAX, EVENT, C>);
   HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -563,7 +582,7 @@ int prepare_solve(int bytes, int threads, int* max_blocks_per_cu) {
   *max_blocks_per_cu = nb;
   return TB_OK;
 }
-template <int MEM, int TMAX, bool EVENT, bool C>
+template <int MEM, int TMAX, bool EVENT, int C>
 int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
   const void* k = reinterpret_cast<const void*>(&propagate_kernel<MEM, TMAX, EVENT, C>);
   HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -586,24 +605,26 @@ int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
 //  to the event kernel that way.)
 #define DISPATCH_KERNEL(FN, mem, tmax, event, opt, ...)                                 \
   do {                                                                                  \
-    const int dk_mem = (mem), dk_tmax = (tmax);                                         \
-    const bool dk_event = (event), dk_opt = (opt);                                      \
+    const int dk_mem = (mem), dk_tmax = (tmax), dk_opt = (opt);                         \
+    const bool dk_event = (event);                                                      \
     if (dk_tmax == 256) {                                                               \
-      if (dk_event && dk_opt) DISPATCH_MEM(FN, 256, true, true, dk_mem, __VA_ARGS__);   \
-      else if (dk_event) DISPATCH_MEM(FN, 256, true, false, dk_mem, __VA_ARGS__);       \
-      else if (dk_opt) DISPATCH_MEM(FN, 256, false, true, dk_mem, __VA_ARGS__);         \
-      else DISPATCH_MEM(FN, 256, false, false, dk_mem, __VA_ARGS__);                    \
+      if (dk_event && dk_opt == 2) DISPATCH_MEM(FN, 256, true, 2, dk_mem, __VA_ARGS__); \
+      else if (dk_event && dk_opt) DISPATCH_MEM(FN, 256, true, 1, dk_mem, __VA_ARGS__); \
+      else if (dk_event) DISPATCH_MEM(FN, 256, true, 0, dk_mem, __VA_ARGS__);           \
+      else if (dk_opt) DISPATCH_MEM(FN, 256, false, 1, dk_mem, __VA_ARGS__);            \
+      else DISPATCH_MEM(FN, 256, false, 0, dk_mem, __VA_ARGS__);                        \
     } else {                                                                            \
-      if (dk_event && dk_opt) DISPATCH_MEM(FN, 1024, true, true, dk_mem, __VA_ARGS__);  \
-      else if (dk_event) DISPATCH_MEM(FN, 1024, true, false, dk_mem, __VA_ARGS__);      \
-      else if (dk_opt) DISPATCH_MEM(FN, 1024, false, true, dk_mem, __VA_ARGS__);        \
-      else DISPATCH_MEM(FN, 1024, false, false, dk_mem, __VA_ARGS__);                   \
+      if (dk_event && dk_opt == 2) DISPATCH_MEM(FN, 1024, true, 2, dk_mem, __VA_ARGS__); \
+      else if (dk_event && dk_opt) DISPATCH_MEM(FN, 1024, true, 1, dk_mem, __VA_ARGS__); \
+      else if (dk_event) DISPATCH_MEM(FN, 1024, true, 0, dk_mem, __VA_ARGS__);          \
+      else if (dk_opt) DISPATCH_MEM(FN, 1024, false, 1, dk_mem, __VA_ARGS__);           \
+      else DISPATCH_MEM(FN, 1024, false, 0, dk_mem, __VA_ARGS__);                       \
     }                                                                                   \
   } while (0)
 
 // Sets the dynamic-LDS limit of the kernel that will run and returns how many of its workgroups a CU holds
 // (register / LDS limited).  A persistent kernel gains nothing from queued workgroups, so the grid is capped.
-int prepare_kernel(bool solve, int mem, int tmax, bool event, bool opt, int bytes, int threads, int* max_blocks_per_cu) {
+int prepare_kernel(bool solve, int mem, int tmax, bool event, int opt, int bytes, int threads, int* max_blocks_per_cu) {
   int rc = TB_OK;
   if (solve) DISPATCH_KERNEL(rc = prepare_solve, mem, tmax, event, opt, (bytes, threads, max_blocks_per_cu));
   else DISPATCH_KERNEL(rc = prepare_prop, mem, tmax, event, opt, (bytes, threads, max_blocks_per_cu));
@@ -621,6 +642,17 @@ int choose_layout(const tb_config& cfg, const DeviceCaps& caps, int32_t n_vars, 
   if (!lc.compact) return rc;
   LaunchPlan pc;
   if ((rc = plan_launch(cfg, caps, lc, n_props, &pc)) != TB_OK) return rc;
+  // COMPACT16 (reserved[0] & 0x10000000 always when eligible, 0x20000000 never): half the bytes per integer variable.  Taken when it
+  // puts more workgroups on a CU than COMPACT does, or brings the slab into LDS at all -- trains15: 50 KB -> 29 KB per workgroup.
+  if (!(cfg.reserved[0] & 0x20000000)) {
+    Layout l16 = make_layout(n_vars, n_stores, stores, true, true);
+    LaunchPlan p16;
+    if (l16.c16 && plan_launch(cfg, caps, l16, n_props, &p16) == TB_OK) {
+      const bool better = (pc.mem_kind == TB_MEM_GLOBAL && p16.mem_kind != TB_MEM_GLOBAL) ||
+                          (pc.mem_kind != TB_MEM_GLOBAL && p16.mem_kind != TB_MEM_GLOBAL && p16.blocks_per_cu > pc.blocks_per_cu);
+      if (better || (cfg.reserved[0] & 0x10000000)) { lc = std::move(l16); pc = p16; }
+    }
+  }
   const bool forced = (cfg.reserved[0] & 0x100000) != 0;
   // ... and when both layouts end up in global memory, the compact slab is taken if it is at most two thirds of the plain one: the
   // workgroups' slabs then stay closer to the CUs (trains15: 2.04e7 nodes/s against 1.93e7)
@@ -816,8 +848,8 @@ int upload_event_tables(DevBuffers& bufs, DevProblem& P, const tb_config& cfg, c
   HIP_TRY(hipMemcpy(d_real, real.data(), real.size() * sizeof(int), hipMemcpyHostToDevice));
   P.slice_real = d_real;
   // the lean implication records address Boolean words by a 16-bit word index inside the slab
-  const bool lean = lay.compact && std::getenv("TB_NO_LEAN") == nullptr && (size_t)lay.n_int * 2 + (size_t)lay.bool_words() <= 0x10000;  // (TB_NO_LEAN: A/B runs)
-  std::vector<int4> succ = pack_succ(n_rec, net_props.data(), adj, packed, value, !(cfg.reserved[0] & 0x4000000), lay.n_int, lean);
+  const bool lean = lay.compact && std::getenv("TB_NO_LEAN") == nullptr && (size_t)lay.bool_word0() + (size_t)lay.bool_words() <= 0x10000;  // (TB_NO_LEAN: A/B runs)
+  std::vector<int4> succ = pack_succ(n_rec, net_props.data(), adj, packed, value, !(cfg.reserved[0] & 0x4000000), lay.n_int, lean, lay.bool_word0());
   succ.resize((size_t)plan.n_slices * 64, make_int4(-1, -1, -1, 0));
   int4* d_succ = nullptr;
   if ((rc = bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
@@ -944,7 +976,8 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   P.n_vars = n_vars; P.n_props = n_rec; P.props = d_props;
   P.fixpoint = cfg.fixpoint; P.wac1_threshold = (int)std::min<uint64_t>(cfg.wac1_threshold, 0x7fffffffu);
   P.mem_kind = plan.mem_kind; P.debug = cfg.reserved[0];
-  const bool event = cfg.fixpoint == 2, compact = event ? plan.compact != 0 : cfg.entailed_prop_removal != 0;  // the kernels' fourth template flag
+  const bool event = cfg.fixpoint == 2;
+  const int compact = event ? plan.compact : (cfg.entailed_prop_removal != 0 ? 1 : 0);  // the kernels' fourth template flag
   {
     int occ = 0;
     if ((rc = prepare_kernel(false, plan.mem_kind, plan.tmax, event, compact, plan.shared_bytes, plan.threads, &occ)) != TB_OK) return rc;
@@ -1019,7 +1052,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     // cap the grid by what is actually resident (registers, LDS): queued workgroups of a persistent kernel only
     // add tail latency; re-plan so that the subproblem count follows the real workgroup count
     int occ = 0;
-    if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->plan.kernel_event != 0, s->plan.kernel_opt != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
+    if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->plan.kernel_event != 0, s->plan.kernel_opt, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     if (occ > 0 && (long long)occ * s->caps.cus < (long long)s->plan.num_blocks) {
       tb_config capped = s->cfg;
       capped.or_nodes = (uint64_t)occ * (uint64_t)s->caps.cus;
@@ -1028,7 +1061,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
         n_rec = n_props;
         if ((rc = choose_layout(capped, s->caps, n_vars, 1, root_store, n_rec, &s->lay, &s->plan)) != TB_OK) return rc;
       }
-      if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->plan.kernel_event != 0, s->plan.kernel_opt != 0, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
+      if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->plan.kernel_event != 0, s->plan.kernel_opt, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     }
   }
   const LaunchPlan& plan = s->plan;
@@ -1164,7 +1197,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   // The node is still visited and counted; it just finds nothing left to do.  (tb_config.reserved[0] & 0x2000000 keeps the
   // caller's store, for A/B runs.)  An inconsistent root is left as it is: every subproblem then fails on its first node.
   if (n_props > 0 && !(s->cfg.reserved[0] & 0x2000000)) {
-    const bool event = s->plan.kernel_event != 0, opt = s->plan.kernel_opt != 0;
+    const bool event = s->plan.kernel_event != 0; const int opt = s->plan.kernel_opt;
     int occ = 0;
     if ((rc = prepare_kernel(false, plan.mem_kind, plan.tmax, event, opt, plan.shared_bytes, plan.threads, &occ)) != TB_OK) return rc;
     PropagateOut* d_out = nullptr;
@@ -1308,7 +1341,7 @@ int tb_session_start(tb_session* s) {
   HIP_TRY(hipMemcpyAsync(s->d_P, &s->P, sizeof(DevProblem), hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipEventRecord(s->ev_start, s->stream));
   const LaunchPlan& plan = s->plan;
-  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, plan.kernel_event != 0, plan.kernel_opt != 0, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->d_P, s->mbox_dev));
+  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, plan.kernel_event != 0, plan.kernel_opt, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->d_P, s->mbox_dev));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev_stop, s->stream));
   s->started = true;

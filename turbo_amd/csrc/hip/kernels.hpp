@@ -172,18 +172,51 @@ __device__ __forceinline__ void st(int* p, int v) { __hip_atomic_store(p, v, TB_
 // Variables >= ni are the Boolean ones of the COMPACT layout (root domain within 0..1): bit 2k of their word says
 // "lb raised to 1", bit 2k+1 "ub lowered to 0" -- narrowing is a `ds_or` (monotone like max/min), 3 = empty.
 // Without COMPACT ni = n_vars and there are no Boolean words.
-template <bool C>
-__device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v) {
+// Layouts of a workgroup's store slab (template parameter C of everything below):
+//   0  PLAIN      [n_vars x int2 {lb,ub}]
+//   1  COMPACT    [n_int x int2][Boolean words: 16 variables x 2 bits][entailment bits]   -- variables >= ni are 2-bit Booleans
+//   2  COMPACT16  [n_int x u32 {lb:16 | ub:16 << 16}][Boolean words][entailment bits]      -- as COMPACT, and every other variable has a
+//                 root domain within -32768..32767: half the bytes per integer, twice the workgroups per CU for a network like trains15
+// A 16-bit bound cannot be narrowed with one 32-bit atomic max / min (the other half shares the word), so COMPACT16 narrows with a
+// compare-and-swap loop; narrowings are two orders of magnitude rarer than reads.
+template <int C>
+__device__ __forceinline__ Itv load_int(const int2* store, int v) {  // an integer (non-Boolean) variable of the layout
   Itv d;
-  if (!C) {
-    const long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + v), TB_RLX, TB_WG);
-    d.lb = (int)(raw & 0xffffffffll);
-    d.ub = (int)(raw >> 32);
+  if (C == 2) {
+    const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + v, TB_RLX, TB_WG);
+    d.lb = (int)(short)(w & 0xffffu);
+    d.ub = (int)w >> 16;
+    return d;
+  }
+  const long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + v), TB_RLX, TB_WG);
+  d.lb = (int)(raw & 0xffffffffll);
+  d.ub = (int)(raw >> 32);
+  return d;
+}
+// first 32-bit word of the Boolean words of a COMPACT / COMPACT16 slab
+template <int C>
+__device__ __forceinline__ unsigned* bool_words(int2* store, int ni) { return reinterpret_cast<unsigned*>(store) + (C == 2 ? ni : 2 * ni); }
+template <int C>
+__device__ __forceinline__ const unsigned* bool_words(const int2* store, int ni) { return reinterpret_cast<const unsigned*>(store) + (C == 2 ? ni : 2 * ni); }
+
+template <int C>
+__device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v) {
+  if (C == 0) return load_int<0>(store, v);
+  if (C == 2) {
+    // one 4-byte load whatever the kind: the integer's packed bounds, or the Boolean word holding the variable's two bits
+    const bool isb = v >= ni;
+    const int b = v - ni;
+    const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + (isb ? ni + (b >> 4) : v), TB_RLX, TB_WG);
+    const unsigned bits = (w >> ((b & 15) * 2)) & 3u;
+    Itv d;
+    d.lb = isb ? (int)(bits & 1u) : (int)(short)(w & 0xffffu);
+    d.ub = isb ? 1 - (int)(bits >> 1) : (int)w >> 16;
     return d;
   }
   // COMPACT: one 8-byte load whatever the kind of the variable -- an interval, or the pair of Boolean words holding its
   // two bits (the Boolean words start at store + ni, which is 8-byte aligned) -- and selects instead of branches: the
   // three gathers of a propagator are in flight together and a wave with mixed operands does not serialise them.
+  Itv d;
   const bool isb = v >= ni;
   const int b = v - ni;
   const int idx = isb ? ni + (b >> 5) : v;
@@ -195,23 +228,50 @@ __device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v) {
   d.ub = isb ? 1 - (int)(bits >> 1) : hi;
   return d;
 }
-template <bool C>
+// COMPACT16: narrow one half of an integer's word (compare-and-swap: the other bound lives in the same word)
+__device__ __forceinline__ void cas_raise_lb16(unsigned* w, int val) {
+  val = val > 32767 ? 32767 : val;  // (a bound beyond the representable range empties the domain: the caller has raised the failure flag)
+  unsigned old = __hip_atomic_load(w, TB_RLX, TB_WG);
+  while ((int)(short)(old & 0xffffu) < val) {
+    const unsigned nw = (old & 0xffff0000u) | ((unsigned)val & 0xffffu);
+    if (__hip_atomic_compare_exchange_strong(w, &old, nw, TB_RLX, TB_RLX, TB_WG)) break;
+  }
+}
+__device__ __forceinline__ void cas_lower_ub16(unsigned* w, int val) {
+  val = val < -32768 ? -32768 : val;
+  unsigned old = __hip_atomic_load(w, TB_RLX, TB_WG);
+  while (((int)old >> 16) > val) {
+    const unsigned nw = (old & 0xffffu) | ((unsigned)val << 16);
+    if (__hip_atomic_compare_exchange_strong(w, &old, nw, TB_RLX, TB_RLX, TB_WG)) break;
+  }
+}
+template <int C>
+__device__ __forceinline__ void raise_int_lb(int2* store, int v, int val) {
+  if (C == 2) { cas_raise_lb16(reinterpret_cast<unsigned*>(store) + v, val); return; }
+  (void)__hip_atomic_fetch_max(&store[v].x, val, TB_RLX, TB_WG);
+}
+template <int C>
+__device__ __forceinline__ void lower_int_ub(int2* store, int v, int val) {
+  if (C == 2) { cas_lower_ub16(reinterpret_cast<unsigned*>(store) + v, val); return; }
+  (void)__hip_atomic_fetch_min(&store[v].y, val, TB_RLX, TB_WG);
+}
+template <int C>
 __device__ __forceinline__ void raise_lb(int2* store, int ni, int v, int val) {
   if (C && v >= ni) {
     const int b = v - ni;
-    if (val >= 1) (void)__hip_atomic_fetch_or(reinterpret_cast<unsigned*>(store + ni) + (b >> 4), 1u << ((b & 15) * 2), TB_RLX, TB_WG);
+    if (val >= 1) (void)__hip_atomic_fetch_or(bool_words<C>(store, ni) + (b >> 4), 1u << ((b & 15) * 2), TB_RLX, TB_WG);
     return;
   }
-  (void)__hip_atomic_fetch_max(&store[v].x, val, TB_RLX, TB_WG);
+  raise_int_lb<C>(store, v, val);
 }
-template <bool C>
+template <int C>
 __device__ __forceinline__ void lower_ub(int2* store, int ni, int v, int val) {
   if (C && v >= ni) {
     const int b = v - ni;
-    if (val <= 0) (void)__hip_atomic_fetch_or(reinterpret_cast<unsigned*>(store + ni) + (b >> 4), 2u << ((b & 15) * 2), TB_RLX, TB_WG);
+    if (val <= 0) (void)__hip_atomic_fetch_or(bool_words<C>(store, ni) + (b >> 4), 2u << ((b & 15) * 2), TB_RLX, TB_WG);
     return;
   }
-  (void)__hip_atomic_fetch_min(&store[v].y, val, TB_RLX, TB_WG);
+  lower_int_ub<C>(store, v, val);
 }
 
 // Per-thread counters kept in registers for the whole kernel and reduced once at the end.
@@ -252,7 +312,7 @@ __device__ __forceinline__ void append_change(const ChangeList& cl, int v) {
   if (pos < cl.cap) cl.list[pos] = v;  // an overflowing list degrades to "run every slice"
 }
 
-template <bool EVENT, bool C>
+template <bool EVENT, int C>
 __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store, const int ni, int* bot, bool& changed, bool& un, ThreadCounters& tc, const int dbg = 0,
                                       int* narrowed = nullptr) {
   const int w0 = pr.x;
@@ -587,10 +647,11 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* n
 
 // A 2-bit Boolean of the COMPACT layout as an LDS word address and a bit position (computed once per run).
 struct BoolRef { unsigned* word; int shift; };
+template <int C>
 __device__ __forceinline__ BoolRef bool_ref(int2* store, int ni, int v, bool act) {
   const int b = act ? v - ni : 0;  // idle lanes of a padded slice look at the first Boolean and touch nothing
   BoolRef r;
-  r.word = reinterpret_cast<unsigned*>(store + ni) + (b >> 4);
+  r.word = bool_words<C>(store, ni) + (b >> 4);
   r.shift = (b & 15) * 2;
   return r;
 }
@@ -610,25 +671,25 @@ __device__ __forceinline__ void bool_or(const BoolRef r, unsigned bits) { (void)
 // COMPACT layout: `kinds` (2 bits per operand, word0 bits 26-31 of the slice: 1 all integer variables, 2 all 2-bit Booleans, else mixed) picks
 // the cheapest way to read an operand -- a Boolean column is one ds_read_b32 and three VALU per pass, its word address and bit position
 // computed once per run.
-template <bool C>
+template <int C>
 struct LeanOperand {
   int v;            // variable (idle lanes: 0)
   BoolRef b;        // COMPACT Boolean column: word and bit position
 };
-template <bool C>
+template <int C>
 __device__ __forceinline__ LeanOperand<C> lean_operand(int2* store, int ni, int v, bool act, int kind) {
   LeanOperand<C> o;
   o.v = act ? v : 0;
-  if (C && kind == 2) o.b = bool_ref(store, ni, v, act);
+  if (C && kind == 2) o.b = bool_ref<C>(store, ni, v, act);
   return o;
 }
-template <bool C>
+template <int C>
 __device__ __forceinline__ Itv lean_load(int2* store, int ni, const LeanOperand<C>& o, int kind) {
   if (C && kind == 2) { const unsigned bits = bool_bits(o.b); Itv d; d.lb = (int)(bits & 1u); d.ub = 1 - (int)(bits >> 1); return d; }
-  if (C && kind != 1) return load_dom<true>(store, ni, o.v);
-  return load_dom<false>(store, ni, o.v);
+  if (C && kind != 1) return load_dom<C>(store, ni, o.v);
+  return load_int<C>(store, o.v);
 }
-template <bool C>
+template <int C>
 __device__ __forceinline__ unsigned lean_class_run(const RunEnv& E, const int cls, const int kinds, const int4 pr, const bool act, int2* store, const int ni, unsigned& wave_writes, int& nar_all) {
   const int lane = threadIdx.x & 63, s = E.s;
   const int kx = kinds & 3, ky = (kinds >> 2) & 3, kz = (kinds >> 4) & 3;  // wave-uniform
@@ -756,7 +817,7 @@ __host__ __device__ inline size_t dirty_region_bytes(int dirty_words) { return (
 // waves: 250 slice runs per node asynchronously against 82 with a single wave).
 // Inside a round a wave still iterates each slice to its local fixpoint (WAC1), and a slice sees the narrowings other
 // waves have already made in the same round.
-template <bool C>
+template <int C>
 __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
                                               const EventState& es, ThreadCounters& tc, bool& all_entailed) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = T >> 6;
@@ -893,7 +954,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
           if (C && (info.y & 0x100)) {
             // ---- lean implication run: `y <= z` on two 2-bit Booleans (bit 0: lb raised to 1, bit 1: ub lowered to 0) from the successor
             // record alone (engine.hip: pack_succ): z.ub = 0 forces y.ub = 0, y.lb = 1 forces z.lb = 1; entailed once y.ub = 0 or z.lb = 1.
-            unsigned* const words = reinterpret_cast<unsigned*>(store);
+            unsigned* const words = reinterpret_cast<unsigned*>(store);  // (word indexes from the start of the slab, whatever the layout)
             unsigned* const wy = words + ((unsigned)sc.x & 0xffffu);
             unsigned* const wz = words + ((unsigned)sc.x >> 16);
             const int ys = (sc.w >> 19) & 30, zs = (sc.w >> 23) & 30;
@@ -947,7 +1008,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               if ((tz >> 16) != 0xffffu) { mark_slice(nxt, (int)(tz >> 16)); did = true; }
               const int ey = (my_ny && ((sc.w >> 17) & 1)) ? EV_UB : 0, ez = (my_nz && ((sc.w >> 2) & 1)) ? EV_LB : 0;
               if (wave_any((ey | ez) != 0)) {  // more than two interested readers: the variable's adjacency record
-                const int base_w = P.n_int * 2;
+                const int base_w = C == 2 ? P.n_int : P.n_int * 2;  // first Boolean word of the slab
                 const int vy = P.n_int + ((((int)((unsigned)sc.x & 0xffffu)) - base_w) << 4) + (ys >> 1);
                 const int vz = P.n_int + ((((int)((unsigned)sc.x >> 16)) - base_w) << 4) + (zs >> 1);
                 int dy = 0, dz = 0, oy = 0, oz = 0;
@@ -980,7 +1041,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
           if (C && key == KEY_LEQT_BB) {
             // y <= z on two Booleans, straight on their 2-bit encodings (bit 0: lb raised to 1, bit 1: ub lowered to 0):
             // z.ub = 0 forces y.ub = 0, y.lb = 1 forces z.lb = 1; entailed once y.ub = 0 or z.lb = 1.
-            const BoolRef ry = bool_ref(store, P.n_int, pr.z, act), rz = bool_ref(store, P.n_int, pr.w, act);
+            const BoolRef ry = bool_ref<C>(store, P.n_int, pr.z, act), rz = bool_ref<C>(store, P.n_int, pr.w, act);
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               const unsigned yb = bool_bits(ry), zb = bool_bits(rz);
               const bool ny = (zb & 2u) && !(yb & 2u), nz = (yb & 1u) && !(zb & 1u);
@@ -1007,7 +1068,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             // groups at once: every lane carries its group's bounds, a ballot masked with the group's lanes says whether some
             // false b_i sits on a bound, and the bounds step over the excluded values in registers -- no memory traffic; then
             // every b_i outside the new bounds becomes false and, if y is assigned, its b_i true.  Same fixpoint, one pass.
-            const BoolRef rx = bool_ref(store, P.n_int, pr.y, act);
+            const BoolRef rx = bool_ref<C>(store, P.n_int, pr.y, act);
             const int yv = act ? pr.z : 0;
             const int w0u = info.x;
             const bool single_pass = ((w0u >> 11) & 1) != 0;
@@ -1023,7 +1084,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             const int k0 = kc - (lane - g_start), k_last = k0 + (g_last - g_start);  // (meaningful when dense)
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               const unsigned xb = bool_bits(rx);
-              const Itv Y = load_dom<false>(store, P.n_int, yv);
+              const Itv Y = load_int<C>(store, yv);
               const bool t = act && (xb & 1u), f = act && (xb & 2u), u = act && xb == 0u;
               int lb = Y.lb, ub = Y.ub;
               for (unsigned long long tm = wave_ballot(t); tm; tm &= tm - 1) {  // y = k for every true b (normally at most one per group)
@@ -1066,9 +1127,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                 }
                 const bool cyl = writer && lb != Y.lb, cyu = writer && ub != Y.ub;
                 if (cyl | cyu) {
-                  if (cyl) raise_lb<false>(store, P.n_int, yv, lb);
-                  if (cyu) lower_ub<false>(store, P.n_int, yv, ub);
-                  const Itv now = load_dom<false>(store, P.n_int, yv);
+                  if (cyl) raise_int_lb<C>(store, yv, lb);
+                  if (cyu) lower_int_ub<C>(store, yv, ub);
+                  const Itv now = load_int<C>(store, yv);
                   if (now.lb > now.ub) st(&sh.bot, 1);
                 }
                 run_writes += (unsigned)(set0 | set1) + (unsigned)cyl + (unsigned)cyu;
@@ -1084,12 +1145,12 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
           } else if (C && (key == KEY_EQR_BIC || key == KEY_LEQR_BIC)) {
             // b = (y = k) / b = (y <= k): Boolean truth variable, integer y, constant k (read once per run)
             const bool is_eq = key == KEY_EQR_BIC;
-            const BoolRef rx = bool_ref(store, P.n_int, pr.y, act);
+            const BoolRef rx = bool_ref<C>(store, P.n_int, pr.y, act);
             const int yv = act ? pr.z : 0;
             const int kc = sc.z;  // the constant's value travels in the z slots of the successor record (pack_succ)
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               const unsigned xb = bool_bits(rx);
-              const Itv Y = load_dom<false>(store, P.n_int, yv);
+              const Itv Y = load_int<C>(store, yv);
               const bool t = (xb & 1u) != 0, f = (xb & 2u) != 0, u = !t && !f;
               const bool empty_in = (xb == 3u) | (Y.lb > Y.ub);
               bool set1, set0, ent;
@@ -1113,8 +1174,8 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                   if (empty_in | (nyl > nyu)) st(&sh.bot, 1);  // (a narrowed constant is an empty y: same condition)
                   if (!empty_in) {
                     if (set1 | set0) bool_or(rx, set1 ? 1u : 2u);
-                    if (cyl) raise_lb<false>(store, P.n_int, yv, nyl);
-                    if (cyu) lower_ub<false>(store, P.n_int, yv, nyu);
+                    if (cyl) raise_int_lb<C>(store, yv, nyl);
+                    if (cyu) lower_int_ub<C>(store, yv, nyu);
                     const int kw = (int)(set1 | set0) + (int)cyl + (int)cyu;
                     run_writes += (unsigned)kw;
                     ch = kw != 0;
@@ -1221,7 +1282,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
 struct FpResult { int rounds; int all_entailed; unsigned writes; };
 // SL: the store (and the entailment bits behind it) lives in LDS, `store_ref` is then its LDS offset; otherwise the store is the
 // workgroup's slab in global memory and `gstore` points to it.
-template <bool C, int MEM>
+template <int C, int MEM>
 static __device__ TB_FIX_ATTR FpResult fixpoint_event_call(const DevProblem* Pp, unsigned sh_off, unsigned store_off, int2* gstore, unsigned props_off, const int4* gprops,
                                                      unsigned dirty_off, unsigned list_off, unsigned writes_in) {
   BlockShared& sh = *lds_ptr<BlockShared>(sh_off);
@@ -1281,7 +1342,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 }
 
 // Thread 0 only: VStore::embed of one interval (decisions, objective bound).
-template <bool C>
+template <int C>
 __device__ __forceinline__ int embed0(int2* store, int ni, int* bot, int v, int lb, int ub) {  // returns EV_LB / EV_UB bits
   Itv d = load_dom<C>(store, ni, v);
   int ev = 0;
@@ -1291,7 +1352,7 @@ __device__ __forceinline__ int embed0(int2* store, int ni, int* bot, int v, int 
   return ev;
 }
 // embed0 + event bookkeeping: the slices reading v must run in the first sweep of the next fixpoint
-template <bool EVENT, bool C>
+template <bool EVENT, int C>
 __device__ __forceinline__ void embed0_mark(const DevProblem& P, BlockShared& sh, const EventState& es, int2* store, int* bot, int v, int lb, int ub) {
   const int ev = embed0<C>(store, P.n_int, bot, v, lb, ub);
   if (EVENT && ev) note_change(sh, es, v, ev);
@@ -1317,7 +1378,7 @@ __device__ __forceinline__ Decision& dec_at(const DevProblem& P, BlockShared& sh
 }
 
 // Thread 0 only (barebones:355-405).
-template <bool C>
+template <int C>
 __device__ __forceinline__ bool push_decision(const DevProblem& P, BlockShared& sh, Decision* dec, const int2* store, int val_order, int var) {
   const int depth = sh.depth;
   if (depth + 1 >= ((1 + sh.n_dec_seg) << P.max_depth_log2)) {  // grow: one more segment from the pool
@@ -1351,7 +1412,7 @@ __device__ __forceinline__ bool push_decision(const DevProblem& P, BlockShared& 
 // input_order_split / lattice_smallest_split (barebones:240-349) by one strided scan, a wave-level
 // min reduction (DPP/bpermute shuffles) and one LDS round per strategy.
 // Ends with a barrier; sh.found tells whether a decision was pushed at sh.depth-1.
-template <bool C>
+template <int C>
 __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Decision* dec, const int2* store) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
   for (;;) {
@@ -1661,7 +1722,7 @@ __device__ __forceinline__ void skip_subtree(const DevProblem& P, BlockShared& s
 
 struct NodeTimers { long long t_last; };
 
-template <bool EVENT, bool C, bool RM, int MEM>
+template <bool EVENT, int C, bool RM, int MEM>
 __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
                                                     int2* best_store, Mailbox* mbox, ThreadCounters& tc) {
   const int tid = threadIdx.x;
@@ -1796,7 +1857,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
 // copy of each instead of one per call site, registers allocated for their own loops, and the persistent search loop keeps only
 // a handful of values alive across them.  (The sweeping kernels stay inlined: their problem description is a by-value kernel
 // argument, which a call would have to copy to memory.)
-template <bool C, int MEM>
+template <int C, int MEM>
 static __device__ TB_NODE_ATTR unsigned propagate_node_event(const DevProblem* Pp, unsigned sh_off, unsigned store_off, int2* gstore, unsigned props_off, const int4* gprops,
                                                       unsigned dirty_off, unsigned list_off, int2* best_store, Mailbox* mbox, unsigned writes) {
   BlockShared& sh = *lds_ptr<BlockShared>(sh_off);
@@ -1813,12 +1874,12 @@ static __device__ TB_NODE_ATTR unsigned propagate_node_event(const DevProblem* P
   propagate_node_impl<true, C, false, MEM>(constant_problem(Pp), sh, store, props, es, best_store, glob(mbox), tc);
   return tc.writes;
 }
-template <bool C, bool SL>
+template <int C, bool SL>
 static __device__ TB_SPLIT_ATTR void split_event(const DevProblem* Pp, unsigned sh_off, Decision* dec, unsigned store_off, const int2* gstore) {
   split<C>(constant_problem(Pp), *lds_ptr<BlockShared>(sh_off), glob(dec), SL ? lds_ptr<const int2>(store_off) : glob(gstore));
 }
 
-template <bool EVENT, bool C, bool RM, int MEM>
+template <bool EVENT, int C, bool RM, int MEM>
 __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
                                                int2* best_store, Mailbox* mbox, ThreadCounters& tc) {
   constexpr bool SL = MEM >= TB_MEM_STORE_SHARED, PL = MEM == TB_MEM_TCN_SHARED;
@@ -1826,7 +1887,7 @@ __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared&
                                                                 lds_off(es.dirty), lds_off(es.list), best_store, mbox, tc.writes);
   else propagate_node_impl<EVENT, C, RM, MEM>(P, sh, store, props, es, best_store, mbox, tc);
 }
-template <bool EVENT, bool C, bool SL>
+template <bool EVENT, int C, bool SL>
 __device__ __forceinline__ void split_node(const DevProblem& P, BlockShared& sh, Decision* dec, int2* store) {
   if constexpr (EVENT) split_event<C, SL>(&P, lds_off(&sh), dec, SL ? lds_off(store) : 0u, SL ? nullptr : store);
   else split<C>(P, sh, dec, store);
@@ -1840,7 +1901,7 @@ constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 255) / 256 * 256);
 // SIMD (<= 72 VGPRs) so that 7 workgroups are resident per CU when their stores fit (wordpress7_500: 7 x 22.7 KB of
 // LDS; measured 17.9 / 20.5 / 22.3 / 23.4e6 nodes/s with 4 / 5 / 6 / 7); the sweep variants are VALU bound and keep 4.
 // OPT: the COMPACT store layout for the event kernels, entailed-slice removal for the sweeping ones.
-template <int MEM, int TMAX, bool EVENT, bool OPT>
+template <int MEM, int TMAX, bool EVENT, int OPT>
 __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES : (TMAX == 256 ? 5 : 4)) solve_kernel(DevProblem by_value, const DevProblem* __restrict__ problem, Mailbox* mbox) {
   // The problem description is read through a pointer, not passed by value: as kernel arguments its ~70 scalars were all
   // hoisted into SGPRs for the whole persistent loop and 260 of them spilled through VGPR lanes (v_writelane / v_readlane,
@@ -1853,7 +1914,8 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   // pat11 went wrong), so every wave drops it once, here.
   __builtin_amdgcn_s_dcache_inv();
   const DevProblem& P = EVENT ? *problem : by_value;
-  constexpr bool C = EVENT && OPT, RM = !EVENT && OPT;
+  constexpr int C = EVENT ? OPT : 0;  // store layout of the event kernels: 0 plain, 1 COMPACT, 2 COMPACT16
+  constexpr bool RM = !EVENT && OPT != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -2060,10 +2122,11 @@ struct PropagateOut {
 };
 
 // `stores` holds n_stores slabs of P.vext intervals each (the layout of a workgroup slab, encoded by the host).
-template <int MEM, int TMAX, bool EVENT, bool OPT>
+template <int MEM, int TMAX, bool EVENT, int OPT>
 __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* stores, PropagateOut* out, int n_stores) {
   __builtin_amdgcn_s_dcache_inv();  // (see solve_kernel)
-  constexpr bool C = EVENT && OPT, RM = !EVENT && OPT;
+  constexpr int C = EVENT ? OPT : 0;  // store layout of the event kernels: 0 plain, 1 COMPACT, 2 COMPACT16
+  constexpr bool RM = !EVENT && OPT != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, V = P.n_vars;
