@@ -178,6 +178,14 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64) * 8) + dirty_region_bytes(((n_props + 63) / 64 + 31) / 32) + 4096 + SH_BYTES;
     while (T < 1024 && slab <= (size_t)caps.lds_per_cu && std::min<size_t>((size_t)caps.lds_per_cu / slab, (size_t)(2048 / T)) * (size_t)(T / 64) < 16) T *= 2;
   }
+  bool small_wg = false;
+  if (auto_threads && T == 256 && !cfg.only_global_memory && (event || n_props < 2048)) {
+    // What a CU needs is subproblems in flight (and the fewer waves meet at a barrier, the less they wait for each other): when 14
+    // slabs fit in LDS, 14 workgroups of two waves beat 7 of four -- accap_a3: 4.5e7 -> 7.0e7 nodes/s (event), 3.1e7 -> 5.3e7 (wac1).
+    // wordpress7_500 (8 slabs fit) and trains15 (6) keep their four waves.
+    const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64) * 8) + dirty_region_bytes(((n_props + 63) / 64 + 31) / 32) + align16(256 * 4) + SH_BYTES;
+    if (slab * 14 <= (size_t)caps.lds_per_cu) { T = 128; small_wg = true; }
+  }
   if (T != 64 && T != 128 && T != 256 && T != 512 && T != 1024) return fail(TB_ERR_INVALID, "threads_per_block must be 64, 128, 256, 512 or 1024");
   p.threads = T;
   p.tmax = T <= 256 ? 256 : 1024;
@@ -197,7 +205,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   // (event mode keeps the successor records next to the bytecodes: 32 bytes per propagator)
   const size_t store_b = align16((size_t)vext * 8) + dirty_b, props_b = (size_t)n_slices * 64 * (event ? 32 : 16);  // padded to whole slices
   const size_t fixed = SH_BYTES;
-  int bpc_max = std::min(cfg.reserved[2] > 0 ? cfg.reserved[2] : 8, 2048 / T);  // 32 waves per CU (reserved[2]: tuning knob)
+  int bpc_max = std::min(cfg.reserved[2] > 0 ? cfg.reserved[2] : (small_wg ? 16 : 8), 2048 / T);  // 32 waves per CU (reserved[2]: tuning knob)
   if (bpc_max < 1) bpc_max = 1;
   if (cfg.only_global_memory) {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
