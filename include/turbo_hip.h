@@ -94,7 +94,9 @@ typedef struct {
                                        [0] bit mask -- 0x1/0x2/0x4/0x8 and bits 8-15: sweep ablations of scripts/ablate.py (results are
                                            not fixpoints); 0x10000 in-kernel phase timers; 0x20000 keep running entailed slices;
                                            0x40000 event mode accepts < 4 workgroups per CU in LDS; 0x80000 never / 0x100000 always
-                                           use the compact (2-bit Boolean) store layout of the event kernels; 0x200000 keep the caller's
+                                           use the compact (2-bit Boolean) store layout of the event kernels (0x100000 with the sweeps and
+                                           without entailed_prop_removal: the sweeps on that layout, an opt-in); 0x10000000 always / 0x20000000
+                                           never pack integer variables as 16-bit bounds on top of it (COMPACT16); 0x200000 keep the caller's
                                            propagator order instead of sorting the records by class; 0x400000 count slice
                                            runs instead of propagator evaluations; 0x800000 test aid: keep the store every workgroup stopped
                                            on (tb_session_debug_last_store); 0x1000000 no work stealing between linked GPUs (A/B runs, tests);
@@ -197,8 +199,8 @@ int tb_session_start(tb_session* s);
 typedef struct {
   int32_t num_blocks, threads_per_block, mem_kind, shared_bytes, subproblems_power, eps_chunk_log2, snapshot_levels, decision_stack_depth;
   uint64_t eps_local_subproblems;
-  int32_t kernel_event, kernel_opt; /* which kernel start() launches: event-driven fixpoint or sweeps; its option flag (COMPACT store
-                                     * layout for the event kernels, entailed-slice removal for the sweeps) */
+  int32_t kernel_event, kernel_opt; /* which kernel start() launches: event-driven fixpoint or sweeps; its option flag (event: 0 plain store,
+                                     * 1 COMPACT, 2 COMPACT16; sweeps: 0 plain, 1 entailed-slice removal, 2 COMPACT, 4 COMPACT16) */
 } tb_plan;
 int tb_session_plan(tb_session* s, tb_plan* plan_out);
 /*

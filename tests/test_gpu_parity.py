@@ -107,7 +107,8 @@ def test_wordpress_nodes_bit_exact():
     check_batch(tcn, stores, fixpoint=2, debug=0x80000)  # the same without it
 
 
-@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT), (1, "rm"), (0, "rm"), (2, COMPACT16)], ids=["wac1", "event", "event_compact", "wac1_rm", "ac1_rm", "event_compact16"])
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT), (1, "rm"), (0, "rm"), (2, COMPACT16), (1, COMPACT16)],
+                         ids=["wac1", "event", "event_compact", "wac1_rm", "ac1_rm", "event_compact16", "wac1_compact16"])
 @pytest.mark.parametrize("rel,expected", FAST)
 def test_sequential_tree_identical(rel, expected, fixpoint, debug):
     rm, debug = (1, 0) if debug == "rm" else (0, debug)
@@ -185,12 +186,13 @@ def test_random_models_tree_identical(chunk, fixpoint, debug):
             np.testing.assert_array_equal(best_g, best_o, err_msg=str(seed))
 
 
-@pytest.mark.parametrize("mode", ["ac1", "wac1", "event", "event_compact"])
+@pytest.mark.parametrize("mode", ["ac1", "wac1", "event", "event_compact", "wac1_compact", "ac1_compact"])
 def test_random_networks_with_wide_and_infinite_domains(mode):
     """Fuzz at the node level: all eight operators over small, Boolean, wide (1e6), huge (2^30: saturation) and
     unbounded domains; the fixpoint must be the oracle's, bit for bit."""
     from fuzz_models import random_network
-    cfg = {"ac1": dict(fixpoint=0), "wac1": dict(fixpoint=1), "event": dict(fixpoint=2), "event_compact": dict(fixpoint=2, debug=COMPACT)}[mode]
+    cfg = {"ac1": dict(fixpoint=0), "wac1": dict(fixpoint=1), "event": dict(fixpoint=2), "event_compact": dict(fixpoint=2, debug=COMPACT),
+           "wac1_compact": dict(fixpoint=1, debug=COMPACT), "ac1_compact": dict(fixpoint=0, debug=COMPACT)}[mode]  # (sweeps on a compact layout: an option, see DESIGN.md)
     for seed in range(200):
         rng = np.random.default_rng(seed)
         store, props = random_network(rng)
@@ -257,7 +259,7 @@ def test_channelling_networks_bit_exact(mode):
                 np.testing.assert_array_equal(got[i], exp, err_msg=f"seed {seed} store {i}")
 
 
-@pytest.mark.parametrize("mode", ["wac1", "event", "event_compact", "event_globalmem", "event_compact_globalmem", "event_compact16", "event_compact16_globalmem"])
+@pytest.mark.parametrize("mode", ["wac1", "event", "event_compact", "event_globalmem", "event_compact_globalmem", "event_compact16", "event_compact16_globalmem", "wac1_compact", "wac1_compact16"])
 def test_class_pure_finite_networks_bit_exact(mode):
     """Fuzz of the lean runs of the event kernels: class-pure slices over finite domains in the plain and in the compact layout
     (lean_class_run), Boolean implication slices read from their successor records alone (compact), stores in LDS and in
@@ -265,7 +267,8 @@ def test_class_pure_finite_networks_bit_exact(mode):
     from fuzz_models import finite_class_network
     cfg = {"wac1": dict(fixpoint=1), "event": dict(fixpoint=2), "event_compact": dict(fixpoint=2, debug=COMPACT),
            "event_globalmem": dict(fixpoint=2, only_global_memory=1), "event_compact_globalmem": dict(fixpoint=2, debug=COMPACT, only_global_memory=1),
-           "event_compact16": dict(fixpoint=2, debug=COMPACT16), "event_compact16_globalmem": dict(fixpoint=2, debug=COMPACT16, only_global_memory=1)}[mode]
+           "event_compact16": dict(fixpoint=2, debug=COMPACT16), "event_compact16_globalmem": dict(fixpoint=2, debug=COMPACT16, only_global_memory=1),
+           "wac1_compact": dict(fixpoint=1, debug=COMPACT), "wac1_compact16": dict(fixpoint=1, debug=COMPACT16)}[mode]
     for seed in range(60):
         rng = np.random.default_rng(5000 + seed)
         store, props = finite_class_network(rng)

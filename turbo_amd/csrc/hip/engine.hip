@@ -257,7 +257,8 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   }
   p.snapshot_levels = std::max(1, std::min(L, p.max_depth));
   p.kernel_event = event ? 1 : 0;
-  p.kernel_opt = event ? p.compact : (cfg.entailed_prop_removal != 0 ? 1 : 0);
+  // sweeps: entailed-slice removal (bit 0) or a compact layout (2: COMPACT, 4: COMPACT16) -- not both, to keep the number of kernels down
+  p.kernel_opt = event ? p.compact : (cfg.entailed_prop_removal != 0 ? 1 : p.compact * 2);
   *plan = p;
   return TB_OK;
 }
@@ -619,12 +620,16 @@ int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
       if (dk_event && dk_opt == 2) DISPATCH_MEM(FN, 256, true, 2, dk_mem, __VA_ARGS__); \
       else if (dk_event && dk_opt) DISPATCH_MEM(FN, 256, true, 1, dk_mem, __VA_ARGS__); \
       else if (dk_event) DISPATCH_MEM(FN, 256, true, 0, dk_mem, __VA_ARGS__);           \
+      else if (dk_opt == 4) DISPATCH_MEM(FN, 256, false, 4, dk_mem, __VA_ARGS__);       \
+      else if (dk_opt == 2) DISPATCH_MEM(FN, 256, false, 2, dk_mem, __VA_ARGS__);       \
       else if (dk_opt) DISPATCH_MEM(FN, 256, false, 1, dk_mem, __VA_ARGS__);            \
       else DISPATCH_MEM(FN, 256, false, 0, dk_mem, __VA_ARGS__);                        \
     } else {                                                                            \
       if (dk_event && dk_opt == 2) DISPATCH_MEM(FN, 1024, true, 2, dk_mem, __VA_ARGS__); \
       else if (dk_event && dk_opt) DISPATCH_MEM(FN, 1024, true, 1, dk_mem, __VA_ARGS__); \
       else if (dk_event) DISPATCH_MEM(FN, 1024, true, 0, dk_mem, __VA_ARGS__);          \
+      else if (dk_opt == 4) DISPATCH_MEM(FN, 1024, false, 4, dk_mem, __VA_ARGS__);      \
+      else if (dk_opt == 2) DISPATCH_MEM(FN, 1024, false, 2, dk_mem, __VA_ARGS__);      \
       else if (dk_opt) DISPATCH_MEM(FN, 1024, false, 1, dk_mem, __VA_ARGS__);           \
       else DISPATCH_MEM(FN, 1024, false, 0, dk_mem, __VA_ARGS__);                       \
     }                                                                                   \
@@ -645,7 +650,11 @@ int choose_layout(const tb_config& cfg, const DeviceCaps& caps, int32_t n_vars, 
                   Layout* lay, LaunchPlan* plan) {
   *lay = make_layout(n_vars, n_stores, stores, false);
   int rc = plan_launch(cfg, caps, *lay, n_props, plan);
-  if (rc != TB_OK || cfg.fixpoint != 2 || (cfg.reserved[0] & 0x80000)) return rc;
+  // The sweeps take a compact layout only when it is forced (and never together with entailed-slice removal): measured r03, a sweep
+  // evaluates every propagator whatever the layout, and the decode costs more than the extra workgroups bring -- wordpress7_500 WAC1
+  // 2.10e6 nodes/s plain (256 x 1024) against 1.81e6 compact (1280 x 256); trains15 6.77e6 against 7.44e6.
+  const bool sweeps_opt_in = cfg.fixpoint != 2 && !cfg.entailed_prop_removal && (cfg.reserved[0] & 0x100000);
+  if (rc != TB_OK || (cfg.fixpoint != 2 && !sweeps_opt_in) || (cfg.reserved[0] & 0x80000)) return rc;
   Layout lc = make_layout(n_vars, n_stores, stores, true);
   if (!lc.compact) return rc;
   LaunchPlan pc;
@@ -985,7 +994,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   P.fixpoint = cfg.fixpoint; P.wac1_threshold = (int)std::min<uint64_t>(cfg.wac1_threshold, 0x7fffffffu);
   P.mem_kind = plan.mem_kind; P.debug = cfg.reserved[0];
   const bool event = cfg.fixpoint == 2;
-  const int compact = event ? plan.compact : (cfg.entailed_prop_removal != 0 ? 1 : 0);  // the kernels' fourth template flag
+  const int compact = plan.kernel_opt;  // the kernels' fourth template flag
   {
     int occ = 0;
     if ((rc = prepare_kernel(false, plan.mem_kind, plan.tmax, event, compact, plan.shared_bytes, plan.threads, &occ)) != TB_OK) return rc;

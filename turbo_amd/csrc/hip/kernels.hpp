@@ -380,7 +380,7 @@ __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store
 // With RM (tb_config.entailed_prop_removal) a slice whose byte is 0 is skipped for the whole subtree -- entailed-propagator removal
 // (FixpointSubsetGPU::select, gpu_dive_and_solve.hpp:334, barebones:984; a build option of the reference, off by
 // default) at the granularity of a wave's slice instead of a compacted index array.
-template <bool RM>
+template <bool RM, int C>
 __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
                                         unsigned char* slice_unent, ThreadCounters& tc, bool& all_entailed) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
@@ -412,13 +412,13 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         if (rm) {
           if (slice_unent[base >> 6] == 0) continue;
           bool ch = false, un_i = false;
-          apply<false, false>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
+          apply<false, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
           ++wave_evals;  // iterations x active propagators (gpu_dive_and_solve.hpp:304-306)
           changed |= ch; un |= un_i;
           if (!wave_any(ch) && !wave_any(un_i) && lane == 0) slice_unent[base >> 6] = 0;
           continue;
         }
-        apply<false, false>(pr, act, store, P.n_int, &sh.bot, changed, un, tc, dbg);
+        apply<false, C>(pr, act, store, P.n_int, &sh.bot, changed, un, tc, dbg);
       }
     } else {
       // WAC1: a wave iterates its 64 propagators to a local fixpoint before moving on (config.cpp:26,
@@ -431,7 +431,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         if (rm && slice_unent[base >> 6] == 0) continue;
         for (unsigned local_iters = 1;; ++local_iters) {
           bool ch = false, un_i = false;
-          apply<false, false>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
+          apply<false, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
           ++wave_evals;
           if (!wave_any(ch)) {
             un |= un_i;
@@ -1736,7 +1736,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
     const FpResult r = fixpoint_event_call<C, MEM>(&P, lds_off(&sh), SL ? lds_off(store) : 0u, SL ? nullptr : store, PL ? lds_off(props) : 0u, PL ? nullptr : props,
                                                    lds_off(es.dirty), lds_off(es.list), tc.writes);
     iters = r.rounds; all_entailed = r.all_entailed != 0; tc.writes = r.writes;
-  } else iters = fixpoint<RM>(P, sh, store, props, es.unent, tc, all_entailed);
+  } else iters = fixpoint<RM, C>(P, sh, store, props, es.unent, tc, all_entailed);
   flush_writes(sh, tc, false);
   const bool aborted = ld(&sh.abort) != 0;
   const bool failed = !aborted && ld(&sh.bot) != 0;
@@ -1914,8 +1914,9 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES 
   // pat11 went wrong), so every wave drops it once, here.
   __builtin_amdgcn_s_dcache_inv();
   const DevProblem& P = EVENT ? *problem : by_value;
-  constexpr int C = EVENT ? OPT : 0;  // store layout of the event kernels: 0 plain, 1 COMPACT, 2 COMPACT16
-  constexpr bool RM = !EVENT && OPT != 0;
+  // OPT: event kernels -- the store layout (0 plain, 1 COMPACT, 2 COMPACT16); sweeps -- bit 0 entailed-slice removal, bits 1-2 the layout
+  constexpr int C = EVENT ? OPT : (OPT >> 1);
+  constexpr bool RM = !EVENT && (OPT & 1) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -2125,8 +2126,9 @@ struct PropagateOut {
 template <int MEM, int TMAX, bool EVENT, int OPT>
 __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* stores, PropagateOut* out, int n_stores) {
   __builtin_amdgcn_s_dcache_inv();  // (see solve_kernel)
-  constexpr int C = EVENT ? OPT : 0;  // store layout of the event kernels: 0 plain, 1 COMPACT, 2 COMPACT16
-  constexpr bool RM = !EVENT && OPT != 0;
+  // OPT: event kernels -- the store layout (0 plain, 1 COMPACT, 2 COMPACT16); sweeps -- bit 0 entailed-slice removal, bits 1-2 the layout
+  constexpr int C = EVENT ? OPT : (OPT >> 1);
+  constexpr bool RM = !EVENT && (OPT & 1) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, V = P.n_vars;
@@ -2167,7 +2169,7 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
     if (EVENT) { if (tid == 0) { sh.ev_all = 1; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; } __syncthreads(); }
     if (!ld(&sh.bot)) {
       if constexpr (EVENT) iters = fixpoint_event<C>(P, sh, store, props, es, tc, all_entailed);
-      else iters = fixpoint<RM>(P, sh, store, props, es.unent, tc, all_entailed);
+      else iters = fixpoint<RM, C>(P, sh, store, props, es.unent, tc, all_entailed);
     }
     if (MEM >= TB_MEM_STORE_SHARED) copy_store(gstore, store, VX);
     flush_writes(sh, tc, true);
