@@ -85,41 +85,67 @@ struct LaunchPlan {
 // others and kept as 2 bits each (kernels.hpp: load_dom / raise_lb / lower_ub); everything the engine works on --
 // propagators, strategies, objective, adjacency -- is expressed in the internal numbering, and stores are
 // converted at the boundary (encode_slab / decode_slab).  Without COMPACT the numbering is the caller's.
+//
+// Constants out of the slab (COMPACT layouts): a non-Boolean variable that is the same finite singleton in every store of the batch -- TCN has
+// no constants, only singleton variables (common_solving.hpp:743-771); wordpress7_500 has 847 of them among its 1644 integers -- is numbered
+// behind the Booleans and takes no room in the slab at all: the records that read it carry its VALUE in the operand field (sign bit set,
+// kernels.hpp: load_dom), the strategy lists skip it, decode_slab puts it back.  Narrowing a constant is a failure; whoever tries raises the flag.
 struct Layout {
   bool compact = false;
   bool c16 = false;  // COMPACT16: the non-Boolean variables as two 16-bit bounds in one word (kernels.hpp: load_dom<2>)
   int n_vars = 0, n_int = 0, n_bool = 0;
+  int n_out = 0;               // constants kept out of the slab: internal ids n_int + n_bool .. n_vars - 1
+  std::vector<int> out_value;  // [n_out] their values
+  int n_slab() const { return n_int + n_bool; }
   std::vector<int> perm, inv;  // perm[caller's id] = internal id, inv = its inverse
   int bool_words() const { return (n_bool + 15) / 16; }
   int int_bytes() const { return c16 ? 4 : 8; }
   int bool_word0() const { return c16 ? n_int : 2 * n_int; }  // first Boolean word, in 32-bit words from the start of the slab
   int unent_off() const { return n_int * int_bytes() + bool_words() * 4; }
-  int vext(int n_slices) const { return (int)((((size_t)unent_off() + (size_t)std::max(n_slices, 4) + 15) / 16) * 2); }  // (>= one 32-bit word of entailment bits)
+  // slab size in 8-byte units: the domains, then the "not entailed" marks of the slices -- a byte per slice for the sweeps with entailed-slice
+  // removal (every wave writes its own), a bit per slice for the event-driven fixpoint (dirty_words 32-bit words)
+  int vext(int n_slices, bool event) const {
+    const size_t marks = event ? (size_t)((n_slices + 31) / 32) * 4 : (size_t)std::max(n_slices, 4);
+    return (int)((((size_t)unent_off() + std::max<size_t>(marks, 4) + 15) / 16) * 2);
+  }
 };
 
-Layout make_layout(int32_t n_vars, int32_t n_stores, const tb_itv* stores, bool compact, bool want_c16 = false) {
+// (`pinned`: a variable the kernels address by index outside the records -- the objective -- stays in the slab; `outs`: constants leave it)
+Layout make_layout(int32_t n_vars, int32_t n_stores, const tb_itv* stores, bool compact, bool want_c16 = false, bool outs = false, int32_t pinned = -1) {
   Layout L;
   L.n_vars = n_vars; L.compact = compact;
   L.perm.resize((size_t)n_vars); L.inv.resize((size_t)n_vars);
-  std::vector<char> is_bool((size_t)n_vars, 0);
+  std::vector<char> is_bool((size_t)n_vars, 0), is_out((size_t)n_vars, 0);
   if (compact) {
+    int n_b = 0;
     for (int32_t v = 0; v < n_vars; ++v) {
       bool b = n_stores > 0;
       for (int32_t k = 0; k < n_stores && b; ++k) { const tb_itv d = stores[(size_t)k * (size_t)n_vars + (size_t)v]; b = d.lb >= 0 && d.ub <= 1; }
       is_bool[(size_t)v] = b ? 1 : 0;
+      n_b += b ? 1 : 0;
     }
+    if (outs && n_b > 0)
+      for (int32_t v = 0; v < n_vars; ++v) {
+        if (is_bool[(size_t)v] || v == pinned) continue;
+        const tb_itv d0 = stores[v];
+        bool c = d0.lb == d0.ub && d0.lb > -(1 << 30) && d0.lb < (1 << 30);
+        for (int32_t k = 1; k < n_stores && c; ++k) { const tb_itv d = stores[(size_t)k * (size_t)n_vars + (size_t)v]; c = d.lb == d0.lb && d.ub == d0.ub; }
+        is_out[(size_t)v] = c ? 1 : 0;
+      }
   }
   int next = 0;
-  for (int32_t v = 0; v < n_vars; ++v) if (!is_bool[(size_t)v]) L.perm[(size_t)v] = next++;
+  for (int32_t v = 0; v < n_vars; ++v) if (!is_bool[(size_t)v] && !is_out[(size_t)v]) L.perm[(size_t)v] = next++;
   L.n_int = next;
   for (int32_t v = 0; v < n_vars; ++v) if (is_bool[(size_t)v]) L.perm[(size_t)v] = next++;
-  L.n_bool = n_vars - L.n_int;
+  L.n_bool = next - L.n_int;
+  for (int32_t v = 0; v < n_vars; ++v) if (is_out[(size_t)v]) { L.perm[(size_t)v] = next++; L.out_value.push_back(stores[v].lb); }
+  L.n_out = n_vars - L.n_int - L.n_bool;
   for (int32_t v = 0; v < n_vars; ++v) L.inv[(size_t)L.perm[(size_t)v]] = v;
   if (L.n_bool == 0) L.compact = false;
-  if (L.compact && want_c16) {  // every non-Boolean variable within -32768..32767 in every store of the batch
+  if (L.compact && want_c16) {  // every non-Boolean variable of the slab within -32768..32767 in every store of the batch
     bool ok = true;
     for (int32_t v = 0; v < n_vars && ok; ++v) {
-      if (is_bool[(size_t)v]) continue;
+      if (is_bool[(size_t)v] || is_out[(size_t)v]) continue;
       for (int32_t k = 0; k < n_stores && ok; ++k) { const tb_itv d = stores[(size_t)k * (size_t)n_vars + (size_t)v]; ok = d.lb >= -32768 && d.ub <= 32767; }
     }
     L.c16 = ok;
@@ -139,6 +165,7 @@ void encode_slab(const Layout& L, const tb_itv* orig, unsigned char* slab) {
       else ints[i] = orig[v];
       continue;
     }
+    if (i >= L.n_slab()) continue;  // a constant kept out of the slab
     const int b = i - L.n_int;
     const unsigned bits = (orig[v].lb >= 1 ? 1u : 0u) | (orig[v].ub <= 0 ? 2u : 0u);
     words[b >> 4] |= bits << ((b & 15) * 2);
@@ -151,6 +178,7 @@ void decode_slab(const Layout& L, const unsigned char* slab, tb_itv* orig_out) {
   for (int i = 0; i < L.n_vars; ++i) {
     tb_itv d;
     if (i < L.n_int) { if (L.c16) { d.lb = (int)(short)(ints16[i] & 0xffffu); d.ub = (int)ints16[i] >> 16; } else d = ints[i]; }
+    else if (i >= L.n_slab()) { d.lb = d.ub = L.out_value[(size_t)(i - L.n_slab())]; }
     else { const int b = i - L.n_int; const unsigned bits = (words[b >> 4] >> ((b & 15) * 2)) & 3u; d.lb = (int)(bits & 1u); d.ub = 1 - (int)(bits >> 1); }
     orig_out[L.inv[(size_t)i]] = d;
   }
@@ -175,16 +203,17 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   if (auto_threads && !event && !cfg.only_global_memory && (n_props + 63) / 64 >= 32) {
     // A store that leaves room for a single workgroup per CU: make that workgroup wide enough to fill the CU's 16 wave
     // slots (trains15 simplified, 87 KB store: 4.9e6 -> 7.3e6 nodes/s going from 512 to 1024 threads).
-    const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64) * 8) + dirty_region_bytes(((n_props + 63) / 64 + 31) / 32) + 4096 + SH_BYTES;
+    const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64, event) * 8) + dirty_region_bytes(((n_props + 63) / 64 + 31) / 32) + 4096 + SH_BYTES;
     while (T < 1024 && slab <= (size_t)caps.lds_per_cu && std::min<size_t>((size_t)caps.lds_per_cu / slab, (size_t)(2048 / T)) * (size_t)(T / 64) < 16) T *= 2;
   }
   bool small_wg = false;
   if (auto_threads && T == 256 && !cfg.only_global_memory && (event || n_props < 2048)) {
-    // What a CU needs is subproblems in flight (and the fewer waves meet at a barrier, the less they wait for each other): when 14
-    // slabs fit in LDS, 14 workgroups of two waves beat 7 of four -- accap_a3: 4.5e7 -> 7.0e7 nodes/s (event), 3.1e7 -> 5.3e7 (wac1).
-    // wordpress7_500 (8 slabs fit) and trains15 (6) keep their four waves.
-    const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64) * 8) + dirty_region_bytes(((n_props + 63) / 64 + 31) / 32) + align16(256 * 4) + SH_BYTES;
-    if (slab * 14 <= (size_t)caps.lds_per_cu) { T = 128; small_wg = true; }
+    // What a CU needs is subproblems in flight (and the fewer waves meet at a barrier, the less they wait for each other): when 10
+    // slabs fit in LDS, workgroups of two waves beat 7 of four -- accap_a3, 14 per CU: 4.5e7 -> 7.0e7 nodes/s (event), 3.1e7 -> 5.3e7 (wac1);
+    // wordpress7_500 with its constants out of the slab (Layout), same box: 7 x 256 threads 3.38e7, 8 x 128 3.22e7, 10 x 128 3.71e7,
+    // 12 x 128 3.95e7.  trains15 (6 slabs fit) keeps its four waves.
+    const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64, event) * 8) + dirty_region_bytes(((n_props + 63) / 64 + 31) / 32) + align16(256 * 4) + SH_BYTES;
+    if (slab * 10 <= (size_t)caps.lds_per_cu) { T = 128; small_wg = true; }
   }
   if (T != 64 && T != 128 && T != 256 && T != 512 && T != 1024) return fail(TB_ERR_INVALID, "threads_per_block must be 64, 128, 256, 512 or 1024");
   p.threads = T;
@@ -192,7 +221,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   const size_t lds = (size_t)caps.lds_per_cu;
   // slab = domains + one entailment byte per slice, rounded to an even number of intervals so that every slab of a
   // stack (stores, snapshots) starts 16-byte aligned and copies as 16-byte words
-  const int n_slices = (n_props + 63) / 64, dirty_words = (n_slices + 31) / 32, vext = lay.vext(n_slices);
+  const int n_slices = (n_props + 63) / 64, dirty_words = (n_slices + 31) / 32, vext = lay.vext(n_slices, event);
   p.n_slices = n_slices; p.dirty_words = dirty_words; p.vext = vext;
   p.compact = lay.compact ? (lay.c16 ? 2 : 1) : 0; p.n_int = lay.n_int; p.unent_off = lay.unent_off();
   // store slab = domains + one entailment byte per 64-propagator slice; the dirty bitmap and the change list of the
@@ -317,8 +346,14 @@ Adjacency build_adjacency(int32_t n_vars, int32_t n_props, const tb_prop* props,
 
 // Rewrite the caller's bytecodes into the engine's packed records (propagators.hpp): word0 = pack-time class |
 // "operand is read by no other slice" bits 8-10 | original op << 12 | classes present in the 64-record slice << 16.
+// An operand that is a constant kept out of the slab (internal id >= n_slab, Layout) is replaced by its value with the sign bit set.
+inline int operand_field(int v, int n_slab, const std::vector<int>& value) {
+  return v >= n_slab ? (int)(0x80000000u | ((unsigned)value[(size_t)v] & 0x7fffffffu)) : v;
+}
+inline bool field_is_value(int f) { return f < 0; }
+inline int field_value(int f) { return (int)((unsigned)f << 1) >> 1; }
 std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::vector<char>& is_const, const std::vector<int>& value,
-                             const Adjacency& adj, int n_int) {
+                             const Adjacency& adj, int n_int, int n_slab) {
   // padded to whole slices with idle records (never narrow, always entailed): the kernels may load any lane of a slice
   std::vector<int4> out(((size_t)n_props + 63) / 64 * 64, make_int4(K_LEQ_T, 0, 0, 0));
   for (int32_t base = 0; base < n_props; base += 64) {
@@ -337,7 +372,7 @@ std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::v
         const std::vector<Reader>& l = adj.lists[(size_t)vs[k]];
         if (l.empty() || (l.size() == 1 && l[0].slice == s)) priv |= 1 << k;
       }
-      out[(size_t)i] = make_int4(cls | (priv << 8) | (p.op << 12), p.x, p.y, p.z);
+      out[(size_t)i] = make_int4(cls | (priv << 8) | (p.op << 12), operand_field(p.x, n_slab, value), operand_field(p.y, n_slab, value), operand_field(p.z, n_slab, value));
     }
     // operand kinds of the slice (bits 26-31, two per operand): 1 all integer variables, 2 all Booleans of the COMPACT layout
     // (internal id >= n_int), 3 all constants, 0 mixed.  The event kernels have dedicated runs for the commonest signatures.
@@ -558,7 +593,7 @@ std::vector<int2> slice_infos(const std::vector<int4>& packed, const std::vector
     for (int l = 0; l < n_real && finite; ++l) {
       const int4 r = packed[(size_t)s * 64 + (size_t)l];
       for (int v : {r.y, r.z, r.w}) {
-        const tb_itv d = root[v];
+        const tb_itv d = field_is_value(v) ? tb_itv{field_value(v), field_value(v)} : root[v];
         if (d.lb < -(1 << 29) || d.ub > (1 << 29)) finite = false;
       }
     }
@@ -647,7 +682,7 @@ int prepare_kernel(bool solve, int mem, int tmax, bool event, int opt, int bytes
 // Layout + launch plan of a network.  The COMPACT layout is chosen for the event-driven fixpoint when it brings a
 // store that would otherwise sit in global memory into LDS (tb_config.reserved[0]: 0x80000 never, 0x100000 always).
 int choose_layout(const tb_config& cfg, const DeviceCaps& caps, int32_t n_vars, int32_t n_stores, const tb_itv* stores, int32_t n_props,
-                  Layout* lay, LaunchPlan* plan) {
+                  Layout* lay, LaunchPlan* plan, int32_t pinned = -1) {
   *lay = make_layout(n_vars, n_stores, stores, false);
   int rc = plan_launch(cfg, caps, *lay, n_props, plan);
   // The sweeps take a compact layout only when it is forced (and never together with entailed-slice removal): measured r03, a sweep
@@ -655,14 +690,15 @@ int choose_layout(const tb_config& cfg, const DeviceCaps& caps, int32_t n_vars, 
   // 2.10e6 nodes/s plain (256 x 1024) against 1.81e6 compact (1280 x 256); trains15 6.77e6 against 7.44e6.
   const bool sweeps_opt_in = cfg.fixpoint != 2 && !cfg.entailed_prop_removal && (cfg.reserved[0] & 0x100000);
   if (rc != TB_OK || (cfg.fixpoint != 2 && !sweeps_opt_in) || (cfg.reserved[0] & 0x80000)) return rc;
-  Layout lc = make_layout(n_vars, n_stores, stores, true);
+  const bool outs = !(cfg.reserved[0] & 0x40000000);  // constants out of the slab (0x40000000: keep them in, A/B runs and tests)
+  Layout lc = make_layout(n_vars, n_stores, stores, true, false, outs, pinned);
   if (!lc.compact) return rc;
   LaunchPlan pc;
   if ((rc = plan_launch(cfg, caps, lc, n_props, &pc)) != TB_OK) return rc;
   // COMPACT16 (reserved[0] & 0x10000000 always when eligible, 0x20000000 never): half the bytes per integer variable.  Taken when it
   // puts more workgroups on a CU than COMPACT does, or brings the slab into LDS at all -- trains15: 50 KB -> 29 KB per workgroup.
   if (!(cfg.reserved[0] & 0x20000000)) {
-    Layout l16 = make_layout(n_vars, n_stores, stores, true, true);
+    Layout l16 = make_layout(n_vars, n_stores, stores, true, true, outs, pinned);
     LaunchPlan p16;
     if (l16.c16 && plan_launch(cfg, caps, l16, n_props, &p16) == TB_OK) {
       const bool better = (pc.mem_kind == TB_MEM_GLOBAL && p16.mem_kind != TB_MEM_GLOBAL) ||
@@ -832,7 +868,7 @@ struct tb_session {
 // Event-driven fixpoint with sorted records: plan for the class-padded record array (to_internal) when the store stays out of
 // global memory with it.  Returns the number of records the kernels will see.
 int32_t plan_records(const tb_config& cfg, const DeviceCaps& caps, int32_t n_vars, int32_t n_stores, const tb_itv* stores, int32_t n_props,
-                     const tb_prop* props, Layout* lay, LaunchPlan* plan) {
+                     const tb_prop* props, Layout* lay, LaunchPlan* plan, int32_t pinned = -1) {
   if (cfg.fixpoint != 2 || n_props == 0 || plan->mem_kind == TB_MEM_GLOBAL || (cfg.reserved[0] & (0x200000 | 0x20))) return n_props;
   const int32_t n_pad = padded_count(n_props, props, stores);
   // Worth it where the class-straddling slices are a large share of the network (accap_a3, 16 slices: +21 % nodes/s); on a large
@@ -840,7 +876,7 @@ int32_t plan_records(const tb_config& cfg, const DeviceCaps& caps, int32_t n_var
   if (n_pad == n_props || (n_pad + 63) / 64 >= 0xfffe || ((long long)(n_pad - n_props) * 16 < n_props && !(cfg.reserved[0] & 0x10))) return n_props;
   Layout l2;
   LaunchPlan p2;
-  if (choose_layout(cfg, caps, n_vars, n_stores, stores, n_pad, &l2, &p2) != TB_OK || p2.mem_kind == TB_MEM_GLOBAL) return n_props;
+  if (choose_layout(cfg, caps, n_vars, n_stores, stores, n_pad, &l2, &p2, pinned) != TB_OK || p2.mem_kind == TB_MEM_GLOBAL) return n_props;
   *lay = std::move(l2);
   *plan = p2;
   return n_pad;
@@ -973,7 +1009,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     const InternalNet net = to_internal(lay, stores_inout, n_props, props, (cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL, cfg.fixpoint == 2 && !(cfg.reserved[0] & 0x8000000), n_rec != n_props);
     if ((int32_t)net.props.size() != n_rec) return fail(TB_ERR_INVALID, "internal: record padding does not match its plan");
     const Adjacency adj = build_adjacency(n_vars, n_rec, net.props.data(), is_const, value, !(cfg.reserved[0] & 0x80));
-    std::vector<int4> packed = pack_props(n_rec, net.props.data(), is_const, value, adj, lay.n_int);
+    std::vector<int4> packed = pack_props(n_rec, net.props.data(), is_const, value, adj, lay.n_int, lay.n_slab());
     packed.resize((size_t)plan.n_slices * 64, make_int4(K_LEQ_T, 0, 0, 0));
     if (n_rec) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
     // hull of the batch, internal numbering: what "finite domains" means for a batch of stores
@@ -990,7 +1026,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   std::vector<unsigned char> slabs((size_t)n_stores * slab_bytes, 0);
   for (int32_t k = 0; k < n_stores; ++k) encode_slab(lay, stores_inout + (size_t)k * (size_t)n_vars, slabs.data() + (size_t)k * slab_bytes);
   HIP_TRY(hipMemcpy(d_stores, slabs.data(), slabs.size(), hipMemcpyHostToDevice));
-  P.n_vars = n_vars; P.n_props = n_rec; P.props = d_props;
+  P.n_vars = lay.n_slab(); P.n_props = n_rec; P.props = d_props;  // (the variables of the slab)
   P.fixpoint = cfg.fixpoint; P.wac1_threshold = (int)std::min<uint64_t>(cfg.wac1_threshold, 0x7fffffffu);
   P.mem_kind = plan.mem_kind; P.debug = cfg.reserved[0];
   const bool event = cfg.fixpoint == 2;
@@ -1063,8 +1099,8 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   resolve_fixpoint(&s->cfg, n_props);
   s->n_vars = n_vars; s->obj_var = obj_var;
   if ((rc = query_caps(s->cfg.device, &s->caps)) != TB_OK) return rc;
-  if ((rc = choose_layout(s->cfg, s->caps, n_vars, 1, root_store, n_props, &s->lay, &s->plan)) != TB_OK) return rc;
-  int32_t n_rec = plan_records(s->cfg, s->caps, n_vars, 1, root_store, n_props, props, &s->lay, &s->plan);  // records the kernels see
+  if ((rc = choose_layout(s->cfg, s->caps, n_vars, 1, root_store, n_props, &s->lay, &s->plan, obj_var)) != TB_OK) return rc;
+  int32_t n_rec = plan_records(s->cfg, s->caps, n_vars, 1, root_store, n_props, props, &s->lay, &s->plan, obj_var);  // records the kernels see
   {
     // cap the grid by what is actually resident (registers, LDS): queued workgroups of a persistent kernel only
     // add tail latency; re-plan so that the subproblem count follows the real workgroup count
@@ -1073,10 +1109,10 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     if (occ > 0 && (long long)occ * s->caps.cus < (long long)s->plan.num_blocks) {
       tb_config capped = s->cfg;
       capped.or_nodes = (uint64_t)occ * (uint64_t)s->caps.cus;
-      if ((rc = choose_layout(capped, s->caps, n_vars, 1, root_store, n_rec, &s->lay, &s->plan)) != TB_OK) return rc;
+      if ((rc = choose_layout(capped, s->caps, n_vars, 1, root_store, n_rec, &s->lay, &s->plan, obj_var)) != TB_OK) return rc;
       if (n_rec != n_props && s->plan.mem_kind == TB_MEM_GLOBAL) {  // (the padded array no longer fits next to the capped grid: plan the plain one)
         n_rec = n_props;
-        if ((rc = choose_layout(capped, s->caps, n_vars, 1, root_store, n_rec, &s->lay, &s->plan)) != TB_OK) return rc;
+        if ((rc = choose_layout(capped, s->caps, n_vars, 1, root_store, n_rec, &s->lay, &s->plan, obj_var)) != TB_OK) return rc;
       }
       if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->plan.kernel_event != 0, s->plan.kernel_opt, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     }
@@ -1092,8 +1128,10 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   std::vector<int32_t> i_off((size_t)n_strats + 1, 0), i_vars;
   for (int32_t k = 0; k < n_strats; ++k) {
     i_off[(size_t)k] = (int32_t)i_vars.size();
-    if (strat_off[k] == strat_off[k + 1] && lay.compact) for (int32_t v = 0; v < n_vars; ++v) i_vars.push_back(lay.perm[(size_t)v]);
-    else for (int32_t j = strat_off[k]; j < strat_off[k + 1]; ++j) i_vars.push_back(lay.perm[(size_t)strat_vars[j]]);
+    // (a constant kept out of the slab keeps its position in the list -- positions break ties -- as -1: assigned, never a candidate)
+    auto entry = [&](int32_t v) { const int i = lay.perm[(size_t)v]; return i >= lay.n_slab() ? -1 : i; };
+    if (strat_off[k] == strat_off[k + 1] && lay.compact) for (int32_t v = 0; v < n_vars; ++v) i_vars.push_back(entry(v));
+    else for (int32_t j = strat_off[k]; j < strat_off[k + 1]; ++j) i_vars.push_back(entry(strat_vars[j]));
   }
   i_off[(size_t)n_strats] = (int32_t)i_vars.size();
   total_svars = (int32_t)i_vars.size();
@@ -1113,7 +1151,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     std::vector<int> value;
     find_constants(n_vars, 1, net.store.data(), &is_const, &value);  // constants = singleton variables of the root store
     const Adjacency adj = build_adjacency(n_vars, n_rec, net.props.data(), is_const, value, !(s->cfg.reserved[0] & 0x80));
-    std::vector<int4> packed = pack_props(n_rec, net.props.data(), is_const, value, adj, lay.n_int);
+    std::vector<int4> packed = pack_props(n_rec, net.props.data(), is_const, value, adj, lay.n_int, lay.n_slab());
     packed.resize((size_t)plan.n_slices * 64, make_int4(K_LEQ_T, 0, 0, 0));
     if (n_rec) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
     if ((rc = upload_event_tables(s->bufs, s->P, s->cfg, s->plan, s->lay, n_rec, net.props, adj, packed, value, net.store.data())) != TB_OK) return rc;
@@ -1151,7 +1189,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   if ((rc = s->bufs.alloc(&P.ctrl, 1)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&s->d_now, 1)) != TB_OK) return rc;
 
-  P.n_vars = n_vars; P.n_props = n_rec; P.n_strats = n_strats; P.obj_var = i_obj;
+  P.n_vars = lay.n_slab(); P.n_props = n_rec; P.n_strats = n_strats; P.obj_var = i_obj;  // (the variables of the slab)
   P.props = d_props; P.root_store = d_root;
   P.strat_var_order = d_vo; P.strat_val_order = d_vl; P.strat_off = d_off; P.strat_vars = d_sv;
   P.fixpoint = s->cfg.fixpoint;

@@ -199,18 +199,24 @@ __device__ __forceinline__ unsigned* bool_words(int2* store, int ni) { return re
 template <int C>
 __device__ __forceinline__ const unsigned* bool_words(const int2* store, int ni) { return reinterpret_cast<const unsigned*>(store) + (C == 2 ? ni : 2 * ni); }
 
+// An operand field with the sign bit set is not a variable but the VALUE of a constant the layout keeps out of the slab (engine.hip: Layout,
+// operand_field; COMPACT layouts only): no memory access -- the load below goes to word 0 and is discarded by a select -- and nothing to
+// narrow: a rule that would move a constant has emptied it, and the caller raises the failure flag on the empty candidate.
+__device__ __forceinline__ int field_value(int v) { return (int)((unsigned)v << 1) >> 1; }
 template <int C>
 __device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v) {
   if (C == 0) return load_int<0>(store, v);
+  const bool isk = v < 0;
+  const int kv = field_value(v);
   if (C == 2) {
     // one 4-byte load whatever the kind: the integer's packed bounds, or the Boolean word holding the variable's two bits
     const bool isb = v >= ni;
     const int b = v - ni;
-    const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + (isb ? ni + (b >> 4) : v), TB_RLX, TB_WG);
+    const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + (isk ? 0 : (isb ? ni + (b >> 4) : v)), TB_RLX, TB_WG);
     const unsigned bits = (w >> ((b & 15) * 2)) & 3u;
     Itv d;
-    d.lb = isb ? (int)(bits & 1u) : (int)(short)(w & 0xffffu);
-    d.ub = isb ? 1 - (int)(bits >> 1) : (int)w >> 16;
+    d.lb = isk ? kv : (isb ? (int)(bits & 1u) : (int)(short)(w & 0xffffu));
+    d.ub = isk ? kv : (isb ? 1 - (int)(bits >> 1) : (int)w >> 16);
     return d;
   }
   // COMPACT: one 8-byte load whatever the kind of the variable -- an interval, or the pair of Boolean words holding its
@@ -219,13 +225,13 @@ __device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v) {
   Itv d;
   const bool isb = v >= ni;
   const int b = v - ni;
-  const int idx = isb ? ni + (b >> 5) : v;
+  const int idx = isk ? 0 : (isb ? ni + (b >> 5) : v);
   const long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + idx), TB_RLX, TB_WG);
   const int lo = (int)(raw & 0xffffffffll), hi = (int)(raw >> 32);
   const unsigned word = (unsigned)(((b >> 4) & 1) ? hi : lo);
   const unsigned bits = (word >> ((b & 15) * 2)) & 3u;
-  d.lb = isb ? (int)(bits & 1u) : lo;
-  d.ub = isb ? 1 - (int)(bits >> 1) : hi;
+  d.lb = isk ? kv : (isb ? (int)(bits & 1u) : lo);
+  d.ub = isk ? kv : (isb ? 1 - (int)(bits >> 1) : hi);
   return d;
 }
 // COMPACT16: narrow one half of an integer's word (compare-and-swap: the other bound lives in the same word)
@@ -257,6 +263,7 @@ __device__ __forceinline__ void lower_int_ub(int2* store, int v, int val) {
 }
 template <int C>
 __device__ __forceinline__ void raise_lb(int2* store, int ni, int v, int val) {
+  if (C && v < 0) return;  // a constant kept out of the slab (load_dom)
   if (C && v >= ni) {
     const int b = v - ni;
     if (val >= 1) (void)__hip_atomic_fetch_or(bool_words<C>(store, ni) + (b >> 4), 1u << ((b & 15) * 2), TB_RLX, TB_WG);
@@ -266,6 +273,7 @@ __device__ __forceinline__ void raise_lb(int2* store, int ni, int v, int val) {
 }
 template <int C>
 __device__ __forceinline__ void lower_ub(int2* store, int ni, int v, int val) {
+  if (C && v < 0) return;
   if (C && v >= ni) {
     const int b = v - ni;
     if (val <= 0) (void)__hip_atomic_fetch_or(bool_words<C>(store, ni) + (b >> 4), 2u << ((b & 15) * 2), TB_RLX, TB_WG);
@@ -697,8 +705,13 @@ __device__ __forceinline__ unsigned lean_class_run(const RunEnv& E, const int cl
   const int vx = ox.v, vy = oy.v, vz = oz.v;  // idle lanes look at variable 0 (a constant) and move nothing
   unsigned long long mxl = 0, mxu = 0, myl = 0, myu = 0, mzl = 0, mzu = 0;  // lanes that moved each bound during the run
   unsigned iters = 0;
+  // a column of constants (kind 3: singletons of the root, in the slab or carried by the record) is read once: it can only change by failing
+  Itv KX{0, 0}, KY{0, 0}, KZ{0, 0};
+  if (kx == 3) KX = load_dom<C>(store, ni, vx);
+  if (ky == 3) KY = load_dom<C>(store, ni, vy);
+  if (kz == 3) KZ = load_dom<C>(store, ni, vz);
   for (;;) {
-    const Itv X = lean_load<C>(store, ni, ox, kx), Y = lean_load<C>(store, ni, oy, ky), Z = lean_load<C>(store, ni, oz, kz);
+    const Itv X = kx == 3 ? KX : lean_load<C>(store, ni, ox, kx), Y = ky == 3 ? KY : lean_load<C>(store, ni, oy, ky), Z = kz == 3 ? KZ : lean_load<C>(store, ni, oz, kz);
     int xl = X.lb, xu = X.ub, yl = Y.lb, yu = Y.ub, zl = Z.lb, zu = Z.ub;  // the new bounds: start from the current ones
     bool ent;
     if (cls == K_ADD) {
@@ -1895,7 +1908,7 @@ __device__ __forceinline__ void split_node(const DevProblem& P, BlockShared& sh,
 
 // ---- the persistent search kernel ----------------------------------------------------------------
 
-constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 255) / 256 * 256);
+constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 15) / 16 * 16);
 
 // The event-driven variant is latency bound: its 256-thread form asks the register allocator for 7 waves per
 // SIMD (<= 72 VGPRs) so that 7 workgroups are resident per CU when their stores fit (wordpress7_500: 7 x 22.7 KB of
