@@ -13,9 +13,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 rows = []
-work = [("wordpress7_500", "example_wordpress7_500.fzn", 6_000_000, 1_500_000), ("accap_a3", "accap_a3.fzn", 12_000_000, 12_000_000),
-        ("trains15", "trains15.fzn", 12_000_000, 4_000_000), ("synthetic 100k x 500k", None, 8000, 8000)]
-modes = [("event", dict(fixpoint=2), 0), ("event, compact store forced", dict(fixpoint=2, debug=0x100000), 0), ("wac1", dict(fixpoint=1), 1), ("ac1", dict(fixpoint=0), 1),
+work = [("wordpress7_500", "example_wordpress7_500.fzn", 48_000_000, 3_000_000), ("accap_a3", "accap_a3.fzn", 48_000_000, 24_000_000),
+        ("trains15", "trains15.fzn", 24_000_000, 8_000_000), ("synthetic 100k x 500k", None, 8000, 8000)]
+modes = [("event", dict(fixpoint=2), 0), ("event, plain store (no compact layout)", dict(fixpoint=2, debug=0x80000), 0),
+         ("event, compact layout with the constants kept in the slab", dict(fixpoint=2, debug=0x40000000), 0),
+         ("wac1", dict(fixpoint=1), 1), ("wac1 on the compact layout (opt-in)", dict(fixpoint=1, debug=0x100000), 1), ("ac1", dict(fixpoint=0), 1),
          ("wac1 + entailed removal", dict(fixpoint=1, entailed_prop_removal=1), 1)]
 for name, fzn, b_event, b_sweep in work:
     tcn = make_synthetic(100_000, 500_000, seed=42) if fzn is None else preprocess.load_fzn_simplified(os.path.join(ROOT, "benchmarks", fzn))[1]
@@ -28,7 +30,7 @@ for name, fzn, b_event, b_sweep in work:
                "memory": capi.MEM_KINDS[st["mem_kind"]], "lds_bytes": st["shared_bytes"], "nodes": st["nodes"], "propagations_per_s": st["num_deductions"] / secs, "nodes_per_s": st["nodes"] / secs,
                "propagations_per_node": st["num_deductions"] / max(1, st["nodes"]), "kernel_ms": secs * 1e3}
         rows.append(row)
-        print(f"{name:22s} {mode:28s} {row['workgroups']:5d}x{row['threads']:<4d} {row['memory']:12s} {row['propagations_per_s']:.3e} props/s {row['nodes_per_s']:.3e} nodes/s "
+        print(f"{name:22s} {mode:58s} {row['workgroups']:5d}x{row['threads']:<4d} {row['memory']:12s} {row['propagations_per_s']:.3e} props/s {row['nodes_per_s']:.3e} nodes/s "
               f"{row['propagations_per_node']:.0f} props/node", flush=True)
 if a.out:
     json.dump({"note": "python scripts/rates_table.py on one MI355X; simplified networks; node budget for the whole GPU (stop_after_n_nodes_total), second of two runs", "rows": rows}, open(a.out, "w"), indent=1)
