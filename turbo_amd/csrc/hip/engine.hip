@@ -217,7 +217,9 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   }
   if (T != 64 && T != 128 && T != 256 && T != 512 && T != 1024) return fail(TB_ERR_INVALID, "threads_per_block must be 64, 128, 256, 512 or 1024");
   p.threads = T;
-  p.tmax = T <= 256 ? 256 : 1024;
+  // (the event kernels have an instantiation of their own for workgroups of at most two waves: 7 waves per SIMD -- 72 VGPRs -- there,
+  //  6 -- 84 VGPRs -- for the 256-thread ones, whose workgroups per CU are limited by LDS before registers: trains15 2.88e7 -> 3.12e7 nodes/s)
+  p.tmax = (event && T <= 128) ? 128 : (T <= 256 ? 256 : 1024);
   const size_t lds = (size_t)caps.lds_per_cu;
   // slab = domains + one entailment byte per slice, rounded to an even number of intervals so that every slab of a
   // stack (stores, snapshots) starts 16-byte aligned and copies as 16-byte words
@@ -647,11 +649,22 @@ int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
 // (The run-time selectors are evaluated ONCE into locals: callers pass expressions, and `a == 2 && a == 2 ? x : y` is not
 //  what an unparenthesised `event && opt` was meant to be -- r02 found the solve launch of "sweeps + entailed removal" going
 //  to the event kernel that way.)
+// DISPATCH_KERNEL_WIDE: the 256- and 1024-thread instantiations (everything but the search with two-wave event workgroups);
+// DISPATCH_KERNEL adds the 128-thread event instantiations of the search kernel.
 #define DISPATCH_KERNEL(FN, mem, tmax, event, opt, ...)                                 \
+  do {                                                                                  \
+    if ((tmax) == 128) {                                                                \
+      const int dk_mem = (mem), dk_opt = (opt);                                         \
+      if (dk_opt == 2) DISPATCH_MEM(FN, 128, true, 2, dk_mem, __VA_ARGS__);             \
+      else if (dk_opt) DISPATCH_MEM(FN, 128, true, 1, dk_mem, __VA_ARGS__);             \
+      else DISPATCH_MEM(FN, 128, true, 0, dk_mem, __VA_ARGS__);                         \
+    } else DISPATCH_KERNEL_WIDE(FN, mem, tmax, event, opt, __VA_ARGS__);                \
+  } while (0)
+#define DISPATCH_KERNEL_WIDE(FN, mem, tmax, event, opt, ...)                            \
   do {                                                                                  \
     const int dk_mem = (mem), dk_tmax = (tmax), dk_opt = (opt);                         \
     const bool dk_event = (event);                                                      \
-    if (dk_tmax == 256) {                                                               \
+    if (dk_tmax <= 256) {                                                               \
       if (dk_event && dk_opt == 2) DISPATCH_MEM(FN, 256, true, 2, dk_mem, __VA_ARGS__); \
       else if (dk_event && dk_opt) DISPATCH_MEM(FN, 256, true, 1, dk_mem, __VA_ARGS__); \
       else if (dk_event) DISPATCH_MEM(FN, 256, true, 0, dk_mem, __VA_ARGS__);           \
@@ -675,7 +688,7 @@ int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
 int prepare_kernel(bool solve, int mem, int tmax, bool event, int opt, int bytes, int threads, int* max_blocks_per_cu) {
   int rc = TB_OK;
   if (solve) DISPATCH_KERNEL(rc = prepare_solve, mem, tmax, event, opt, (bytes, threads, max_blocks_per_cu));
-  else DISPATCH_KERNEL(rc = prepare_prop, mem, tmax, event, opt, (bytes, threads, max_blocks_per_cu));
+  else DISPATCH_KERNEL_WIDE(rc = prepare_prop, mem, tmax, event, opt, (bytes, threads, max_blocks_per_cu));  // (batch propagation: no 128-thread instantiation)
   return rc;
 }
 
@@ -1056,7 +1069,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   }
   const int grid = std::min(n_stores, plan.num_blocks);
   HIP_TRY(hipEventRecord(e0, stream));
-  DISPATCH_KERNEL(propagate_kernel, plan.mem_kind, plan.tmax, event, compact, <<<dim3(grid), dim3(plan.threads), plan.shared_bytes, stream>>>(P, d_stores, d_out, n_stores));
+  DISPATCH_KERNEL_WIDE(propagate_kernel, plan.mem_kind, plan.tmax, event, compact, <<<dim3(grid), dim3(plan.threads), plan.shared_bytes, stream>>>(P, d_stores, d_out, n_stores));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e1, stream));
   HIP_TRY(hipStreamSynchronize(stream));
@@ -1271,7 +1284,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
       if ((rc = device_now(s->stream, s->d_now, &now)) != TB_OK) return rc;
       Q.deadline_ticks = now + (long long)s->cfg.timeout_ms * (long long)s->caps.wall_khz;
     }
-    DISPATCH_KERNEL(propagate_kernel, plan.mem_kind, plan.tmax, event, opt, <<<dim3(1), dim3(plan.threads), plan.shared_bytes, s->stream>>>(Q, d_root, d_out, 1));
+    DISPATCH_KERNEL_WIDE(propagate_kernel, plan.mem_kind, plan.tmax, event, opt, <<<dim3(1), dim3(plan.threads), plan.shared_bytes, s->stream>>>(Q, d_root, d_out, 1));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
     PropagateOut o;

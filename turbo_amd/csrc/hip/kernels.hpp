@@ -18,6 +18,9 @@
 
 // Build-time variants of the 256-thread event kernel (experiments): waves per SIMD the register allocator is asked for,
 // software prefetch of the next slice's records (a loss below 5 waves' worth of registers: the prefetched records spill).
+#ifndef TB_EVENT_WAVES_256
+#define TB_EVENT_WAVES_256 6
+#endif
 #ifndef TB_EVENT_WAVES
 #define TB_EVENT_WAVES 7
 #endif
@@ -1915,7 +1918,7 @@ constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 15) / 16 * 16);
 // LDS; measured 17.9 / 20.5 / 22.3 / 23.4e6 nodes/s with 4 / 5 / 6 / 7); the sweep variants are VALU bound and keep 4.
 // OPT: the COMPACT store layout for the event kernels, entailed-slice removal for the sweeping ones.
 template <int MEM, int TMAX, bool EVENT, int OPT>
-__global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 256) ? TB_EVENT_WAVES : (TMAX == 256 ? 5 : 4)) solve_kernel(DevProblem by_value, const DevProblem* __restrict__ problem, Mailbox* mbox) {
+__global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES : ((EVENT && TMAX == 256) ? TB_EVENT_WAVES_256 : (TMAX == 256 ? 5 : 4))) solve_kernel(DevProblem by_value, const DevProblem* __restrict__ problem, Mailbox* mbox) {
   // The problem description is read through a pointer, not passed by value: as kernel arguments its ~70 scalars were all
   // hoisted into SGPRs for the whole persistent loop and 260 of them spilled through VGPR lanes (v_writelane / v_readlane,
   // VALU work on an issue-bound kernel); behind a pointer the compiler loads a field where it is used (scalar cache):
