@@ -96,7 +96,8 @@ typedef struct {
                                            0x40000 event mode accepts < 4 workgroups per CU in LDS; 0x80000 never / 0x100000 always
                                            use the compact (2-bit Boolean) store layout of the event kernels (0x100000 with the sweeps and
                                            without entailed_prop_removal: the sweeps on that layout, an opt-in); 0x10000000 always / 0x20000000
-                                           never pack integer variables as 16-bit bounds on top of it (COMPACT16); 0x200000 keep the caller's
+                                           never pack integer variables as 16-bit bounds on top of it (COMPACT16); 0x40000000 keep the non-Boolean singletons
+                                           of the root in the slab (by default the compact layouts carry their values in the records); 0x200000 keep the caller's
                                            propagator order instead of sorting the records by class; 0x400000 count slice
                                            runs instead of propagator evaluations; 0x800000 test aid: keep the store every workgroup stopped
                                            on (tb_session_debug_last_store); 0x1000000 no work stealing between linked GPUs (A/B runs, tests);
