@@ -38,9 +38,9 @@ if ROOT not in sys.path:
 
 # instance, node budget of one step for the event / sweeping fixpoints.  The budget is the same at every N (strong scaling), so
 # it is sized for the LARGEST run: at 8 GPUs a step of the headline workload still lasts >= 0.3 s (process-launch skew after the
-# arm -> barrier -> start handshake is well under that), which makes it 2-3 s on one GPU.
+# arm -> barrier -> start handshake is well under that), which makes it 3-4 s on one GPU.
 WORKLOADS = {
-    "wordpress7_500": ("example_wordpress7_500.fzn", 96_000_000, 6_000_000),
+    "wordpress7_500": ("example_wordpress7_500.fzn", 144_000_000, 6_000_000),
     "accap_a3": ("accap_a3.fzn", 24_000_000, 24_000_000),
     "trains15": ("trains15.fzn", 24_000_000, 8_000_000),
     "synthetic": ("synthetic 100k x 500k (seed 42)", 48_000, 24_000),
