@@ -63,7 +63,7 @@ sanitize:
 	$(CC) $(SAN) -std=c11 -c oracle/oracle.c -o build/oracle_san.o
 	$(CXX) $(SAN) -std=c++17 tests/tools/san_front.cpp $(FRONT_SRC) -o build/san_front
 	$(CXX) $(SAN) -std=c++17 tests/tools/san_oracle.cpp $(FRONT_SRC) build/oracle_san.o -o build/san_oracle
-	build/san_front benchmarks/*.fzn benchmarks/test_data/*.fzn benchmarks/test_data/*.xml benchmarks/unsolved_bugs_data/*.fzn > build/san_front.log
+	build/san_front benchmarks/*.fzn benchmarks/test_data/*.fzn benchmarks/test_data/*.xml tests/golden/xcsp3/*.xml benchmarks/unsolved_bugs_data/*.fzn > build/san_front.log
 	build/san_oracle benchmarks/*.fzn benchmarks/test_data/*.fzn benchmarks/unsolved_bugs_data/bigdom.fzn > build/san_oracle.log
 	@echo "sanitize: no report"
 

@@ -227,6 +227,20 @@ def test_solution_counts_of_the_wider_constraint_set(name, xml, expected):
     assert n == expected
 
 
+def test_sanitizer_corpus_holds_every_instance_above():
+    """`make sanitize` runs the ASan + UBSan build of the front end over tests/golden/xcsp3/*.xml: the instances of the two tables above,
+    one file each (regenerate a file by writing the `xml` of its row)."""
+    rows = []
+    for f in (test_solution_counts_match_brute_force, test_solution_counts_of_the_wider_constraint_set):
+        for mark in f.pytestmark:
+            if mark.name == "parametrize":
+                rows += [tuple(getattr(r, "values", r))[:2] for r in mark.args[1]]
+    corpus = os.path.join(ROOT, "tests", "golden", "xcsp3")
+    assert sorted(os.listdir(corpus)) == sorted(name + ".xml" for name, _ in rows)
+    for name, xml in rows:
+        assert open(os.path.join(corpus, name + ".xml")).read() == xml, name
+
+
 def test_objectives():
     v = '<array id="a" size="[3]"> 0..4 </array>'
     c = "<allDifferent> a[] </allDifferent><sum><list> a[] </list><condition> (ge,7) </condition></sum>"
