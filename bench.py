@@ -200,9 +200,11 @@ def main() -> int:
     ap.add_argument("--debug-bits", type=lambda v: int(v, 0), default=0, help="tuning knobs of tb_config.reserved[0] (experiments only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="testing aid: gloo lets two ranks share one GPU")
+    ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"], help="default nccl (= RCCL); gloo with --share-device (RCCL refuses two ranks on one GPU)")
     ap.add_argument("--share-device", action="store_true", help="testing aid: every rank uses cuda:0")
     args = ap.parse_args()
+    if args.dist_backend is None:
+        args.dist_backend = "gloo" if args.share_device else "nccl"
 
     # The cells the GPUs exchange through travel between processes as dmabuf IPC handles: the legacy IPC mode of the HSA runtime
     # is not supported by the host driver (hipIpcGetMemHandle fails with "invalid argument").  Set before HIP initialises, in
