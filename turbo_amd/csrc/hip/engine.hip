@@ -240,7 +240,9 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   if (bpc_max < 1) bpc_max = 1;
   if (cfg.only_global_memory) {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
-  } else if ((fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
+  } else if (!event && !lay.compact && (fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
+    // (records in LDS: the plain sweeps on small networks only.  The event kernels and the compact layouts have no such instantiation:
+    //  their records come out of L2 fast enough, see below, and a third memory kind for them is a quarter of the library's compile time.)
     p.mem_kind = TB_MEM_TCN_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b + props_b);
   // (event mode, measured on accap_a3: the records in LDS at the price of 3 workgroups per CU instead of 7 -- 1.39e7 against 4.50e7 nodes/s.
   //  The records come out of L2 fast enough; what a CU needs is subproblems in flight.)
@@ -641,8 +643,8 @@ int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
 #define DISPATCH_MEM(FN, TM, EV, CP, mem, ...)                                          \
   do {                                                                                  \
     if ((mem) == TB_MEM_GLOBAL) FN<TB_MEM_GLOBAL, TM, EV, CP> __VA_ARGS__;              \
-    else if ((mem) == TB_MEM_STORE_SHARED) FN<TB_MEM_STORE_SHARED, TM, EV, CP> __VA_ARGS__; \
-    else FN<TB_MEM_TCN_SHARED, TM, EV, CP> __VA_ARGS__;                                 \
+    else if ((mem) == TB_MEM_STORE_SHARED || (EV) || (CP) >= 2) FN<TB_MEM_STORE_SHARED, TM, EV, CP> __VA_ARGS__; /* (plan_launch never plans TCN_SHARED for these) */ \
+    else FN<TB_MEM_TCN_SHARED, ((EV) ? 256 : TM), false, ((CP) >= 2 ? 0 : (CP))> __VA_ARGS__; /* (dead for EV / CP >= 2: names an instantiation that exists anyway) */ \
   } while (0)
 // Fourth template flag (`opt`): the COMPACT store layout for the event-driven kernels (the sweeps are VALU bound:
 // decoding 2-bit Booleans would cost them more than the LDS it frees), entailed-slice removal for the sweeps.
