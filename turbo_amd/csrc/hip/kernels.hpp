@@ -676,8 +676,8 @@ __device__ __forceinline__ void bool_or(const BoolRef r, unsigned bits) { (void)
 // operands all have finite root domains within +-2^29 (engine.hip: slice_infos, bit 9 of the info word -- domains only shrink, so
 // this holds in the whole tree) needs none of that: plain 32-bit arithmetic cannot overflow, a class body touches only the bounds
 // its rule can move, and an empty input needs no test -- whoever emptied a domain raised the failure flag when it did.  Same rules,
-// same fixpoint as `evaluate_packed`; what changed is kept as six lane masks (SGPR pairs) and turned into per-lane event bits once,
-// after the run.  One pass is ~25 VALU instead of ~90.
+// same fixpoint as `evaluate_packed`; what changed is kept as per-lane event bits (six ballots per narrowing pass kept the scalar unit
+// busier than it pays).  One pass is ~25 VALU instead of ~90.
 // Returns the wave iterations; `nar_all`: bits 2k / 2k+1 = lower bound raised / upper bound lowered of operand k (0 x, 1 y, 2 z).
 // COMPACT layout: `kinds` (2 bits per operand, word0 bits 26-31 of the slice: 1 all integer variables, 2 all 2-bit Booleans, else mixed) picks
 // the cheapest way to read an operand -- a Boolean column is one ds_read_b32 and three VALU per pass, its word address and bit position
@@ -701,12 +701,18 @@ __device__ __forceinline__ Itv lean_load(int2* store, int ni, const LeanOperand<
   return load_int<C>(store, o.v);
 }
 template <int C>
-__device__ __forceinline__ unsigned lean_class_run(const RunEnv& E, const int cls, const int kinds, const int4 pr, const bool act, int2* store, const int ni, unsigned& wave_writes, int& nar_all) {
+__device__ __forceinline__ unsigned lean_class_run(const RunEnv& E, const int cls, const int kinds, const int4 pr, const bool act, int2* store, const int ni, unsigned& run_writes, unsigned& wave_writes, int& nar_all) {
   const int lane = threadIdx.x & 63, s = E.s;
   const int kx = kinds & 3, ky = (kinds >> 2) & 3, kz = (kinds >> 4) & 3;  // wave-uniform
   const LeanOperand<C> ox = lean_operand<C>(store, ni, pr.y, act, kx), oy = lean_operand<C>(store, ni, pr.z, act, ky), oz = lean_operand<C>(store, ni, pr.w, act, kz);
   const int vx = ox.v, vy = oy.v, vz = oz.v;  // idle lanes look at variable 0 (a constant) and move nothing
-  unsigned long long mxl = 0, mxu = 0, myl = 0, myu = 0, mzl = 0, mzu = 0;  // lanes that moved each bound during the run
+  // What moved during the run is kept per lane (bits 2k / 2k+1 = lower bound raised / upper bound lowered of operand k, a write count) -- except in
+  // the COMPACT kernels, which keep it as six lane masks in SGPR pairs: there this function is a side path (wordpress7_500: 0.4 of 70 runs per node),
+  // and the per-lane form costs the whole kernel registers: 4.28e7 -> 4.09e7 nodes/s, against 6.4e7 -> 7.8e7 on accap_a3 (COMPACT16), same box.
+  constexpr bool LANE_BITS = C != 1;
+  int nar_bits = 0;
+  unsigned lane_writes = 0;
+  unsigned long long mxl = 0, mxu = 0, myl = 0, myu = 0, mzl = 0, mzu = 0;  // (!LANE_BITS) lanes that moved each bound during the run
   unsigned iters = 0;
   // a column of constants (kind 3: singletons of the root, in the slab or carried by the record) is read once: it can only change by failing
   Itv KX{0, 0}, KY{0, 0}, KZ{0, 0};
@@ -782,11 +788,19 @@ __device__ __forceinline__ unsigned lean_class_run(const RunEnv& E, const int cl
       if (czl) raise_lb<C>(store, ni, vz, zl);
       if (czu) lower_ub<C>(store, ni, vz, zu);
     }
-    const unsigned long long bxl = wave_ballot(act && cxl), bxu = wave_ballot(act && cxu), byl = wave_ballot(act && cyl), byu = wave_ballot(act && cyu),
-                             bzl = wave_ballot(act && czl), bzu = wave_ballot(act && czu);
-    mxl |= bxl; mxu |= bxu; myl |= byl; myu |= byu; mzl |= bzl; mzu |= bzu;
-    wave_writes += (unsigned)(__builtin_popcountll(bxl) + __builtin_popcountll(bxu) + __builtin_popcountll(byl) + __builtin_popcountll(byu) +
-                              __builtin_popcountll(bzl) + __builtin_popcountll(bzu));
+    if constexpr (LANE_BITS) {
+      // what this lane moved in this pass as per-lane bits: kept off the scalar unit, the busiest resource of a network like accap_a3 (84 %;
+      // six ballots, six 64-bit ORs and six bit counts per narrowing pass are ~25 scalar instructions): accap_a3 6.4e7 -> 7.8e7 nodes/s
+      const int moved_bits = !act ? 0 : ((cxl ? 1 : 0) | (cxu ? 2 : 0) | (cyl ? 4 : 0) | (cyu ? 8 : 0) | (czl ? 16 : 0) | (czu ? 32 : 0));
+      nar_bits |= moved_bits;
+      lane_writes += (unsigned)__builtin_popcount((unsigned)moved_bits);
+    } else {
+      const unsigned long long bxl = wave_ballot(act && cxl), bxu = wave_ballot(act && cxu), byl = wave_ballot(act && cyl), byu = wave_ballot(act && cyu),
+                               bzl = wave_ballot(act && czl), bzu = wave_ballot(act && czu);
+      mxl |= bxl; mxu |= bxu; myl |= byl; myu |= byu; mzl |= bzl; mzu |= bzu;
+      wave_writes += (unsigned)(__builtin_popcountll(bxl) + __builtin_popcountll(bxu) + __builtin_popcountll(byl) + __builtin_popcountll(byu) +
+                                __builtin_popcountll(bzl) + __builtin_popcountll(bzu));
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (ld(&E.sh.bot)) break;
     if ((iters % WAVE_WATCHDOG_PERIOD) == 0) {  // watchdog inside the wave-local loop (see fixpoint)
@@ -794,7 +808,10 @@ __device__ __forceinline__ unsigned lean_class_run(const RunEnv& E, const int cl
       if (ld(&E.sh.abort)) break;
     }
   }
-  if ((mxl | mxu | myl | myu | mzl | mzu) != 0ull) {
+  if constexpr (LANE_BITS) {
+    nar_all = nar_bits;
+    run_writes += lane_writes;
+  } else if ((mxl | mxu | myl | myu | mzl | mzu) != 0ull) {
     const unsigned long long me = 1ull << lane;
     nar_all = ((mxl & me) ? 1 : 0) | ((mxu & me) ? 2 : 0) | ((myl & me) ? 4 : 0) | ((myu & me) ? 8 : 0) | ((mzl & me) ? 16 : 0) | ((mzu & me) ? 32 : 0);
   }
@@ -1202,7 +1219,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               un_i = act & !ent;
             });
           } else if (info.y & 0x200) {
-            wave_iters = lean_class_run<C>(E, __builtin_ctz(key & CLASS_SET_MASK), (int)(key >> 10), pr, act, store, P.n_int, wave_writes, nar_all);
+            wave_iters = lean_class_run<C>(E, __builtin_ctz(key & CLASS_SET_MASK), (int)(key >> 10), pr, act, store, P.n_int, run_writes, wave_writes, nar_all);
           } else {
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               apply<true, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, 0, &nar);
