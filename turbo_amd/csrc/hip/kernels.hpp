@@ -992,17 +992,18 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             unsigned* const wz = words + ((unsigned)sc.x >> 16);
             const int ys = (sc.w >> 19) & 30, zs = (sc.w >> 23) & 30;
             const unsigned am = act ? ~0u : 0u;  // idle lanes of a padded slice see nothing to do
-            unsigned long long ny_acc = 0ull, nz_acc = 0ull;  // lanes that narrowed their y / their z during the run
+            unsigned acc = 0u;  // what this lane narrowed during the run: bit 1 its y (upper bound lowered), bit 0 its z (lower bound raised)
             TB_PROF_MARK(0);
             unsigned iters = 0;
+            unsigned run_writes_lean = 0;  // per lane
             for (;;) {
               // predicates as integers on the raw bit pairs (bit 0 of yb / zb: lb raised, bit 1: ub lowered), one vote each
               const unsigned yb = __hip_atomic_load(wy, TB_RLX, TB_WG) >> ys, zb = __hip_atomic_load(wz, TB_RLX, TB_WG) >> zs;
               const unsigned ny = zb & ~yb & 2u & am, nz = yb & ~zb & 1u & am;             // y.ub := 0 / z.lb := 1
               const unsigned bad = ((yb & (yb >> 1)) | (zb & (zb >> 1)) | (yb & (zb >> 1))) & 1u & am;  // an empty domain, or y true and z false
               ++iters;
-              const unsigned long long m_ny = mask_nz(ny), m_nz = mask_nz(nz), m_bad = mask_nz(bad);
-              if ((m_ny | m_nz | m_bad) == 0ull) {
+              const unsigned long long m_bad = mask_nz(bad);
+              if (mask_nz(ny | nz | bad) == 0ull) {
                 // quiet pass: the local fixpoint is reached; the slice's "not entailed" bit only ever goes 1 -> 0 below a node
                 if (mask_nz(~(yb >> 1) & ~zb & 1u & am) == 0ull && lane == 0)
                   (void)__hip_atomic_fetch_and(&ubits[s >> 5], ~(1u << (s & 31)), TB_RLX, TB_WG);
@@ -1011,12 +1012,13 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               if (m_bad != 0ull) { if (lane == 0) st(&sh.bot, 1); break; }  // the node fails: what this pass would still write is moot
               if (ny) (void)__hip_atomic_fetch_or(wy, 2u << ys, TB_RLX, TB_WG);
               if (nz) (void)__hip_atomic_fetch_or(wz, 1u << zs, TB_RLX, TB_WG);
-              wave_writes += (unsigned)__builtin_popcountll(m_ny) + (unsigned)__builtin_popcountll(m_nz);
-              ny_acc |= m_ny; nz_acc |= m_nz;
+              run_writes_lean += (ny >> 1) + nz;
+              acc |= ny | nz;
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
               if (ld(&sh.bot)) break;
             }
             if (rep == reps_of(P, 3)) wave_iters_total += (pk(P) & 0x400000) ? 1u : iters;
+            tc.writes += run_writes_lean;
 #ifdef TB_TUNING
             if (prof && wave == 0) {
               const long long t_ = clock64();
@@ -1030,9 +1032,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               asm volatile("" :: "s"(again));
             }
             for (int mrep = (pk(P) & 0x1) ? 2 : 1; mrep > 0; --mrep)
-            if ((ny_acc | nz_acc) != 0ull) {
+            if (mask_nz(acc) != 0ull) {
               // successors: the slots hold the readers interested in exactly these events (y.ub lowered / z.lb raised), pre-filtered
-              const bool my_ny = ((ny_acc >> lane) & 1ull) != 0ull, my_nz = ((nz_acc >> lane) & 1ull) != 0ull;
+              const bool my_ny = (acc & 2u) != 0u, my_nz = (acc & 1u) != 0u;
               const unsigned ty = my_ny ? (unsigned)sc.y : 0xffffffffu, tz = my_nz ? (unsigned)sc.z : 0xffffffffu;
               bool did = false;
               if ((ty & 0xffffu) != 0xffffu) { mark_slice(nxt, (int)(ty & 0xffffu)); did = true; }
