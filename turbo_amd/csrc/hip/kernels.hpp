@@ -700,8 +700,10 @@ __device__ __forceinline__ Itv lean_load(int2* store, int ni, const LeanOperand<
   if (C && kind != 1) return load_dom<C>(store, ni, o.v);
   return load_int<C>(store, o.v);
 }
-template <int C>
-__device__ __forceinline__ unsigned lean_class_run(const RunEnv& E, const int cls, const int kinds, const int4 pr, const bool act, int2* store, const int ni, unsigned& run_writes, unsigned& wave_writes, int& nar_all) {
+// CLS >= 0: the class is a compile-time constant (the pass loop then holds one class body and no chain of scalar compares); -1: `cls_dyn`.
+template <int C, int CLS>
+__device__ __forceinline__ unsigned lean_class_run_t(const RunEnv& E, const int cls_dyn, const int kinds, const int4 pr, const bool act, int2* store, const int ni, unsigned& run_writes, unsigned& wave_writes, int& nar_all) {
+  const int cls = CLS >= 0 ? CLS : cls_dyn;
   const int lane = threadIdx.x & 63, s = E.s;
   const int kx = kinds & 3, ky = (kinds >> 2) & 3, kz = (kinds >> 4) & 3;  // wave-uniform
   const LeanOperand<C> ox = lean_operand<C>(store, ni, pr.y, act, kx), oy = lean_operand<C>(store, ni, pr.z, act, ky), oz = lean_operand<C>(store, ni, pr.w, act, kz);
@@ -816,6 +818,26 @@ __device__ __forceinline__ unsigned lean_class_run(const RunEnv& E, const int cl
     nar_all = ((mxl & me) ? 1 : 0) | ((mxu & me) ? 2 : 0) | ((myl & me) ? 4 : 0) | ((myu & me) ? 8 : 0) | ((mzl & me) ? 16 : 0) | ((mzu & me) ? 32 : 0);
   }
   return iters;
+}
+// The class of a slice is wave-uniform and fixed for the run: outside the COMPACT kernels (where this function is a side path and its size is paid in
+// registers by everything around it) the pass loop is instantiated per class -- a slice of `max` or of reified `<=` no longer walks a chain of
+// seven scalar compares and branches in every pass (the scalar unit is the busiest resource of a network like accap_a3).
+template <int C>
+__device__ __forceinline__ unsigned lean_class_run(const RunEnv& E, const int cls, const int kinds, const int4 pr, const bool act, int2* store, const int ni, unsigned& run_writes, unsigned& wave_writes, int& nar_all) {
+  if constexpr (C == 1) return lean_class_run_t<C, -1>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
+  else {
+    // (specialising the operand kinds of the commonest signatures as well -- sums of three variables, `c = y + z`, min / max over Booleans -- was
+    //  measured: accap_a3 +0.6 %, trains15 -1 %; not kept)
+    switch (cls) {
+      case K_ADD: return lean_class_run_t<C, K_ADD>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
+      case K_MIN: return lean_class_run_t<C, K_MIN>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
+      case K_MAX: return lean_class_run_t<C, K_MAX>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
+      case K_LEQ_R: return lean_class_run_t<C, K_LEQ_R>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
+      case K_EQ_R: return lean_class_run_t<C, K_EQ_R>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
+      case K_LEQ_T: return lean_class_run_t<C, K_LEQ_T>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
+      default: return lean_class_run_t<C, -1>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);  // K_LEQ_F, K_EQ_T, K_EQ_F: rare
+    }
+  }
 }
 
 // Slice signatures with a dedicated run (word0 >> 16 of the slice's records: class set | operand kinds << 10; see pack_props).
