@@ -35,7 +35,9 @@ enum tb_op { TB_ADD = 0, TB_MUL = 1, TB_TDIV = 2, TB_TMOD = 3, TB_MIN = 4, TB_MA
 enum tb_var_order { TB_INPUT_ORDER = 0, TB_FIRST_FAIL = 1, TB_ANTI_FIRST_FAIL = 2, TB_SMALLEST = 3, TB_LARGEST = 4 };
 enum tb_val_order { TB_VAL_MIN = 0, TB_VAL_MAX = 1, TB_VAL_SPLIT = 2, TB_VAL_REVERSE_SPLIT = 3 };
 
-/* memory_gpu.hpp:18-22 */
+/* memory_gpu.hpp:18-22.  Where a workgroup's working store (and the propagator records) live: GLOBAL = a slab in HBM per workgroup; STORE_SHARED =
+ * the store in LDS, records streamed from L2; TCN_SHARED = store and records in LDS (planned for the plain sweeps on small networks only: the
+ * event-driven fixpoint and the compact layouts keep their records in L2, measured faster -- more workgroups per CU). */
 enum tb_mem_kind { TB_MEM_GLOBAL = 0, TB_MEM_STORE_SHARED = 1, TB_MEM_TCN_SHARED = 2 };
 
 enum tb_error {
