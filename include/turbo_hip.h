@@ -124,6 +124,8 @@ typedef struct {
   uint64_t eps_stolen_subproblems;  /* subproblems this GPU took over from other GPUs' queues (xGMI work stealing) */
   int64_t wait_time_ns;             /* summed over workgroups: time without a subproblem (looking / waiting for work on other GPUs) */
   int64_t min_block_ns, max_block_ns; /* first and last workgroup to leave the kernel (the reference's first_block_idle_time is the min) */
+  uint64_t active_lane_evaluations; /* num_deductions counts wave iterations x wave width, as the reference does (barebones:958-960); this is the
+                                       same count without the idle lanes of partly filled slices (class padding, the network's last slice) */
 } tb_stats;
 
 enum tb_timer { /* enum class Timer, statistics.hpp:13-29 (same order, 11 timers) */
@@ -226,12 +228,36 @@ typedef struct { unsigned char bytes[64]; } tb_peer_handle;
 int tb_session_export_peer(tb_session* s, tb_peer_handle* handle_out);
 int tb_session_import_peer(tb_session* s, int32_t peer_rank, const tb_peer_handle* handle);
 int tb_session_link_peer(tb_session* s, tb_session* peer);
+/* Drop every cell linked / imported so far (a group that could not be linked completely falls back to the host relay as a whole). */
+int tb_session_unlink_peers(tb_session* s);
 int tb_session_arm(tb_session* s);
 /* Remaining work of this GPU as of the kernel's last poll: subproblems not yet handed to a workgroup (its own share and
  * what it took from others), and how many it has taken from / lost to other GPUs so far. */
 int tb_session_progress(tb_session* s, uint64_t* remaining_out, uint64_t* stolen_in_out, uint64_t* stolen_out_out);
 /* Test aid (tb_config.reserved[0] & 0x800000): the store workgroup `workgroup` was working on when it left the kernel. */
 int tb_session_debug_last_store(tb_session* s, int32_t workgroup, tb_itv* store_out);
+/* Test aid (same knob): where workgroup `workgroup` stood when it left the kernel -- its subproblem, how much of the dive was left, the decisions on
+ * its stack (variable in the caller's numbering, both children, the child taken, the objective's upper bound in force when the decision was taken) and
+ * the bound in force at its last node.  With it a checker can replay the path from the root: root -> dive along the bits of `subproblem` -> the
+ * decisions, and must arrive at the store of tb_session_debug_last_store (barebones_dive_and_solve.hpp:675-714,752-864 is what is being replayed).
+ * At most `capacity` decisions are written (and only those of the first decision-stack segment). */
+typedef struct {
+  uint64_t subproblem;
+  int32_t dive_levels_left;   /* > 0: the workgroup stopped while diving; the decisions below are then stale */
+  int32_t depth;              /* decisions on the stack */
+  int32_t decisions;          /* entries written to decisions_out */
+  int32_t last_objective_ub;  /* INT32_MAX: no bound imposed yet in this subproblem */
+  int32_t last_node_failed;
+  int32_t had_work;           /* 0: it left because no subproblem was left */
+  int32_t nodes;
+  int32_t reserved;
+} tb_debug_path;
+typedef struct {
+  int32_t var, child;         /* child: 0 / 1, the one being explored */
+  tb_itv children[2];
+  int32_t objective_ub;       /* INT32_MAX: none */
+} tb_debug_decision;
+int tb_session_debug_path(tb_session* s, int32_t workgroup, tb_debug_path* path_out, int32_t capacity, tb_debug_decision* decisions_out);
 int tb_session_poll(tb_session* s, int32_t* local_best_out, int32_t* done_out);
 int tb_session_push_bound(tb_session* s, int32_t bound);
 int tb_session_stop(tb_session* s);

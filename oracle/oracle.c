@@ -35,6 +35,10 @@ static int64_t g_trace_cap = 0;
 static orc_itv* g_last_store = NULL;
 void orc_set_node_trace(unsigned char* failed_flags, int64_t capacity) { g_trace = failed_flags; g_trace_cap = capacity; }
 void orc_set_last_store_sink(orc_itv* buf) { g_last_store = buf; }
+static orc_path_header* g_path_hdr = NULL;
+static orc_path_decision* g_path_dec = NULL;
+static int32_t g_path_cap = 0;
+void orc_set_path_sink(orc_path_header* hdr, orc_path_decision* decisions, int32_t capacity) { g_path_hdr = hdr; g_path_dec = decisions; g_path_cap = capacity; }
 
 #define NINF ORC_NINF
 #define PINF ORC_PINF
@@ -276,6 +280,7 @@ typedef struct { /* lala LightBranch, barebones:135,355-393 */
   int32_t var, cur;
   orc_itv child[2];
   int32_t rope[2];
+  int32_t obj_ub; /* test aid (orc_set_path_sink): the objective's upper bound in force when the decision was taken */
 } decision_t;
 
 typedef struct {
@@ -293,6 +298,7 @@ typedef struct {
   orc_stats st;
   struct timespec t0;
   uint64_t cur_subproblem;
+  int32_t last_obj_ub, dive_left; /* test aid (orc_set_path_sink) */
 } engine_t;
 
 static void eng_embed(engine_t* e, int32_t v, int32_t l, int32_t u) {
@@ -413,6 +419,67 @@ static int propagate(engine_t* e, int is_dive) {
   return leaf;
 }
 
+/* Test aid: replay the path a workgroup of the HIP engine reports when it leaves its kernel (include/turbo_hip.h: tb_session_debug_path) and
+ * return the store under its last node.  The replay is the reference's own walk restricted to ONE root-to-node path: root, then the dive along
+ * the bits of `subproblem` (barebones:675-714: propagate, split, take child `bit`), then the recorded decisions of the solve loop
+ * (barebones:752-864: tell the objective bound that was in force, propagate, split -- which must choose the recorded variable and children --,
+ * take the recorded child), then the last node under the last bound.  A node's fixpoint does not depend on the order in which decisions and
+ * bounds were added, nor on the snapshot it was restored from, so the result must equal the engine's store bit for bit.
+ * (The variable-selection cursors cur_strategy / next_unassigned are carried along the path from the subproblem's root, as after a backtrack,
+ * barebones:859-860; they only skip variables that are assigned or unsplittable.)
+ * *mismatch_out: -1 the path replays; i >= 0: decision i differs (or node i was a leaf); -2 - l: level l of the dive was a leaf. */
+int orc_replay_path(const orc_config* cfg, int32_t n_vars, const orc_itv* root_store, int32_t n_props, const orc_prop* props,
+                    int32_t n_strats, const int32_t* strat_var_order, const int32_t* strat_val_order, const int32_t* strat_off, const int32_t* strat_vars,
+                    int32_t obj_var, uint64_t subproblem, int32_t dive_levels_left, int32_t n_decisions, const orc_path_decision* decisions,
+                    int32_t last_objective_ub, orc_itv* store_out, int32_t* failed_out, int32_t* mismatch_out) {
+  engine_t E;
+  memset(&E, 0, sizeof(E));
+  engine_t* e = &E;
+  e->cfg = cfg; e->n_vars = n_vars; e->n_props = n_props; e->n_strats = n_strats; e->obj_var = obj_var;
+  e->props = props; e->svar_order = strat_var_order; e->sval_order = strat_val_order; e->soff = strat_off; e->svars = strat_vars;
+  size_t sb = sizeof(orc_itv) * (size_t)(n_vars > 0 ? n_vars : 1);
+  e->store = (orc_itv*)malloc(sb);
+  e->dec_cap = 1024; e->dec = (decision_t*)malloc(sizeof(decision_t) * (size_t)e->dec_cap);
+  memcpy(e->store, root_store, sizeof(orc_itv) * (size_t)n_vars);
+  for (int32_t v = 0; v < n_vars; ++v) if (e->store[v].lb > e->store[v].ub) e->store_bot = 1;
+  int mismatch = -1, failed = 0, done = 0;
+  uint64_t it = 0, de = 0;
+  int remaining = cfg->subproblems_power;
+  /* the dive */
+  while (remaining > dive_levels_left && !done) {
+    failed = fixpoint(n_props, props, e->store, e->store_bot, &it, &de);
+    int ent = !failed;
+    for (int32_t i = 0; i < n_props && ent; ++i) ent = orc_ask(&props[i], e->store);
+    if (failed || ent || !split(e)) { mismatch = -2 - (cfg->subproblems_power - remaining); done = 1; break; }
+    --remaining; --e->depth;
+    const int bit = (int)((subproblem >> remaining) & 1u);
+    eng_embed(e, e->dec[0].var, e->dec[0].child[bit].lb, e->dec[0].child[bit].ub);
+  }
+  if (!done && dive_levels_left == 0) {
+    if (cfg->has_eps_strategy) { if (e->cur_strategy < 1) e->cur_strategy = 1; e->next_unassigned = 0; }
+    for (int32_t i = 0; i < n_decisions && !done; ++i) {
+      if (obj_var >= 0 && decisions[i].objective_ub != PINF) eng_embed(e, obj_var, NINF, decisions[i].objective_ub);
+      failed = fixpoint(n_props, props, e->store, e->store_bot, &it, &de);
+      int ent = !failed;
+      for (int32_t q = 0; q < n_props && ent; ++q) ent = orc_ask(&props[q], e->store);
+      if (failed || ent || !split(e)) { mismatch = i; done = 1; break; }
+      decision_t* dd = &e->dec[e->depth - 1];
+      const orc_path_decision* r = &decisions[i];
+      if (dd->var != r->var || dd->child[0].lb != r->children[0].lb || dd->child[0].ub != r->children[0].ub ||
+          dd->child[1].lb != r->children[1].lb || dd->child[1].ub != r->children[1].ub || (r->child != 0 && r->child != 1)) { mismatch = i; done = 1; break; }
+      dd->cur = r->child;
+      eng_embed(e, dd->var, dd->child[dd->cur].lb, dd->child[dd->cur].ub);
+    }
+    if (!done && obj_var >= 0 && last_objective_ub != PINF) eng_embed(e, obj_var, NINF, last_objective_ub);
+  }
+  if (!done) failed = fixpoint(n_props, props, e->store, e->store_bot, &it, &de);
+  if (store_out) memcpy(store_out, e->store, sizeof(orc_itv) * (size_t)n_vars);
+  if (failed_out) *failed_out = failed;
+  if (mismatch_out) *mismatch_out = mismatch;
+  free(e->store); free(e->dec);
+  return 0;
+}
+
 int orc_solve(const orc_config* cfg, int32_t n_vars, const orc_itv* root_store,
               int32_t n_props, const orc_prop* props,
               int32_t n_strats, const int32_t* strat_var_order, const int32_t* strat_val_order,
@@ -443,12 +510,13 @@ int orc_solve(const orc_config* cfg, int32_t n_vars, const orc_itv* root_store,
     for (int32_t v = 0; v < n_vars; ++v) if (e->store[v].lb > e->store[v].ub) e->store_bot = 1;
     /* D. dive (barebones:675-714): no objective bound is applied while diving (gpu_dive_and_solve.hpp:370-372) */
     int remaining = d, leaf = 0;
+    e->last_obj_ub = PINF; e->dive_left = d;
     while (remaining > 0 && !leaf && !e->stop) {
       leaf = propagate(e, 1);
-      if (!leaf) {
+      if (!leaf && !e->stop) { /* (a search stopped by its node budget leaves the store under its last node untouched) */
         if (!split(e)) { leaf = 1; e->st.exhaustive = 0; }
         else {
-          --remaining; --e->depth;
+          --remaining; --e->depth; e->dive_left = remaining;
           int bit = (int)((idx >> remaining) & 1u);
           eng_embed(e, e->dec[0].var, e->dec[0].child[bit].lb, e->dec[0].child[bit].ub);
         }
@@ -464,9 +532,10 @@ int orc_solve(const orc_config* cfg, int32_t n_vars, const orc_itv* root_store,
       if (cfg->has_eps_strategy) { if (e->cur_strategy < 1) e->cur_strategy = 1; e->next_unassigned = 0; }
       while (!e->stop) {
         if (obj_var >= 0) {
-          if (cfg->use_fixed_bound) eng_embed(e, obj_var, NINF, cfg->fixed_bound);
+          if (cfg->use_fixed_bound) { e->last_obj_ub = cfg->fixed_bound; eng_embed(e, obj_var, NINF, cfg->fixed_bound); }
           else if (e->best_bound != PINF) {
             if (e->best_bound == NINF) { e->stop = 1; break; } /* unbounded objective, barebones:767-770 */
+            e->last_obj_ub = e->best_bound - 1;
             eng_embed(e, obj_var, NINF, e->best_bound - 1);
           }
         }
@@ -481,6 +550,7 @@ int orc_solve(const orc_config* cfg, int32_t n_vars, const orc_itv* root_store,
           else {
             decision_t* dd = &e->dec[e->depth - 1];
             ++dd->cur;
+            dd->obj_ub = e->last_obj_ub;
             eng_embed(e, dd->var, dd->child[dd->cur].lb, dd->child[dd->cur].ub);
           }
         }
@@ -504,6 +574,15 @@ int orc_solve(const orc_config* cfg, int32_t n_vars, const orc_itv* root_store,
   e->st.best_bound = e->best_bound;
   e->st.solve_seconds = elapsed_s(e);
   if (g_last_store) memcpy(g_last_store, e->store, sizeof(orc_itv) * (size_t)n_vars);
+  if (g_path_hdr) { /* the path the search stood on when it returned, in the format of orc_replay_path */
+    g_path_hdr->subproblem = e->cur_subproblem; g_path_hdr->dive_levels_left = e->dive_left; g_path_hdr->depth = e->depth;
+    g_path_hdr->last_objective_ub = e->last_obj_ub; g_path_hdr->decisions = 0;
+    for (int32_t i = 0; i < e->depth && i < g_path_cap; ++i) {
+      orc_path_decision* r = &g_path_dec[i];
+      r->var = e->dec[i].var; r->child = e->dec[i].cur; r->children[0] = e->dec[i].child[0]; r->children[1] = e->dec[i].child[1]; r->objective_ub = e->dec[i].obj_ub;
+      g_path_hdr->decisions = i + 1;
+    }
+  }
   if (has_solution_out) *has_solution_out = e->st.solutions > 0 ? 1 : 0;
   if (best_store_out && e->st.solutions > 0) memcpy(best_store_out, e->best_store, sizeof(orc_itv) * (size_t)n_vars);
   if (stats_out) *stats_out = e->st;

@@ -104,6 +104,18 @@ int64_t orc_solution_sink_count(void);
 void orc_set_node_trace(unsigned char* failed_flags, int64_t capacity);
 void orc_set_last_store_sink(orc_itv* buf);
 
+/* Test aid: replay one root-to-node path reported by the HIP engine (tb_session_debug_path) and return the store under its last node
+ * (see oracle.c).  *mismatch_out = -1 when every recorded decision is the one this oracle takes on the replayed store. */
+typedef struct { int32_t var, child; orc_itv children[2]; int32_t objective_ub; } orc_path_decision;
+typedef struct { uint64_t subproblem; int32_t dive_levels_left, depth, decisions, last_objective_ub; } orc_path_header;
+/* Test aid: the path the next orc_solve calls stand on when they return (NULL switches it off); feeding it to orc_replay_path
+ * must give back the store of orc_set_last_store_sink -- the CPU-side check of the replay itself. */
+void orc_set_path_sink(orc_path_header* hdr, orc_path_decision* decisions, int32_t capacity);
+int orc_replay_path(const orc_config* cfg, int32_t n_vars, const orc_itv* root_store, int32_t n_props, const orc_prop* props,
+                    int32_t n_strats, const int32_t* strat_var_order, const int32_t* strat_val_order, const int32_t* strat_off, const int32_t* strat_vars,
+                    int32_t obj_var, uint64_t subproblem, int32_t dive_levels_left, int32_t n_decisions, const orc_path_decision* decisions,
+                    int32_t last_objective_ub, orc_itv* store_out, int32_t* failed_out, int32_t* mismatch_out);
+
 #ifdef __cplusplus
 }
 #endif

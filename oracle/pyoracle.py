@@ -138,6 +138,66 @@ def enumerate_solutions(tcn, capacity: int = 100000):
     return buf[:k, :n], st
 
 
+def replay_path(tcn, subproblems_power: int, header: dict, decisions: np.ndarray):
+    """Replay a path reported by the HIP engine (capi.Session.debug_path): returns (store under the last node, failed, mismatch) with
+    mismatch == -1 when every recorded decision is the one this oracle takes."""
+    cfg = OrcConfig(subproblems_power=subproblems_power, has_eps_strategy=int(bool(getattr(tcn, "has_eps_strategy", False))))
+    store = np.ascontiguousarray(tcn.store, dtype=ITV)
+    props = np.ascontiguousarray(tcn.props, dtype=PROP)
+    vo = np.ascontiguousarray(tcn.strat_var_order, dtype=np.int32)
+    vl = np.ascontiguousarray(tcn.strat_val_order, dtype=np.int32)
+    off = np.ascontiguousarray(tcn.strat_off, dtype=np.int32)
+    sv = np.ascontiguousarray(tcn.strat_vars, dtype=np.int32)
+    dec = np.ascontiguousarray(decisions)
+    assert dec.dtype.itemsize == 28, "orc_path_decision is seven 32-bit words"
+    out = np.zeros(store.shape[0], dtype=ITV)
+    failed, mismatch = C.c_int32(0), C.c_int32(0)
+    L = lib()
+    L.orc_replay_path.restype = C.c_int
+    L.orc_replay_path.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.orc_replay_path(C.byref(cfg), store.shape[0], store.ctypes.data, props.shape[0], props.ctypes.data,
+                           vo.shape[0], vo.ctypes.data, vl.ctypes.data, off.ctypes.data, sv.ctypes.data, int(tcn.obj_var),
+                           int(header["subproblem"]), int(header["dive_levels_left"]), int(dec.shape[0]), dec.ctypes.data,
+                           int(header["last_objective_ub"]), out.ctypes.data, C.byref(failed), C.byref(mismatch))
+    if rc != 0:
+        raise RuntimeError(f"orc_replay_path failed with {rc}")
+    return out, bool(failed.value), int(mismatch.value)
+
+
+PATH_DECISION = np.dtype([("var", np.int32), ("child", np.int32), ("lb0", np.int32), ("ub0", np.int32), ("lb1", np.int32), ("ub1", np.int32),
+                          ("objective_ub", np.int32)])
+
+
+class OrcPathHeader(C.Structure):
+    _fields_ = [("subproblem", C.c_uint64), ("dive_levels_left", C.c_int32), ("depth", C.c_int32), ("decisions", C.c_int32), ("last_objective_ub", C.c_int32)]
+
+
+def solve_with_path(tcn, cutnodes: int, subproblems_power: int = 0, capacity: int = 4096):
+    """solve() with a node budget, plus the path the search stood on when it returned (header dict, decisions) and the store under it:
+    (has, best, stats, header, decisions, last_store, last_failed)."""
+    L = lib()
+    L.orc_set_path_sink.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.orc_set_node_trace.argtypes = [C.c_void_p, C.c_int64]
+    L.orc_set_last_store_sink.argtypes = [C.c_void_p]
+    hdr = OrcPathHeader()
+    dec = np.zeros(capacity, dtype=PATH_DECISION)
+    n = int(np.asarray(tcn.store).shape[0])
+    last = np.zeros(max(n, 1), dtype=ITV)
+    trace = np.zeros(cutnodes + 1, dtype=np.uint8)
+    L.orc_set_path_sink(C.addressof(hdr), dec.ctypes.data, capacity)
+    L.orc_set_last_store_sink(last.ctypes.data)
+    L.orc_set_node_trace(trace.ctypes.data, trace.shape[0])
+    try:
+        has, best, st = solve(tcn, subproblems_power=subproblems_power, cutnodes=cutnodes)
+    finally:
+        L.orc_set_path_sink(None, None, 0)
+        L.orc_set_last_store_sink(None)
+        L.orc_set_node_trace(None, 0)
+    header = {k: getattr(hdr, k) for k, _ in hdr._fields_}
+    return has, best, st, header, dec[:hdr.decisions].copy(), last[:n], bool(trace[st["nodes"] - 1]) if st["nodes"] else False
+
+
 def solve_traced(tcn, cutnodes: int, subproblems_power: int = 0):
     """solve() with a node budget, plus the failed flag of every node and the store the search stopped on."""
     L = lib()

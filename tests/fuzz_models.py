@@ -227,3 +227,51 @@ def finite_class_network(rng):
     st = np.array(store, dtype=ITV_DTYPE)
     pr = np.array([props[i] for i in order], dtype=PROP_DTYPE)
     return st, pr
+
+
+def element_model(seed: int) -> str:
+    """FlatZinc model shaped like the headline instance (wordpress7_500): a few index variables over 70-260 positions, each read by two
+    to four `array_int_element` constraints with tables over few distinct values, linear constraints over the looked-up values and an
+    objective.  Lowered, an index becomes a CHAIN of channelling propagators `b_i = (idx = i)` over several 64-record slices, a value one
+    over its table's values, linked by implications `b_i <= c_table[i]` -- what the r04 wake-up filters work on (chain slices woken by
+    value range; a chain woken by "b_i became false" only when i sits on a bound of idx)."""
+    rng = random.Random(seed)
+    n_idx = rng.randint(2, 3)
+    lines, idxs, vals = [], [], []
+    tables = 0
+    for a in range(n_idx):
+        n = rng.randint(70, 260)
+        lo = rng.choice([1, 1, 1, 0, 3])  # (an index domain that starts elsewhere than the table: the front-end clips it)
+        lines.append(f"var {lo}..{n + rng.choice([0, 0, 2])}: i{a} :: output_var;")
+        idxs.append(f"i{a}")
+        for _ in range(rng.randint(2, 4)):
+            distinct = rng.randint(3, 40)
+            base = rng.randint(-5, 20)
+            style = rng.random()
+            if style < 0.4:      # sorted table (offers by size): a value bound cuts a contiguous range of positions
+                tab = sorted(base + rng.randint(0, distinct) * rng.choice([1, 1, 2]) for _ in range(n))
+            elif style < 0.6:
+                tab = sorted((base + rng.randint(0, distinct) for _ in range(n)), reverse=True)
+            else:
+                tab = [base + rng.randint(0, distinct) for _ in range(n)]
+            lines.insert(0, f"array [1..{n}] of int: t{tables} = [{','.join(map(str, tab))}];")
+            lines.append(f"var {min(tab) - rng.choice([0, 0, 2])}..{max(tab) + rng.choice([0, 0, 3])}: v{tables} :: output_var;")
+            lines.append(f"constraint array_int_element(i{a},t{tables},v{tables});")
+            vals.append((f"v{tables}", min(tab), max(tab)))
+            tables += 1
+    for _ in range(rng.randint(2, 6)):
+        m = rng.randint(2, min(4, len(vals)))
+        pick = rng.sample(vals, m)
+        cs = [rng.choice([-2, -1, 1, 1, 2]) for _ in range(m)]
+        mid = sum(c * (lo + hi) // 2 for c, (_, lo, hi) in zip(cs, pick))
+        lines.append(f"constraint int_lin_le([{','.join(map(str, cs))}],[{','.join(v for v, _, _ in pick)}],{mid + rng.randint(-6, 10)});")
+    if rng.random() < 0.5 and len(idxs) > 1:
+        lines.append(f"constraint int_lin_le([1,-1],[{idxs[0]},{idxs[1]}],{rng.randint(-20, 40)});")
+    obj = rng.sample(vals, min(len(vals), rng.randint(2, 4)))
+    lo, hi = sum(l for _, l, _ in obj), sum(h for _, _, h in obj)
+    lines.append(f"var {lo}..{hi}: obj :: output_var;")
+    lines.append(f"constraint int_lin_eq([{','.join(['1'] * len(obj))},-1],[{','.join(v for v, _, _ in obj)},obj],0);")
+    order = rng.choice(["first_fail", "input_order", "smallest"])
+    val = rng.choice(["indomain_min", "indomain_split", "indomain_max"])
+    lines.append(f"solve :: int_search([{','.join(idxs)}],{order},{val},complete) {rng.choice(['minimize', 'minimize', 'maximize'])} obj;")
+    return "\n".join(lines) + "\n"

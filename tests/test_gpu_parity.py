@@ -259,6 +259,67 @@ def test_channelling_networks_bit_exact(mode):
                 np.testing.assert_array_equal(got[i], exp, err_msg=f"seed {seed} store {i}")
 
 
+@pytest.mark.parametrize("chunk", range(3))
+@pytest.mark.parametrize("mode", ["event_compact", "event_compact16", "event_compact_globalmem", "event_compact_4waves", "event"])
+def test_element_models_tree_identical(chunk, mode):
+    """Fuzz of the r04 wake-up filters (engine.hip: Chains, conditional wake-up in pack_succ): models shaped like wordpress7_500 -- index
+    variables over 70-260 positions read by several element constraints -- whose index chains span several slices.  One workgroup must
+    walk the oracle's tree, node for node, up to a node budget, and stop on the same store, with one subproblem and with 2^4; the
+    root and random nodes must reach the oracle's fixpoint."""
+    from fuzz_models import element_model
+    cfg = {"event_compact": dict(debug=COMPACT), "event_compact16": dict(debug=COMPACT16), "event_compact_globalmem": dict(debug=COMPACT, only_global_memory=1),
+           "event_compact_4waves": dict(debug=COMPACT, threads_per_block=256), "event": dict()}[mode]
+    dbg = cfg.pop("debug", 0)
+    for seed in range(3000 + chunk * 8, 3000 + chunk * 8 + 8):
+        tcn = frontend.Model.from_string(element_model(seed)).tcn()
+        stores = random_nodes(tcn, 6, seed=seed, max_decisions=5)
+        check_batch(tcn, stores, fixpoint=2, debug=dbg, **cfg)
+        for power in (0, 4):
+            has_o, best_o, st_o, trace, last_o = pyoracle.solve_traced(tcn, 1500, power)
+            s = capi.Session(tcn, capi.make_config(or_nodes=1, subproblems_power=power, stop_after_n_nodes=1500, timeout_ms=120000, fixpoint=2, debug=dbg | 0x800000, **cfg))
+            s.start()
+            while not s.poll()[1]:
+                pass
+            has_g, best_g, st_g = s.finish()
+            last_g = s.debug_last_store(0)
+            s.close()
+            assert has_g == has_o, (seed, power)
+            for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
+                assert st_g[k] == st_o[k], (seed, power, k)
+            if has_o:
+                np.testing.assert_array_equal(best_g, best_o, err_msg=str((seed, power)))
+            if st_o["nodes"] and not trace[-1]:
+                np.testing.assert_array_equal(last_g, last_o, err_msg=str((seed, power)))
+
+
+def test_compact_slab_in_global_memory_with_a_ragged_implication_slice():
+    """the idle lanes of a partly filled lean implication slice formed word addresses 0xffff words past the slab -- beyond g_store
+    for the last workgroups of a compact slab in global memory.  A network that ENDS in implications with n_props % 64 != 0, COMPACT forced,
+    store in global memory, every workgroup busy: results must be the oracle's (and the GPU must not fault)."""
+    from turbo_amd.frontend import ITV_DTYPE, PROP_DTYPE
+    rng = np.random.default_rng(11)
+    nb = 200
+    store = np.array([(0, 0), (1, 1), (2, 2)] + [(0, 1)] * nb + [(0, 2)] * 40, dtype=ITV_DTYPE)
+    props = [(0, 3 + nb + i, 3 + int(rng.integers(0, nb)), 3 + int(rng.integers(0, nb))) for i in range(40)]       # t = a + c
+    props += [(7, 1, 3 + int(rng.integers(0, nb)), 3 + int(rng.integers(0, nb))) for _ in range(64 * 3 + 27)]     # implications: the last class, ragged
+    props = np.array(props, dtype=PROP_DTYPE)
+    stores = []
+    for _ in range(96):
+        s = store.copy()
+        for v in rng.choice(np.arange(3, 3 + nb), size=6, replace=False):
+            s["lb"][v] = s["ub"][v] = int(rng.integers(0, 2))
+        stores.append(s)
+    stores = np.stack(stores)
+    for dbg in (COMPACT, COMPACT16):
+        got, failed, ent, _, _, _ = capi.propagate(props, stores, capi.make_config(fixpoint=2, only_global_memory=1, debug=dbg, timeout_ms=20000))
+        for i in range(stores.shape[0]):
+            exp, efailed, eent, _, _ = pyoracle.propagate(stores[i], props)
+            assert bool(failed[i]) == efailed, i
+            if not efailed:
+                assert bool(ent[i]) == eent, i
+                np.testing.assert_array_equal(got[i], exp, err_msg=str(i))
+
+
 @pytest.mark.parametrize("mode", ["wac1", "event", "event_compact", "event_globalmem", "event_compact_globalmem", "event_compact16", "event_compact16_globalmem", "wac1_compact", "wac1_compact16"])
 def test_class_pure_finite_networks_bit_exact(mode):
     """Fuzz of the lean runs of the event kernels: class-pure slices over finite domains in the plain and in the compact layout

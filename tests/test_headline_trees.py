@@ -20,6 +20,9 @@ from turbo_amd import capi, frontend, preprocess
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "headline_trees.json")))
 COUNTERS = ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems")
 KEEP_LAST = 0x800000  # tb_config.reserved[0]: keep the store every workgroup stopped on
+# (threads per workgroup, event kernel, store layout, memory kind) of bench.py's sessions on an MI355X -- the grid differs (one workgroup here), the
+# kernel instantiation must not (tests/test_gpu_fullgrid_paths.py runs the full grids)
+BENCH_PLANS = {"example_wordpress7_500.fzn/simplified": (128, 1, 1, 1), "accap_a3.fzn/simplified": (128, 1, 0, 1), "trains15.fzn/simplified": (256, 1, 2, 1)}
 
 
 def sha(a) -> str:
@@ -83,6 +86,11 @@ def test_engine_reproduces_the_headline_trees(key, mode):
     for case, rec in GOLDEN[key]["cases"].items():
         s = capi.Session(tcn, capi.make_config(or_nodes=1, subproblems_power=rec["subproblems_power"], stop_after_n_nodes=rec["cutnodes"],
                                                timeout_ms=120000, debug=KEEP_LAST | extra, **cfg))
+        if mode == "event" and key in BENCH_PLANS:  # the kernel instantiation and store placement are the ones the bench line reports
+            plan = s.plan()
+            info = capi.device_info(0)
+            if info["compute_units"] == 256 and info["lds_bytes_per_cu"] == 160 * 1024:
+                assert (plan["threads_per_block"], plan["kernel_event"], plan["kernel_opt"], plan["mem_kind"]) == BENCH_PLANS[key], (key, plan)
         s.start()
         while not s.poll()[1]:
             pass

@@ -47,3 +47,23 @@ def test_unsat_by_search():
     tcn = frontend.Model.from_string("var 1..3: x; var 1..3: y; constraint int_lt(x,y); constraint int_lt(y,x); solve satisfy;").tcn()
     has, _, st = pyoracle.solve(tcn)
     assert not has and st["exhaustive"] == 1
+
+
+@pytest.mark.parametrize("rel,power,cut", [("test_data/sudoku_opt4.fzn", 0, 30), ("test_data/sudoku_opt4.fzn", 4, 77), ("test_data/pat2.fzn", 4, 55),
+                                           ("accap_a3.fzn", 6, 400), ("accap_a3.fzn", 0, 37), ("test_data/pennies5.fzn", 4, 70), ("test_data/pennies5.fzn", 0, 41),
+                                           ("example_wordpress7_500.fzn", 6, 30), ("test_data/triangular9.fzn", 2, 1200), ("test_data/triangular9.fzn", 0, 333)]
+                         + [("test_data/triangular9.fzn", 3, c) for c in range(40, 60)] + [("accap_a3.fzn", 4, c) for c in range(100, 130)])
+def test_replay_of_the_oracles_own_path_gives_its_last_store(rel, power, cut):
+    """orc_replay_path (the checker of the full-grid GPU parity test) against orc_solve itself: stop the search after `cut` nodes, take the
+    path it stands on (subproblem, decisions with the objective bound in force at each), replay it from the root -- the store must be
+    the one the search stopped on, whatever snapshots and older bounds it had gone through."""
+    from conftest import BENCH
+    from turbo_amd import frontend
+    tcn = frontend.load_fzn(os.path.join(BENCH, rel))
+    has, best, st, hdr, dec, last, last_failed = pyoracle.solve_with_path(tcn, cut, power)
+    assert st["nodes"] == cut, "the budget must cut the search for the case to mean something"
+    store, failed, mismatch = pyoracle.replay_path(tcn, power, hdr, dec)
+    assert mismatch == -1, (hdr, mismatch)
+    assert failed == last_failed
+    if not failed:
+        np.testing.assert_array_equal(store, last)

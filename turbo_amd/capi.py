@@ -27,7 +27,7 @@ EXPORTS = ["tb_version", "tb_last_error", "tb_device_count", "tb_get_device_info
            "tb_session_create", "tb_session_start", "tb_session_poll", "tb_session_push_bound",
            "tb_session_stop", "tb_session_next_solution", "tb_session_finish", "tb_session_destroy",
            "tb_session_export_peer", "tb_session_import_peer", "tb_session_link_peer", "tb_session_arm",
-           "tb_session_progress", "tb_session_debug_last_store", "tb_session_plan"]
+           "tb_session_progress", "tb_session_debug_last_store", "tb_session_plan", "tb_session_unlink_peers", "tb_session_debug_path"]
 
 
 class TbConfig(C.Structure):
@@ -55,7 +55,7 @@ class TbStats(C.Structure):
                 ("subproblems_power", C.c_int32), ("best_bound", C.c_int32), ("best_subproblem", C.c_int32),
                 ("interrupted", C.c_int32), ("reserved", C.c_int32 * 2),
                 ("eps_local_subproblems", C.c_uint64), ("eps_stolen_subproblems", C.c_uint64), ("wait_time_ns", C.c_int64),
-                ("min_block_ns", C.c_int64), ("max_block_ns", C.c_int64)]
+                ("min_block_ns", C.c_int64), ("max_block_ns", C.c_int64), ("active_lane_evaluations", C.c_uint64)]
 
     def as_dict(self) -> dict:
         d = {}
@@ -74,6 +74,15 @@ class TbPlan(C.Structure):
                 ("subproblems_power", C.c_int32), ("eps_chunk_log2", C.c_int32), ("snapshot_levels", C.c_int32),
                 ("decision_stack_depth", C.c_int32), ("eps_local_subproblems", C.c_uint64),
                 ("kernel_event", C.c_int32), ("kernel_opt", C.c_int32)]
+
+
+class TbDebugPath(C.Structure):
+    _fields_ = [("subproblem", C.c_uint64), ("dive_levels_left", C.c_int32), ("depth", C.c_int32), ("decisions", C.c_int32),
+                ("last_objective_ub", C.c_int32), ("last_node_failed", C.c_int32), ("had_work", C.c_int32), ("nodes", C.c_int32), ("reserved", C.c_int32)]
+
+
+DEBUG_DECISION_DTYPE = np.dtype([("var", np.int32), ("child", np.int32), ("lb0", np.int32), ("ub0", np.int32), ("lb1", np.int32), ("ub1", np.int32),
+                                 ("objective_ub", np.int32)])
 
 
 class TbDeviceInfo(C.Structure):
@@ -128,7 +137,9 @@ def lib() -> C.CDLL:
         L.tb_session_progress.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.tb_session_debug_last_store.restype = C.c_int
         L.tb_session_debug_last_store.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
-        for name in ("tb_session_start", "tb_session_stop", "tb_session_arm"):
+        L.tb_session_debug_path.restype = C.c_int
+        L.tb_session_debug_path.argtypes = [C.c_void_p, C.c_int32, C.POINTER(TbDebugPath), C.c_int32, C.c_void_p]
+        for name in ("tb_session_start", "tb_session_stop", "tb_session_arm", "tb_session_unlink_peers"):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [C.c_void_p]
         L.tb_session_poll.restype = C.c_int
@@ -270,6 +281,10 @@ class Session:
         """Same process: let this session's kernel reach `other`'s cell (call it in both directions)."""
         check(lib().tb_session_link_peer(self._h, other._h))
 
+    def unlink_peers(self) -> None:
+        """Forget every imported / linked cell (a group that cannot be linked completely uses the host relay as a whole)."""
+        check(lib().tb_session_unlink_peers(self._h))
+
     def progress(self, counters: bool = False):
         """Remaining subproblems of this GPU as of the kernel's last poll (and, with counters, stolen in / out so far)."""
         rem, si, so = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
@@ -280,6 +295,13 @@ class Session:
         out = np.zeros(max(self._n_vars, 1), dtype=ITV_DTYPE)
         check(lib().tb_session_debug_last_store(self._h, workgroup, out.ctypes.data))
         return out[:self._n_vars]
+
+    def debug_path(self, workgroup: int = 0, capacity: int = 4096):
+        """Test aid: (header dict, decisions[DEBUG_DECISION_DTYPE]) of the path workgroup `workgroup` stood on when it left the kernel."""
+        hdr = TbDebugPath()
+        dec = np.zeros(max(capacity, 1), dtype=DEBUG_DECISION_DTYPE)
+        check(lib().tb_session_debug_path(self._h, workgroup, C.byref(hdr), capacity, dec.ctypes.data))
+        return {k: getattr(hdr, k) for k, _ in hdr._fields_}, dec[:hdr.decisions]
 
     def poll(self):
         best, done = C.c_int32(0), C.c_int32(0)

@@ -285,8 +285,9 @@ struct Translator {
   void narrow_cell(const Val& c, const std::string& dfz, int64_t dlo, int64_t dhi) {
     if (dfz[0] == '{') cons << "constraint set_in(" << c.var << ", " << dfz << ");\n";
     else cons << "constraint int_le(" << dlo << ", " << c.var << ");\nconstraint int_le(" << c.var << ", " << dhi << ");\n";
-    for (auto& kv : vars) if (kv.second.var == c.var) { kv.second.lo = dlo; kv.second.hi = dhi; }
-    elem_cache.clear();
+    // (looked up by name: one scan of `vars` per cell made per-cell array domains quadratic)
+    auto id = id_of.find(c.var);
+    if (id != id_of.end()) { Val& v = vars[id->second]; v.lo = dlo; v.hi = dhi; auto e = elem_cache.find(c.var); if (e != elem_cache.end()) e->second = v; }
   }
   // "x[]" "x[1..3]" "x[][0]" "y" "3" -> values
   void expand_ref(const std::string& w, std::vector<Val>* out) {
@@ -989,8 +990,10 @@ struct Translator {
       std::vector<const Xml*> conds;
       for (auto& c : n.kids) if (c->name == "condition" || c->name == "limit") conds.push_back(c.get());
       if (conds.size() != 2) fail("knapsack needs two conditions (weights, then profits)");
-      post_linear(w, xs, condition(conds[0]->text));
-      post_linear(pf, xs, condition(conds[1]->text));
+      // (a <limit> holds a bare value or variable: the weight may not exceed it)
+      auto cond_of = [&](const Xml* c) { std::string t = c->text; t.erase(0, t.find_first_not_of(" \t\r\n")); return condition((c->name == "limit" && !t.empty() && t[0] != '(') ? "(le," + t + ")" : t); };
+      post_linear(w, xs, cond_of(conds[0]));
+      post_linear(pf, xs, cond_of(conds[1]));
       return;
     }
     if (k == "binPacking") {
@@ -1080,6 +1083,7 @@ struct Translator {
       scan(*tmpl);
       if (arity == 0) fail("slide: the template has no %i argument");
       const int64_t offset = l->get("offset").empty() ? 1 : std::stoll(l->get("offset"));
+      if (offset < 1) fail("slide: offset must be at least 1");
       const bool circular = n.get("circular") == "true";
       for (size_t a = 0; circular ? a < items.size() : a + arity <= items.size(); a += (size_t)offset) {
         std::vector<std::string> args;

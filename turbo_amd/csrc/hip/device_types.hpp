@@ -110,6 +110,7 @@ struct BlockStats {
   unsigned long long nodes, fails, solutions, fixpoint_iterations, num_deductions;
   unsigned long long eps_solved, eps_skipped, store_writes;
   unsigned long long stolen;        // subproblems this workgroup took from other GPUs' queues
+  unsigned long long active_evals;  // num_deductions without the idle lanes of partly filled slices
   long long timers[TB_NUM_TIMERS];  // wall-clock ticks
   long long best_time;              // tick at which the best solution was found
   long long wait_ticks;             // time spent without a subproblem (waiting for / looking for work on other GPUs)
@@ -117,6 +118,17 @@ struct BlockStats {
   long long best_sub;               // subproblem index that produced best_store (-1: none)
   int why, pad_why;                 // debugging: reasons that cleared `exhaustive` (bit mask)
   int dbg[32];                      // tuning build: first violation found by the self-check of the event fixpoint
+};
+
+// Test aid (tb_config.reserved[0] & 0x800000, tb_session_debug_path): where a workgroup stood when it left the kernel.
+struct PathHeader {
+  unsigned long long sub_idx;  // global index of its subproblem
+  int remaining;               // levels of the dive still to take (> 0: it stopped while diving)
+  int depth;                   // decisions on its stack
+  int last_obj_ub;             // upper bound last imposed on the objective in this subproblem (INT32_MAX: none)
+  int failed;                  // the last node failed
+  int has_work;                // 0: it left because no subproblem was left
+  int nodes;
 };
 
 struct DevProblem {
@@ -169,6 +181,8 @@ struct DevProblem {
   int2* g_snap;      // [B][L][V] snapshot stack
   int2* g_best;      // [B][V]
   int2* g_last;      // [B][V] test aid (tb_config.reserved[0] & 0x800000): the store of each workgroup when it left the kernel
+  int* g_path_ub;    // [B][max_depth] same test aid: the objective's upper bound in force when decision i of the stack was taken
+  PathHeader* g_path_hdr;  // [B] same test aid
   Decision* g_dec;   // [B][max_depth] first segment of every workgroup's decision stack
   Decision* dec_pool;  // [dec_pool_segments][max_depth] further segments, taken by the workgroups whose search goes deeper
   BlockStats* g_stats;

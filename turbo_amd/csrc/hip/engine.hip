@@ -454,6 +454,68 @@ void pack_var_adj(const Adjacency& adj, std::vector<int4>* heads, std::vector<in
   std::memcpy(heads->data(), w.data(), heads->size() * sizeof(int4));
 }
 
+// Chains (r04): the channelling records `b_i = (y = k_i)` of one variable y, sorted by k, are a CHAIN of consecutive records over one or more
+// slices (a 500-value index of an element constraint: eight slices).  When the chain's constants are consecutive integers, the record of value v
+// is first + (v - k_first): a narrowing of y from [a, b] to [a', b'] concerns exactly the chain slices holding the values a..a' and b'..b -- the
+// others hold values that are still inside the bounds (nothing to do) or were outside before (their b are false already).  For an eligible chain
+// the chain's own slices are therefore not listed among y's readers in the channelling records: the lane that writes y marks them by that
+// arithmetic (kernels.hpp: KEY_EQR_BIC run, slice_info 0x400).  Everybody else who narrows y still wakes every reader through var_adj.
+struct Chains {
+  std::vector<int> first, last;  // per variable: record range of its eligible chain, -1 = none
+  std::vector<char> slice_ok;    // per slice: every group of the slice belongs to an eligible chain (the kernel's flag is per slice)
+  bool in_chain(int y, int slice) const { return first[(size_t)y] >= 0 && slice >= first[(size_t)y] / 64 && slice <= last[(size_t)y] / 64; }
+};
+Chains find_chains(int32_t n_vars, int32_t n_props, const tb_prop* props, const std::vector<int4>& records, const std::vector<int>& value, const tb_itv* root, bool enable) {
+  Chains c;
+  c.first.assign((size_t)std::max(1, n_vars), -1); c.last.assign((size_t)std::max(1, n_vars), -1);
+  const int n_slices = (n_props + 63) / 64;
+  c.slice_ok.assign((size_t)std::max(1, n_slices), 0);
+  if (!enable || root == nullptr) return c;
+  std::vector<int> count((size_t)std::max(1, n_vars), 0);
+  std::vector<char> bad((size_t)std::max(1, n_vars), 0);
+  auto chain_slice = [&](int sl) { return (size_t)sl * 64 < records.size() && ((unsigned)records[(size_t)sl * 64].x >> 16) == KEY_EQR_BIC && (((unsigned)records[(size_t)sl * 64].x >> 15) & 1u); };
+  for (int sl = 0; sl < n_slices; ++sl) {
+    if (!chain_slice(sl)) continue;
+    const int32_t base = sl * 64;
+    int32_t end = std::min(n_props, base + 64);
+    for (int32_t i = base; i < end; ++i) if (props[i].op < 0) { end = i; break; }
+    for (int32_t i = base; i < end; ++i) {
+      const int y = props[i].y;
+      if (c.first[(size_t)y] < 0) c.first[(size_t)y] = i;
+      if (c.last[(size_t)y] >= 0 && c.last[(size_t)y] != i - 1) bad[(size_t)y] = 1;  // the records of one y are not contiguous
+      c.last[(size_t)y] = i;
+      count[(size_t)y]++;
+    }
+  }
+  for (int y = 0; y < n_vars; ++y) {
+    if (c.first[(size_t)y] < 0) continue;
+    const int f = c.first[(size_t)y], l = c.last[(size_t)y];
+    const long long k0 = value[(size_t)props[f].z];
+    bool ok = !bad[(size_t)y] && count[(size_t)y] == l - f + 1;
+    for (int i = f; i <= l && ok; ++i) ok = (long long)value[(size_t)props[i].z] == k0 + (i - f);
+    // (a root domain reaching far beyond the chain's values would make the range arithmetic wake slices of other chains, or overflow)
+    ok = ok && (long long)root[y].lb >= k0 - 64 && (long long)root[y].ub <= k0 + (l - f) + 64;
+    if (!ok) { c.first[(size_t)y] = c.last[(size_t)y] = -1; }
+  }
+  // the flag the kernel sees is per slice: a slice qualifies when all its groups do, a chain when all its slices do
+  for (bool changed = true; changed;) {
+    changed = false;
+    for (int sl = 0; sl < n_slices; ++sl) {
+      bool ok = chain_slice(sl);
+      const int32_t base = sl * 64;
+      for (int32_t i = base; ok && i < std::min(n_props, base + 64) && props[i].op >= 0; ++i) ok = c.first[(size_t)props[i].y] >= 0;
+      c.slice_ok[(size_t)sl] = ok ? 1 : 0;
+    }
+    for (int y = 0; y < n_vars; ++y) {
+      if (c.first[(size_t)y] < 0) continue;
+      bool ok = true;
+      for (int sl = c.first[(size_t)y] / 64; sl <= c.last[(size_t)y] / 64; ++sl) ok = ok && c.slice_ok[(size_t)sl];
+      if (!ok) { c.first[(size_t)y] = c.last[(size_t)y] = -1; changed = true; }
+    }
+  }
+  return c;
+}
+
 // Successor slices of each record's operands for the event-driven fixpoint (device_types.hpp: DevProblem::succ): x, y, z =
 // up to two OTHER slices reading the operand (16-bit ids, 0xffff = none); w: bits 4 + 2 (2 k + j) = interest of the j-th packed
 // successor of operand k; bit k = the slices interested in a RAISED LOWER bound of operand k do not all fit (walk var_adj for
@@ -470,8 +532,19 @@ void pack_var_adj(const Adjacency& adj, std::vector<int4>* heads, std::vector<in
 // readers interested in "upper bound lowered", the z slots those interested in "lower bound raised" -- already filtered: no interest check
 // at run time -- and bit 17 / bit 2 say that more than two were interested (walk the variable's adjacency record).
 std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacency& adj, const std::vector<int4>& records, const std::vector<int>& value, bool deal_groups,
-                            int n_int = 0, bool lean = false, int bool_word0 = 0) {
+                            const Chains& chains, int n_int = 0, bool lean = false, int bool_word0 = 0, bool cond_wake = false) {
   std::vector<int4> out(((size_t)n_props + 63) / 64 * 64, make_int4(-1, -1, -1, 0));
+  // Conditional wake-up of a chain by "b became false" (lean implication records, `cond_wake`): the rule of `b = (y = k)` reacts to a false b only when k
+  // sits on a bound of y, and the lane that lowers b can test that itself (one LDS read) -- when b is the truth variable of exactly one chain record.
+  std::vector<int> chan_rec;  // per variable: its only record in a channelling slice, -1 none, -2 several
+  if (lean && cond_wake) {
+    chan_rec.assign(adj.lists.size(), -1);
+    for (int32_t i = 0; i < n_props; ++i) {
+      if (props[i].op < 0 || ((unsigned)records[(size_t)(i / 64) * 64].x >> 16) != KEY_EQR_BIC) continue;
+      int& r = chan_rec[(size_t)props[i].x];
+      r = r == -1 ? i : -2;
+    }
+  }
   std::vector<int> dealt((size_t)n_props, -1);  // index inside its group of a lane whose y slots are dealt
   if (deal_groups)
     for (int32_t base = 0; base < n_props; base += 64) {
@@ -482,7 +555,7 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
         int32_t b = a + 1;
         while (b < end && props[b].y == props[a].y) ++b;
         size_t others = 0;
-        for (const Reader& r : adj.lists[(size_t)props[a].y]) others += r.slice != base / 64 ? 1 : 0;
+        for (const Reader& r : adj.lists[(size_t)props[a].y]) others += (r.slice != base / 64 && !chains.in_chain(props[a].y, r.slice)) ? 1 : 0;
         if (others > 2 && others <= 2 * (size_t)(b - a))
           for (int32_t i = a; i < b; ++i) dealt[(size_t)i] = i - a;
         a = b;
@@ -499,7 +572,7 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
         unsigned o[2] = {0xffffu, 0xffffu};
         int in[2] = {0, 0}, n = 0, idx = 0;
         for (const Reader& r : adj.lists[(size_t)vs[k]]) {
-          if (r.slice == s) continue;
+          if (r.slice == s || chains.in_chain(vs[k], r.slice)) continue;
           if (idx / 2 == dealt[(size_t)i]) { o[n] = (unsigned)r.slice; in[n] = r.interest; ++n; }
           ++idx;
         }
@@ -507,8 +580,10 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
         flags |= (in[0] << (4 + 2 * (2 * k))) | (in[1] << (4 + 2 * (2 * k + 1))) | (1 << 20);
         continue;
       }
+      // (y of a record of an eligible chain: the chain's slices are woken by value range, see Chains)
+      const bool chained = k == 1 && chains.slice_ok[(size_t)s] && chains.first[(size_t)vs[k]] >= 0;
       std::vector<Reader> others;
-      for (const Reader& r : adj.lists[(size_t)vs[k]]) if (r.slice != s) others.push_back(r);
+      for (const Reader& r : adj.lists[(size_t)vs[k]]) if (r.slice != s && !(chained && chains.in_chain(vs[k], r.slice))) others.push_back(r);
       int n_lb = 0, n_ub = 0;
       for (const Reader& r : others) { n_lb += (r.interest & 1) ? 1 : 0; n_ub += (r.interest & 2) ? 1 : 0; }
       // which event gets the slots when both do not fit: the one that fits; the upper bound if both would
@@ -552,6 +627,17 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
         }
         if (over) { o[0] = o[1] = 0xffffu; fl |= k == 1 ? (1 << 17) : (1 << 2); }
         slots[k] = (o[1] << 16) | o[0];
+        // y's only reader interested in "became false" is the chain record `y = (Y = kv)`: slot 0 = that slice, slot 1 = Y's index among the
+        // integers of the slab, bits 3-16 and 28-29 of w = kv (16 bits, signed), bit 30 = the flag; the run marks the slice only when kv is on a
+        // bound of Y at that moment (whoever moves a bound of Y onto kv later wakes that slice for it)
+        if (k == 1 && n == 1 && !over && !chan_rec.empty() && chan_rec[(size_t)vs[1]] >= 0) {
+          const int r = chan_rec[(size_t)vs[1]];
+          const int Y = props[r].y, kv = value[(size_t)props[r].z];
+          if ((unsigned)(r / 64) == o[0] && Y >= 0 && Y < n_int && Y < 0xffff && kv >= -32768 && kv <= 32767) {
+            slots[1] = o[0] | ((unsigned)Y << 16);
+            fl |= (int)((((unsigned)kv & 0x3fffu) << 3) | ((((unsigned)kv >> 14) & 3u) << 28) | (1u << 30));
+          }
+        }
       }
       const int by = vs[1] - n_int, bz = vs[2] - n_int;
       slots[0] = (unsigned)(bool_word0 + (by >> 4)) | ((unsigned)(bool_word0 + (bz >> 4)) << 16);
@@ -559,6 +645,15 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
       out[(size_t)i] = make_int4((int)slots[0], (int)slots[1], (int)slots[2], fl);
     }
   }
+  // Idle lanes of a lean implication slice (class padding, the tail of the last slice): the run forms both word addresses from the record before
+  // it masks anything, so they point at the first Boolean word of the slab (never written through: the lane is inactive) instead of 0xffff words
+  // past its start -- outside the workgroup's LDS allocation, or past the end of g_store for the last workgroups of a compact slab in global memory.
+  if (lean)
+    for (size_t base = 0; base < out.size(); base += 64) {
+      if (base >= records.size() || ((unsigned)records[base].x >> 16) != KEY_LEQT_BB) continue;
+      for (size_t i = base; i < base + 64; ++i)
+        if (i >= (size_t)n_props || props[i].op < 0) out[i] = make_int4((int)((unsigned)bool_word0 | ((unsigned)bool_word0 << 16)), -1, -1, 0);
+    }
   // Reified comparisons against a constant with a Boolean truth variable (KEY_EQR_BIC, KEY_LEQR_BIC: dedicated runs that never
   // report anything about z): the z slots, useless for a constant, carry its VALUE, and in the channelling slices bits 21-26 /
   // 27-31 + 19 of w carry the first / last lane of the record's group -- nothing left to gather or to shuffle at run time.
@@ -586,7 +681,8 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
 // operand kinds, flags), y = lanes that hold a propagator | 0x100 when the slice's successor records carry the lean implication encoding.
 // 0x200: the slice has one class (not the heavy one) and every operand of every record has a finite root domain within +-2^29 -- the plain
 // layout then runs it with lean_plain_run (kernels.hpp): 32-bit sums and differences of two such bounds cannot overflow, anywhere in the tree.
-std::vector<int2> slice_infos(const std::vector<int4>& packed, const std::vector<int>& real, int n_slices, bool lean, const tb_itv* root, bool plain_lean) {
+// 0x400: the slice's channelling groups belong to eligible chains (Chains): the lane that writes y wakes the chain's other slices by value range.
+std::vector<int2> slice_infos(const std::vector<int4>& packed, const std::vector<int>& real, int n_slices, bool lean, const tb_itv* root, bool plain_lean, const Chains& chains) {
   std::vector<int2> info((size_t)std::max(1, n_slices), make_int2(0, 0));
   for (int s = 0; s < n_slices; ++s) {
     const int w0 = (size_t)s * 64 < packed.size() ? packed[(size_t)s * 64].x : 0;
@@ -601,7 +697,8 @@ std::vector<int2> slice_infos(const std::vector<int4>& packed, const std::vector
         if (d.lb < -(1 << 29) || d.ub > (1 << 29)) finite = false;
       }
     }
-    info[(size_t)s] = make_int2(w0, n_real | (is_lean ? 0x100 : 0) | (finite ? 0x200 : 0));
+    const bool chain_ok = (size_t)s < chains.slice_ok.size() && chains.slice_ok[(size_t)s];
+    info[(size_t)s] = make_int2(w0, n_real | (is_lean ? 0x100 : 0) | (finite ? 0x200 : 0) | (chain_ok ? 0x400 : 0));
   }
   return info;
 }
@@ -922,13 +1019,16 @@ int upload_event_tables(DevBuffers& bufs, DevProblem& P, const tb_config& cfg, c
   P.slice_real = d_real;
   // the lean implication records address Boolean words by a 16-bit word index inside the slab
   const bool lean = lay.compact && std::getenv("TB_NO_LEAN") == nullptr && (size_t)lay.bool_word0() + (size_t)lay.bool_words() <= 0x10000;  // (TB_NO_LEAN: A/B runs)
-  std::vector<int4> succ = pack_succ(n_rec, net_props.data(), adj, packed, value, !(cfg.reserved[0] & 0x4000000), lay.n_int, lean, lay.bool_word0());
+  // (TB_NO_CHAIN_RANGE / TB_NO_COND_WAKE: A/B runs of the two r04 wake-up filters)
+  const bool joint = !(cfg.reserved[0] & 0x4000000);  // channelling slices take the joint run
+  const Chains chains = find_chains((int32_t)adj.lists.size(), n_rec, net_props.data(), packed, value, root, lay.compact && joint && std::getenv("TB_NO_CHAIN_RANGE") == nullptr);
+  std::vector<int4> succ = pack_succ(n_rec, net_props.data(), adj, packed, value, joint, chains, lay.n_int, lean, lay.bool_word0(), joint && std::getenv("TB_NO_COND_WAKE") == nullptr);
   succ.resize((size_t)plan.n_slices * 64, make_int4(-1, -1, -1, 0));
   int4* d_succ = nullptr;
   if ((rc = bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
   if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
   P.succ = d_succ;
-  const std::vector<int2> info = slice_infos(packed, real, plan.n_slices, lean, root, std::getenv("TB_NO_LEAN") == nullptr);
+  const std::vector<int2> info = slice_infos(packed, real, plan.n_slices, lean, root, std::getenv("TB_NO_LEAN") == nullptr, chains);
   if (std::getenv("TB_DUMP_SLICES") != nullptr)  // debugging aid
     for (int q = 0; q < plan.n_slices; ++q) {
       int prefix = 0, classed = 0;
@@ -1243,7 +1343,12 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     if ((rc = s->bufs.alloc(&s->d_peers, (size_t)P.world)) != TB_OK) return rc;
     P.cell = s->cell; P.peers = nullptr;  // set at arm time, when some peer is linked
   }
-  if (s->cfg.reserved[0] & 0x800000) { if ((rc = s->bufs.alloc(&P.g_last, B * VX)) != TB_OK) return rc; }
+  if (s->cfg.reserved[0] & 0x800000) {  // test aids: tb_session_debug_last_store, tb_session_debug_path
+    if ((rc = s->bufs.alloc(&P.g_last, B * VX)) != TB_OK) return rc;
+    if ((rc = s->bufs.alloc(&P.g_path_ub, B * (size_t)plan.max_depth)) != TB_OK) return rc;
+    if ((rc = s->bufs.alloc(&P.g_path_hdr, B)) != TB_OK) return rc;
+    HIP_TRY(hipMemset(P.g_path_hdr, 0, B * sizeof(PathHeader)));
+  }
   P.cut_nodes = s->cfg.stop_after_n_nodes;
   P.cut_nodes_total = s->cfg.stop_after_n_nodes_total;
   P.stop_after_n_solutions = s->cfg.stop_after_n_solutions;
@@ -1361,6 +1466,19 @@ int tb_session_link_peer(tb_session* s, tb_session* peer) {
   return TB_OK;
 }
 
+// Forget every peer cell linked or imported so far: a group that could only be linked in part falls back, as a whole, to the host relay with
+// per-rank shares of the node budget (a partly linked rank would otherwise count the group's budget in a cell nobody else adds to).
+int tb_session_unlink_peers(tb_session* s) {
+  if (!s) return fail(TB_ERR_INVALID, "null session");
+  if (s->started && !s->finished) return fail(TB_ERR_STATE, "session is running");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  for (void* m : s->ipc_mapped) (void)hipIpcCloseMemHandle(m);
+  s->ipc_mapped.clear();
+  for (int r = 0; r < s->P.world; ++r) if (r != s->P.rank) s->peer_cells[(size_t)r] = nullptr;
+  s->armed = false;
+  return TB_OK;
+}
+
 // Device-side state of one search: queue = this rank's whole share, no incumbent, counters at zero.
 int tb_session_arm(tb_session* s) {
   if (!s) return fail(TB_ERR_INVALID, "null session");
@@ -1449,6 +1567,36 @@ int tb_session_debug_last_store(tb_session* s, int32_t workgroup, tb_itv* store_
   std::vector<unsigned char> slab(std::max<size_t>(16, VX * 8));
   HIP_TRY(hipMemcpy(slab.data(), s->P.g_last + (size_t)workgroup * VX, VX * 8, hipMemcpyDeviceToHost));
   decode_slab(s->lay, slab.data(), store_out);
+  return TB_OK;
+}
+
+int tb_session_debug_path(tb_session* s, int32_t workgroup, tb_debug_path* path_out, int32_t capacity, tb_debug_decision* decisions_out) {
+  if (!s || !path_out || capacity < 0 || (capacity > 0 && !decisions_out)) return fail(TB_ERR_INVALID, "null argument");
+  if (!s->finished) return fail(TB_ERR_STATE, "session not finished");
+  if (!s->P.g_path_hdr) return fail(TB_ERR_STATE, "the session was not created with the 0x800000 test knob");
+  if (workgroup < 0 || workgroup >= s->plan.num_blocks) return fail(TB_ERR_INVALID, "workgroup out of range");
+  HIP_TRY(hipSetDevice(s->cfg.device));
+  PathHeader h;
+  HIP_TRY(hipMemcpy(&h, s->P.g_path_hdr + workgroup, sizeof(h), hipMemcpyDeviceToHost));
+  std::memset(path_out, 0, sizeof(*path_out));
+  path_out->subproblem = h.sub_idx; path_out->dive_levels_left = h.remaining; path_out->depth = h.depth;
+  path_out->last_objective_ub = h.last_obj_ub; path_out->last_node_failed = h.failed != 0 ? 1 : 0; path_out->had_work = h.has_work; path_out->nodes = h.nodes;
+  const int n = std::min(std::min(h.depth, s->plan.max_depth), capacity);  // (the first segment of the decision stack: deeper entries live in the pool)
+  path_out->decisions = n;
+  if (n > 0) {
+    std::vector<Decision> dec((size_t)n);
+    std::vector<int> ub((size_t)n);
+    HIP_TRY(hipMemcpy(dec.data(), s->P.g_dec + (size_t)workgroup * (size_t)s->plan.max_depth, (size_t)n * sizeof(Decision), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ub.data(), s->P.g_path_ub + (size_t)workgroup * (size_t)s->plan.max_depth, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+      tb_debug_decision& d = decisions_out[i];
+      d.var = s->lay.inv[(size_t)dec[(size_t)i].var];  // the caller's numbering
+      d.child = dec[(size_t)i].cur;
+      d.children[0] = tb_itv{dec[(size_t)i].child[0].x, dec[(size_t)i].child[0].y};
+      d.children[1] = tb_itv{dec[(size_t)i].child[1].x, dec[(size_t)i].child[1].y};
+      d.objective_ub = ub[(size_t)i];
+    }
+  }
   return TB_OK;
 }
 
@@ -1559,6 +1707,7 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
     st.num_blocks_done += (uint64_t)x.num_blocks_done;
     st.store_writes += x.store_writes;
     st.eps_stolen_subproblems += x.stolen;
+    st.active_lane_evaluations += x.active_evals;
     wait_ticks += x.wait_ticks;
     last_idle = std::max(last_idle, x.timers[TB_T_FIRST_BLOCK_IDLE]);
     st.depth_max = std::max(st.depth_max, x.depth_max);
@@ -1660,10 +1809,13 @@ int tb_solve(const tb_config* cfg_in, int32_t n_vars, const tb_itv* root_store,
   int rc = run(cfg, best_store_out, &has, &st);
   // The reference grows a workgroup's decision stack on demand (barebones:401-403); the stacks here are sized on the
   // host, so a search that outgrows them is run again with deeper ones.
-  for (int depth = cfg.decision_stack_depth > 0 ? cfg.decision_stack_depth : 16384; rc == TB_ERR_DEPTH && depth < (1 << 22);) {
+  // (capped at 2^19 decisions per segment: beyond that the retry could only end in an allocation failure that hides the depth error)
+  for (int depth = cfg.decision_stack_depth > 0 ? cfg.decision_stack_depth : 16384; rc == TB_ERR_DEPTH && depth < (1 << 19);) {
     depth *= 8;
     cfg.decision_stack_depth = depth;
-    rc = run(cfg, best_store_out, &has, &st);
+    const int rc2 = run(cfg, best_store_out, &has, &st);
+    if (rc2 == TB_ERR_OOM) return fail(TB_ERR_DEPTH, "decision stack overflow, and no memory for segments of " + std::to_string(depth) + " decisions");
+    rc = rc2;
   }
   if (rc != TB_OK) return rc;
   // Canonical pass: the B&B above proved `best_bound` optimal; the DFS-first solution under the constant
@@ -1686,6 +1838,7 @@ int tb_solve(const tb_config* cfg_in, int32_t n_vars, const tb_itv* root_store,
     }
     st.nodes += st2.nodes; st.fails += st2.fails; st.fixpoint_iterations += st2.fixpoint_iterations;
     st.num_deductions += st2.num_deductions; st.kernel_ns += st2.kernel_ns; st.store_writes += st2.store_writes;
+    st.active_lane_evaluations += st2.active_lane_evaluations;
   }
   if (has_solution_out) *has_solution_out = has;
   if (stats_out) *stats_out = st;

@@ -97,6 +97,8 @@ struct alignas(16) BlockShared {
   Decision* dec_seg[MAX_DEC_SEGS];  // segments 1.. of this workgroup's decision stack (segment 0 is its slab in g_dec)
   int n_dec_seg, pad_seg;
   long long t_start, t_mark;  // thread 0's clocks (kernel start, last phase boundary): LDS, not registers that live through every loop
+  long long t_dive;           // start of the current dive (0: not diving)
+  int last_obj_ub, pad_ub;    // upper bound last imposed on the objective in this subproblem (PINF: none): test aid, tb_session_debug_path
   unsigned long long red_key[MAX_WAVES];
   int red_first[MAX_WAVES];
   BlockStats bs;  // written by thread 0 only
@@ -294,6 +296,9 @@ struct ThreadCounters {
 __device__ __forceinline__ void add_deductions(BlockShared& sh, unsigned long long n) {
   (void)__hip_atomic_fetch_add(&sh.bs.num_deductions, n, TB_RLX, TB_WG);
 }
+__device__ __forceinline__ void add_active(BlockShared& sh, unsigned long long n) {
+  (void)__hip_atomic_fetch_add(&sh.bs.active_evals, n, TB_RLX, TB_WG);
+}
 __device__ __forceinline__ void flush_writes(BlockShared& sh, ThreadCounters& tc, bool force) {
   if (force || wave_any(tc.writes > (1u << 25))) {  // (64 lanes x 2^25 still fits the 32-bit wave sum)
     unsigned w = tc.writes;
@@ -403,6 +408,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
   __syncthreads();
   int it = 0, k = 0;
   unsigned wave_evals = 0;  // wave-uniform: slice evaluations of this wave (x 64 = deduce calls, barebones:958-960)
+  unsigned long long wave_active = 0;  // ... and the propagators they held (the network's last slice is partly filled)
   for (;;) {
     k = it % 3;
     bool changed = false, un = false;
@@ -425,6 +431,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
           bool ch = false, un_i = false;
           apply<false, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
           ++wave_evals;  // iterations x active propagators (gpu_dive_and_solve.hpp:304-306)
+          wave_active += (unsigned)imin(64, n - base);
           changed |= ch; un |= un_i;
           if (!wave_any(ch) && !wave_any(un_i) && lane == 0) slice_unent[base >> 6] = 0;
           continue;
@@ -444,6 +451,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
           bool ch = false, un_i = false;
           apply<false, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
           ++wave_evals;
+          wave_active += (unsigned)imin(64, n - base);
           if (!wave_any(ch)) {
             un |= un_i;
             if (rm && !wave_any(un_i) && lane == 0) slice_unent[base >> 6] = 0;  // 1 -> 0 only: entailment is monotone below a node
@@ -477,8 +485,8 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     if (force_sweeps) { if (it >= force_sweeps) break; else continue; }
     if (!ld(&sh.flag[k]) || dead_node(sh)) break;
   }
-  if (!wac1 && !rm && tid == 0) add_deductions(sh, (unsigned long long)it * (unsigned long long)n);  // barebones:934
-  if (lane == 0 && wave_evals != 0) add_deductions(sh, 64ull * wave_evals);
+  if (!wac1 && !rm && tid == 0) { add_deductions(sh, (unsigned long long)it * (unsigned long long)n); add_active(sh, (unsigned long long)it * (unsigned long long)n); }  // barebones:934
+  if (lane == 0 && wave_evals != 0) { add_deductions(sh, 64ull * wave_evals); add_active(sh, wave_active); }
   all_entailed = !ld(&sh.unent[k]);
   return it;
 }
@@ -918,6 +926,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   for (int b = wave; b < 32; b += nw) own |= 1u << b;
   int rounds = 0;
   unsigned wave_iters_total = 0;  // wave-uniform
+  unsigned wave_active_total = 0; // wave-uniform: the same, times the propagators of each slice (idle lanes of padded slices not counted)
   unsigned wave_writes = 0;       // wave-uniform: narrowed bounds counted on lane masks (s_bcnt1), credited to lane 0 at the end
 #ifdef TB_TUNING
   long long tprof = prof ? clock64() : 0;
@@ -1039,7 +1048,13 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
               if (ld(&sh.bot)) break;
             }
-            if (rep == reps_of(P, 3)) wave_iters_total += (pk(P) & 0x400000) ? 1u : iters;
+            {  // (tuning build: the class / useless-run filters of the census, as for the other runs below)
+              const int want = (knobs(P) >> 28) & 15;
+              if (rep == reps_of(P, 3) && (want == 0 || want - 1 == K_LEQ_T) && (!(knobs(P) & 0x40) || mask_nz(acc) == 0ull)) {
+                wave_iters_total += (pk(P) & 0x400000) ? 1u : iters;
+                wave_active_total += iters * (unsigned)(info.y & 0xff);
+              }
+            }
             tc.writes += run_writes_lean;
 #ifdef TB_TUNING
             if (prof && wave == 0) {
@@ -1057,7 +1072,18 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             if (mask_nz(acc) != 0ull) {
               // successors: the slots hold the readers interested in exactly these events (y.ub lowered / z.lb raised), pre-filtered
               const bool my_ny = (acc & 2u) != 0u, my_nz = (acc & 1u) != 0u;
-              const unsigned ty = my_ny ? (unsigned)sc.y : 0xffffffffu, tz = my_nz ? (unsigned)sc.z : 0xffffffffu;
+              unsigned ty = my_ny ? (unsigned)sc.y : 0xffffffffu;
+              const unsigned tz = my_nz ? (unsigned)sc.z : 0xffffffffu;
+              // conditional wake-up (pack_succ, bit 30 of w): y's only reader that cares about "became false" is the chain record `y = (Y = kv)`, whose
+              // rule reacts to a false y only when kv sits on a bound of Y -- one LDS read here instead of a whole channelling run there.  (Should a
+              // bound of Y move onto kv later, whoever moves it wakes that slice.)
+              const bool cond = my_ny && ((sc.w >> 30) & 1) != 0;
+              if (wave_any(cond)) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // my write of y, then this read: the chain run does the same with roles reversed
+                const Itv Yc = load_int<C>(store, cond ? (int)(ty >> 16) : 0);
+                const int kv = (int)(short)((((unsigned)sc.w >> 3) & 0x3fffu) | ((((unsigned)sc.w >> 28) & 3u) << 14));
+                if (cond) ty = (kv == Yc.lb || kv == Yc.ub) ? (ty | 0xffff0000u) : 0xffffffffu;
+              }
               bool did = false;
               if ((ty & 0xffffu) != 0xffffu) { mark_slice(nxt, (int)(ty & 0xffffu)); did = true; }
               if ((ty >> 16) != 0xffffu) { mark_slice(nxt, (int)(ty >> 16)); did = true; }
@@ -1139,10 +1165,16 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             const bool writer = act && lane == g_start;
             const bool dense = ((w0u >> 15) & 1) != 0;
             const int k0 = kc - (lane - g_start), k_last = k0 + (g_last - g_start);  // (meaningful when dense)
+            // Eligible chains (engine.hip: Chains, slice_info 0x400): the record of value v of my y is record s * 64 + lane + (v - kc), whatever slice it
+            // is in, and the chain's other slices are not among y's listed readers: the lane that writes y wakes the ones holding the values the
+            // bound moved over (and the new bound itself: its b may be false, or y assigned) -- the others have nothing to do.
+            const bool by_range = (info.y & 0x400) != 0;
+            bool chain_marked = false;
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               const unsigned xb = bool_bits(rx);
               const Itv Y = load_int<C>(store, yv);
               const bool t = act && (xb & 1u), f = act && (xb & 2u), u = act && xb == 0u;
+              bool again = false;
               int lb = Y.lb, ub = Y.ub;
               for (unsigned long long tm = wave_ballot(t); tm; tm &= tm - 1) {  // y = k for every true b (normally at most one per group)
                 const int l = __builtin_ctzll(tm);
@@ -1188,6 +1220,20 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                   if (cyu) lower_int_ub<C>(store, yv, ub);
                   const Itv now = load_int<C>(store, yv);
                   if (now.lb > now.ub) st(&sh.bot, 1);
+                  if (by_range) {
+                    const int rec = s * 64 + lane - kc, q_max = P.n_slices - 1;
+                    if (cyl) for (int q = imax((rec + Y.lb) >> 6, 0), qe = imin((rec + lb) >> 6, q_max); q <= qe; ++q) if (q != s) { mark_slice(nxt, q); chain_marked = true; }
+                    if (cyu) for (int q = imax((rec + ub) >> 6, 0), qe = imin((rec + Y.ub) >> 6, q_max); q <= qe; ++q) if (q != s) { mark_slice(nxt, q); chain_marked = true; }
+                  }
+                }
+                // The other half of the conditional wake-up (lean implication run above): a lane that makes a b false wakes this slice only if it then
+                // finds b's value on a bound of y.  If it read y before the write just above, it found nothing -- so the lane whose value has just
+                // BECOME a bound looks at its b once more, after that write: of the two, at least one sees the other's store (LDS operations of a wave
+                // execute in order, and the writer's come before this read in the same instruction stream).  A b found false now means one more pass.
+                if (wave_any(cyl | cyu)) {
+                  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (relaxed accesses to different addresses: the compiler may not hoist the read)
+                  const bool became_bound = act && !f && !set0 && ((lb != Y.lb && kc == lb) || (ub != Y.ub && kc == ub));
+                  if (became_bound && (bool_bits(rx) & 2u)) again = true;
                 }
                 run_writes += (unsigned)(set0 | set1) + (unsigned)cyl + (unsigned)cyu;
                 // (y is reported by the lane that wrote it, or by every lane of the group when y's readers are dealt out over their records)
@@ -1197,8 +1243,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               } else if (lane == 0) st(&sh.bot, 1);
               // When no truth variable occurs twice in the slice (word0 bit 11, pack_props) the joint fixpoint is reached and no
               // confirmation pass is needed; otherwise a b made false for one lane may still have to act through another one.
-              ch = single_pass ? false : nar != 0;
+              ch = again || (single_pass ? false : nar != 0);
             });
+            if (by_range) marked |= wave_any(chain_marked);
           } else if (C && (key == KEY_EQR_BIC || key == KEY_LEQR_BIC)) {
             // b = (y = k) / b = (y <= k): Boolean truth variable, integer y, constant k (read once per run)
             const bool is_eq = key == KEY_EQR_BIC;
@@ -1271,7 +1318,10 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             const unsigned cm = key & CLASS_SET_MASK;
             const int cls_of_slice = (cm & (cm - 1)) ? 10 : __builtin_ctz(cm | 0x400u);
             const bool useless = !wave_any(nar_all != 0);  // the run narrowed nothing
-            if (rep == reps_of(P, 3) && (want == 0 || want - 1 == cls_of_slice) && (!(knobs(P) & 0x40) || useless)) wave_iters_total += (pk(P) & 0x400000) ? 1u : wave_iters;  // 0x40: only the runs that narrowed nothing
+            if (rep == reps_of(P, 3) && (want == 0 || want - 1 == cls_of_slice) && (!(knobs(P) & 0x40) || useless)) {  // 0x40: only the runs that narrowed nothing
+              wave_iters_total += (pk(P) & 0x400000) ? 1u : wave_iters;
+              wave_active_total += wave_iters * (unsigned)(info.y & 0xff);
+            }
           }
         }
         s = s_next;
@@ -1290,7 +1340,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     if (!ld(&sh.flag[k]) || dead_node(sh)) break;
   }
   if (lane == 0) tc.writes += wave_writes;
-  if (lane == 0 && wave_iters_total != 0) add_deductions(sh, 64ull * wave_iters_total);
+  if (lane == 0 && wave_iters_total != 0) { add_deductions(sh, 64ull * wave_iters_total); add_active(sh, (unsigned long long)wave_active_total); }
   if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += t - tp0; tp0 = t; }  // profiling: rounds
   // leave both bitmaps empty for the next node (they are not after a failure)
   for (int rep = reps_of(P, 7); rep > 0; --rep)
@@ -1952,6 +2002,17 @@ __device__ __forceinline__ void split_node(const DevProblem& P, BlockShared& sh,
 
 // ---- the persistent search kernel ----------------------------------------------------------------
 
+// Thread 0, when the last level of the dive has been taken (or there is none): the dive's share of the time, and the EPS strategy
+// (strategy 0, dive only) hands over to the others (barebones:747-750).
+__device__ __forceinline__ void end_of_dive_timer(BlockShared& sh) {
+  sh.bs.timers[TB_T_DIVE] += wall_clock64() - sh.t_dive;
+  sh.t_dive = 0;
+}
+__device__ __forceinline__ void end_of_dive(const DevProblem& P, BlockShared& sh) {
+  end_of_dive_timer(sh);
+  if (P.has_eps_strategy) { sh.cur_strategy = sh.cur_strategy > 1 ? sh.cur_strategy : 1; sh.next_unassigned = 0; }
+}
+
 constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 15) / 16 * 16);
 
 // The event-driven variant is latency bound: its 256-thread form asks the register allocator for 7 waves per
@@ -2008,7 +2069,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
   if (tid == 0) {
     for (int i = 0; i < TB_NUM_TIMERS; ++i) bs.timers[i] = 0;
     bs.nodes = bs.fails = bs.solutions = bs.fixpoint_iterations = bs.num_deductions = 0;
-    bs.eps_solved = bs.eps_skipped = bs.store_writes = bs.stolen = 0;
+    bs.eps_solved = bs.eps_skipped = bs.store_writes = bs.stolen = bs.active_evals = 0;
     bs.wait_ticks = 0;
     bs.why = 0; bs.pad_why = 0;
     for (int i = 0; i < 32; ++i) bs.dbg[i] = 0;
@@ -2021,7 +2082,10 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
   }
   __syncthreads();
 
-  // B. dive-and-solve loop (barebones:656-886)
+  // B. dive-and-solve loop (barebones:656-886).  The dive (barebones:675-714) and the solve loop (barebones:752-864) share their body -- propagate, then
+  // branch -- so they are ONE loop here with one call site of the node and of the variable selection (r03: the two inlined copies made the headline
+  // kernel 112 KB of code for a dive that is 0.2 % of its time): a node of the dive applies no objective bound (gpu_dive_and_solve.hpp:370-372),
+  // takes no snapshot, keeps no decision (the child is chosen by a bit of the subproblem index) and a leaf there skips the subtree.
   while (sh.has_work && !sh.stop) {
     // C. restore the root
     copy_store(store, glob(P.root_store), VX);  // the root slab is laid out like a workgroup slab
@@ -2030,43 +2094,22 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
       __syncthreads();
       for (int s = tid; s < P.n_slices; s += blockDim.x) es.unent[s] = 1;
     }
-    long long t_dive = 0;
     if (tid == 0) {
       sh.cur_strategy = 0; sh.next_unassigned = 0; sh.depth = 0; sh.bot = 0;
       sh.remaining = P.subproblems_power; sh.leaf = 0;
-      t_dive = wall_clock64();
+      sh.last_obj_ub = PINF;
+      sh.t_dive = wall_clock64();
       if (P.use_fixed_bound && __hip_atomic_load(&glob(P.ctrl)->first_sol_idx, TB_RLX, TB_AGENT) < sh.sub_idx) sh.stop = 1;
+      if (P.subproblems_power == 0) end_of_dive(P, sh);
     }
     __syncthreads();
-    // D. dive: no objective bound while diving (gpu_dive_and_solve.hpp:370-372)
-    while (sh.remaining > 0 && !sh.leaf && !sh.stop) {
-      propagate_node<EVENT, C, RM, MEM>(P, sh, store, props, es, best_store, mbox, tc);
-      if (!sh.leaf && !sh.stop) {
-        split_node<EVENT, C, (MEM >= TB_MEM_STORE_SHARED)>(P, sh, dec, store);
-        if (tid == 0) {
-          if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; bs.why |= 1; }  // unsplittable infinite domains (barebones:688-694)
-          else {
-            --sh.remaining;
-            --sh.depth;  // decisions are not recorded while diving
-            const int bit = (int)((sh.sub_idx >> sh.remaining) & 1ull);
-            embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dec[0].var, dec[0].child[bit].x, dec[0].child[bit].y);
-          }
-        }
-      }
-      __syncthreads();
-    }
-    if (tid == 0) bs.timers[TB_T_DIVE] += wall_clock64() - t_dive;
-    if (sh.leaf && !sh.stop) {
-      // E. a leaf above the subproblem: skip the whole subtree (barebones:718-741)
-      if (tid == 0) skip_subtree(P, sh);
-    } else if (!sh.stop) {
-      // F. solve the subproblem (barebones:742-871)
-      if (tid == 0 && P.has_eps_strategy) { sh.cur_strategy = sh.cur_strategy > 1 ? sh.cur_strategy : 1; sh.next_unassigned = 0; }
-      __syncthreads();
-      while (!sh.stop) {
+    bool exhausted = false;  // uniform: the subproblem's tree was searched to the end (barebones:866-870)
+    while (!sh.stop) {
+      const bool diving = sh.remaining > 0;  // uniform: thread 0 last wrote it before a barrier
+      if (!diving) {
         // I. tighten the objective with the incumbent (barebones:756-771)
         if (tid == 0 && P.obj_var >= 0) {
-          if (P.use_fixed_bound) embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, P.obj_var, NINF, P.fixed_bound);
+          if (P.use_fixed_bound) { sh.last_obj_ub = P.fixed_bound; embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, P.obj_var, NINF, P.fixed_bound); }
           else {
             const unsigned long long bf = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&glob(P.ctrl)->best_bound), TB_RLX, TB_AGENT);
             int g = (int)(bf & 0xffffffffull);
@@ -2075,72 +2118,87 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
             g = sh.best_bound < g ? sh.best_bound : g;
             if (g != PINF) {
               if (g == NINF) { sh.stop = 1; raise_gpu_stop(P); }  // unbounded objective
-              else embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, P.obj_var, NINF, g - 1);
+              else { sh.last_obj_ub = g - 1; embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, P.obj_var, NINF, g - 1); }
             }
           }
         }
         __syncthreads();
         if (sh.stop) break;
-        // II. propagate
-        propagate_node<EVENT, C, RM, MEM>(P, sh, store, props, es, best_store, mbox, tc);
-        if (sh.stop) break;
-        // III. branch
-        if (!sh.leaf) {
-          const int d0 = sh.depth;
-          const bool prof = (knobs(P) & 0x10000) != 0;
-          long long tp = 0;
-          if (prof && tid == 0) tp = wall_clock64();
+      }
+      // II. propagate
+      propagate_node<EVENT, C, RM, MEM>(P, sh, store, props, es, best_store, mbox, tc);
+      if (sh.stop) break;
+      // III. branch
+      if (!sh.leaf) {
+        const int d0 = sh.depth;
+        const bool prof = (knobs(P) & 0x10000) != 0;
+        long long tp = 0;
+        if (prof && tid == 0) tp = wall_clock64();
+        if (!diving) {
           if (d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * VX, store, VX);  // d0 == 0: barebones:785-791
           if ((pk(P) & 0x4) && d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * VX, store, VX);  // tuning: cost of the snapshot
           if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
           __syncthreads();
-          if (prof && tid == 0) { const long long t = wall_clock64(); bs.timers[TB_T_PREPROCESSING] += t - tp; tp = t; }  // profiling: snapshot push
-          split_node<EVENT, C, (MEM >= TB_MEM_STORE_SHARED)>(P, sh, dec, store);
-          if (prof && tid == 0) bs.timers[TB_T_SELECT_FP_FUNCTIONS] += wall_clock64() - tp;  // profiling: variable selection
-          if (sh.stop) break;
-          if (tid == 0) {
-            if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; bs.why |= 2; }
-            else {
-              Decision& dd = dec_at(P, sh, dec, sh.depth - 1);
-              const int c = ++dd.cur;
-              embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
-            }
-          }
-          __syncthreads();
         }
-        // IV. backtrack: rope jump, then restore the deepest snapshot and replay (barebones:812-863)
-        if (sh.leaf) {
-          const int dcur = sh.depth;  // stable: last written before a barrier
-          if (dcur == 0) break;
-          if (tid == 0) { const Decision& dl = dec_at(P, sh, dec, dcur - 1); sh.new_depth = dl.rope[dl.cur]; }
-          __syncthreads();
-          const int depth = sh.new_depth;
-          if (depth == -1) break;
-          const int lvl = (depth - 1) < (P.snapshot_levels - 1) ? (depth - 1) : (P.snapshot_levels - 1);
-          for (int rep = reps_of(P, 6); rep > 0; --rep) copy_store(store, snap + (size_t)lvl * VX, VX);
-          if (tid == 0) { sh.bot = 0; sh.depth = depth; }
-          __syncthreads();
-          // re-apply decisions[lvl .. depth-2].current(): distinct decisions may hit the same variable, the
-          // atomic min/max make the order irrelevant (the reference loops to a fixpoint, barebones:839-851)
-          for (int i = lvl + tid; i < depth - 1; i += blockDim.x) {
-            const Decision& di = dec_at(P, sh, dec, i);
-            const int2 ch = di.child[di.cur];
-            raise_lb<C>(store, P.n_int, di.var, ch.x);
-            lower_ub<C>(store, P.n_int, di.var, ch.y);
-            if (EVENT) note_change(sh, es, di.var, EV_LB | EV_UB);
-          }
-          __syncthreads();
-          if (tid == 0) {
-            Decision& dd = dec_at(P, sh, dec, depth - 1);
+        if (prof && tid == 0) { const long long t = wall_clock64(); bs.timers[TB_T_PREPROCESSING] += t - tp; tp = t; }  // profiling: snapshot push
+        split_node<EVENT, C, (MEM >= TB_MEM_STORE_SHARED)>(P, sh, dec, store);
+        if (prof && tid == 0) bs.timers[TB_T_SELECT_FP_FUNCTIONS] += wall_clock64() - tp;  // profiling: variable selection
+        if (sh.stop) break;
+        if (tid == 0) {
+          if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; bs.why |= diving ? 1 : 2; }  // unsplittable infinite domains (barebones:688-694)
+          else if (diving) {
+            --sh.remaining;
+            --sh.depth;  // decisions are not recorded while diving
+            const int bit = (int)((sh.sub_idx >> sh.remaining) & 1ull);
+            embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dec[0].var, dec[0].child[bit].x, dec[0].child[bit].y);
+            if (sh.remaining == 0) end_of_dive(P, sh);
+          } else {
+            Decision& dd = dec_at(P, sh, dec, sh.depth - 1);
             const int c = ++dd.cur;
             embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
-            sh.cur_strategy = sh.snap_strategy;
-            sh.next_unassigned = sh.snap_next_unassigned;
+            // test aid (tb_session_debug_path): the objective bound in force when this decision was taken
+            if (P.g_path_ub != nullptr && sh.depth <= P.max_depth) glob(P.g_path_ub)[(size_t)b * P.max_depth + (sh.depth - 1)] = sh.last_obj_ub;
           }
-          __syncthreads();
         }
+        __syncthreads();
       }
-      if (tid == 0 && !sh.stop) bs.eps_solved += 1;
+      if (sh.leaf) {
+        // E. a leaf above the subproblem: skip the whole subtree (barebones:718-741)
+        if (diving) { if (tid == 0) skip_subtree(P, sh); break; }
+        // IV. backtrack: rope jump, then restore the deepest snapshot and replay (barebones:812-863)
+        const int dcur = sh.depth;  // stable: last written before a barrier
+        if (dcur == 0) { exhausted = true; break; }
+        if (tid == 0) { const Decision& dl = dec_at(P, sh, dec, dcur - 1); sh.new_depth = dl.rope[dl.cur]; }
+        __syncthreads();
+        const int depth = sh.new_depth;
+        if (depth == -1) { exhausted = true; break; }
+        const int lvl = (depth - 1) < (P.snapshot_levels - 1) ? (depth - 1) : (P.snapshot_levels - 1);
+        for (int rep = reps_of(P, 6); rep > 0; --rep) copy_store(store, snap + (size_t)lvl * VX, VX);
+        if (tid == 0) { sh.bot = 0; sh.depth = depth; }
+        __syncthreads();
+        // re-apply decisions[lvl .. depth-2].current(): distinct decisions may hit the same variable, the
+        // atomic min/max make the order irrelevant (the reference loops to a fixpoint, barebones:839-851)
+        for (int i = lvl + tid; i < depth - 1; i += blockDim.x) {
+          const Decision& di = dec_at(P, sh, dec, i);
+          const int2 ch = di.child[di.cur];
+          raise_lb<C>(store, P.n_int, di.var, ch.x);
+          lower_ub<C>(store, P.n_int, di.var, ch.y);
+          if (EVENT) note_change(sh, es, di.var, EV_LB | EV_UB);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          Decision& dd = dec_at(P, sh, dec, depth - 1);
+          const int c = ++dd.cur;
+          embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+          sh.cur_strategy = sh.snap_strategy;
+          sh.next_unassigned = sh.snap_next_unassigned;
+        }
+        __syncthreads();
+      }
+    }
+    if (tid == 0) {
+      if (sh.t_dive != 0) end_of_dive_timer(sh);  // (stopped, or met a leaf, while diving)
+      if (exhausted && !sh.stop) bs.eps_solved += 1;
     }
     // G. next subproblem (barebones:877-884)
     if (tid == 0 && !sh.stop) {
@@ -2150,6 +2208,13 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
       sh.t_mark = wall_clock64();  // time spent waiting for work is not search time (BlockStats::wait_ticks)
     }
     __syncthreads();
+  }
+  // test aid (tb_config.reserved[0] & 0x800000, tb_session_debug_path): where this workgroup stood when it left
+  if (P.g_path_hdr != nullptr && tid == 0) {
+    PathHeader h;
+    h.sub_idx = sh.sub_idx; h.remaining = sh.remaining; h.depth = sh.depth; h.last_obj_ub = sh.last_obj_ub; h.failed = sh.bot;
+    h.has_work = sh.has_work; h.nodes = (int)bs.nodes;
+    glob(P.g_path_hdr)[b] = h;
   }
   if (P.g_last != nullptr) copy_store(glob(P.g_last) + (size_t)b * VX, store, VX);  // test aid: the store this workgroup stopped on
 

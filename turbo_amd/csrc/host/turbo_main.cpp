@@ -270,7 +270,7 @@ int solve_sessions_once(const Options& o, const tb_config& base, const tf_model*
       for (int g = 0; g < G && rc == TB_OK; ++g) {
         tb_plan pl{};
         rc = tb_session_plan(ss[(size_t)g], &pl);
-        if (rc == TB_OK && (pl.subproblems_power != dmax || pl.eps_chunk_log2 != std::min(base.eps_chunk_log2, dmax))) {
+        if (rc == TB_OK && (pl.subproblems_power != dmax || pl.eps_chunk_log2 != std::max(0, std::min(base.eps_chunk_log2, dmax)))) {  // (the engine clamps the chunk to 0 .. d)
           std::cerr << "the GPUs of this search cannot agree on one subproblem count (2^" << pl.subproblems_power << " on GPU " << g << ", 2^" << dmax << " wanted)" << std::endl;
           for (tb_session* s : ss) tb_session_destroy(s);
           return TB_ERR_INVALID;
@@ -280,10 +280,15 @@ int solve_sessions_once(const Options& o, const tb_config& base, const tf_model*
   }
   // The kernels exchange the incumbent bound and rebalance work among themselves over xGMI (include/turbo_hip.h:
   // tb_session_link_peer); without a peer path between two devices the relay below (poll / push_bound) carries the bound.
+  bool all_linked = true;
   for (int a = 0; a < G && rc == TB_OK; ++a)
     for (int b = 0; b < G && rc == TB_OK; ++b)
-      if (a != b && tb_session_link_peer(ss[(size_t)a], ss[(size_t)b]) != TB_OK && o.verbose)
-        std::printf("%% GPUs %d and %d are not linked (%s): the host relays the bound.\n", a, b, tb_last_error());
+      if (a != b && tb_session_link_peer(ss[(size_t)a], ss[(size_t)b]) != TB_OK) {
+        all_linked = false;
+        if (o.verbose) std::printf("%% GPUs %d and %d are not linked (%s): the host relays the bound.\n", a, b, tb_last_error());
+      }
+  // (all or nothing: a partly linked group would count its node budget in a cell that not every GPU adds to)
+  if (!all_linked) for (int g = 0; g < G && rc == TB_OK; ++g) rc = tb_session_unlink_peers(ss[(size_t)g]);
   for (int g = 0; g < G && rc == TB_OK; ++g) rc = tb_session_arm(ss[(size_t)g]);  // every cell is reset before any kernel can touch it
   for (int g = 0; g < G && rc == TB_OK; ++g) rc = tb_session_start(ss[(size_t)g]);
   std::vector<tb_itv> tmp(best.size());
@@ -341,7 +346,9 @@ int solve_sessions_once(const Options& o, const tb_config& base, const tf_model*
 int solve_sessions(const Options& o, const tb_config& base, const tf_model* m, std::vector<tb_itv>& best, int32_t* has, tb_stats* out, SolutionPrinter* printer) {
   int segment = base.decision_stack_depth;
   int rc = solve_sessions_once(o, base, m, segment, best, has, out, printer);
-  for (int depth = segment > 0 ? segment : 16384; rc == TB_ERR_DEPTH && depth < (1 << 22) && (!printer || printer->optimization || printer->printed == 0);) {
+  // (the first segments of all workgroups are one allocation of num_blocks x depth x 32 B: the retry stops at 2^19 decisions per segment --
+  //  16 segments of that are 8 M decisions per workgroup -- instead of ending in an allocation failure that hides the depth error)
+  for (int depth = segment > 0 ? segment : 16384; rc == TB_ERR_DEPTH && depth < (1 << 19) && (!printer || printer->optimization || printer->printed == 0);) {
     depth *= 8;
     if (o.verbose) std::printf("%% A decision stack overflowed: searching again with segments of %d decisions.\n", depth);
     rc = solve_sessions_once(o, base, m, depth, best, has, out, printer);

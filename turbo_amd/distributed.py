@@ -65,7 +65,11 @@ def link_group(session, dist=None, tensor_device="cpu") -> bool:
             ok = 0
     flag = torch.tensor([ok], dtype=torch.int32, device=tensor_device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    return bool(int(flag.item()))
+    linked = bool(int(flag.item()))
+    if not linked:
+        # partly linked: every rank drops what it imported, so that no rank counts the group's node budget in a cell the others do not add to
+        session.unlink_peers()
+    return linked
 
 
 def run_linked(session, dist=None, period_s: float = 0.0002, max_seconds: float | None = None):
