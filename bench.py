@@ -145,7 +145,7 @@ def reference_invocation(seconds: float) -> dict:
 def profile_figures(workload: str, fixpoint: str) -> dict | None:
     """Counter-derived figures of the same command, collected by scripts/profile_round.sh in separate rocprofv3 --pmc
     passes and committed under profiles/ (they are NOT measured in this run: the source file is named)."""
-    for name in ("r03_counters.json", "r02_counters.json"):
+    for name in ("r04_counters.json", "r03_counters.json", "r02_counters.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -156,6 +156,41 @@ def profile_figures(workload: str, fixpoint: str) -> dict | None:
         if rec:
             return dict(rec, source=f"profiles/{name}")
     return None
+
+
+def roofline_record(info: dict, mem_kind: int, props: float, writes: float, kernel_s: float) -> dict:
+    """algorithmic bytes per propagation = 16 B record + 3 x 8 B domains (+ 8 B per narrowed bound).  The level that serves the
+    domains bounds the kernel's memory side: LDS when the store is LDS resident (records from L2), HBM when the store lives in global memory.
+    Every fraction is achieved / peak of THAT level, so it cannot exceed 1.  `props`, `writes`: per launch; `kernel_s`: average launch duration."""
+    lds_peak = info["compute_units"] * LDS_BYTES_PER_CLK_CU * info["clock_khz"] * 1e3 / 1e9
+    dom_gbps = (props * DOMAIN_BYTES + writes * 8) / max(kernel_s, 1e-12) / 1e9
+    rec_gbps = props * RECORD_BYTES / max(kernel_s, 1e-12) / 1e9
+    if mem_kind != 0:
+        roof = {"bound": "lds", "achieved": dom_gbps, "peak": lds_peak, "unit": "GB/s", "frac": dom_gbps / lds_peak,
+                "records_from_l2": {"achieved": rec_gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": rec_gbps / L2_PEAK_GBPS}}
+    else:
+        alg = dom_gbps + rec_gbps
+        roof = {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBPS}
+    roof.update({"traffic": None, "kernel": "tb::solve_kernel", "avg_launch_ms": kernel_s * 1000.0,
+                 "algorithmic_bytes_per_launch": props * (RECORD_BYTES + DOMAIN_BYTES) + writes * 8})
+    return roof
+
+
+def attach_counters(roof: dict, workload: str, fixpoint: str, launch_s: float) -> None:
+    """`traffic` = memory-side bytes per launch from the committed rocprofv3 --pmc passes of the same command (profiles/, NOT measured in this run:
+    the source file is named), scaled to this run's launch duration when the profiled launch was sized differently."""
+    prof = profile_figures(workload, fixpoint)
+    if not prof:
+        return
+    roof["traffic_source"] = prof.get("source")
+    if prof.get("hbm_bytes_per_launch") and prof.get("launch_ms"):
+        roof["traffic"] = prof["hbm_bytes_per_launch"] * (launch_s * 1000.0 / prof["launch_ms"])
+        roof["traffic_note"] = ("(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B of the counter passes named in traffic_source, per launch, scaled by this run's launch duration over "
+                                "the profiled one; MALL hits included (the guide's correction for 16-byte-per-lane streams)")
+    roof["hbm_counters"] = {k: prof[k] for k in ("hbm_bytes_per_launch", "hbm_gbps", "hbm_frac_of_peak", "launch_ms", "tcc_hit_rate", "fabric_read_bytes_per_propagation") if k in prof}
+    roof["issue"] = {k: prof[k] for k in ("valu_busy", "salu_busy", "lds_busy", "wait_any_share", "wait_inst_any_share",
+                                          "valu_per_64_propagations", "salu_per_64_propagations", "valu_per_node", "salu_per_node", "icache_hit_rate") if k in prof}
+    roof["issue"]["note"] = "binding resource; rocprofv3 --pmc SQ_* passes of this command, not measured in this run"
 
 
 def launch_ranks(n: int) -> int:
@@ -190,6 +225,8 @@ def main() -> int:
     ap.add_argument("--or-nodes", type=int, default=0, help="workgroups per GPU (0 = fill the GPU)")
     ap.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = the engine's choice)")
     ap.add_argument("--side-steps", type=int, default=2, help="steps of each of the other fixpoints (wac1, ac1, event) timed beside the headline (0 = skip)")
+    ap.add_argument("--other-steps", type=int, default=2,
+                    help="steps of each of the OTHER BASELINE configurations (accap_a3, trains15, synthetic 100k x 500k) timed after the headline, N = 1 only (0 = skip)")
     ap.add_argument("--reference-seconds", type=float, default=8.0,
                     help="-t of the reference's README invocation run through the turbo CLI for the `reference_invocation` record (0 = skip)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -242,19 +279,23 @@ def main() -> int:
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)  # "nccl" is RCCL over xGMI
         dist.barrier()  # communicator set-up happens here, outside every timed region
 
-    fzn, budget_event, budget_sweep = WORKLOADS[args.workload]
-    if args.workload == "synthetic":
-        from turbo_amd.synth import make_synthetic
-        tcn = make_synthetic(100_000, 500_000, seed=42)
-    elif args.no_simplify:
-        tcn = frontend.load_fzn(os.path.join(ROOT, "benchmarks", fzn))
-    else:
+    def load_workload(name: str):
+        file_name = WORKLOADS[name][0]
+        if name == "synthetic":
+            from turbo_amd.synth import make_synthetic
+            return make_synthetic(100_000, 500_000, seed=42)
+        if args.no_simplify:
+            return frontend.load_fzn(os.path.join(ROOT, "benchmarks", file_name))
         # the reference's default pipeline: root fixpoint (tb_propagate on this GPU) + network simplifier, outside the timed region
         from turbo_amd import preprocess
-        _model, tcn, _ = preprocess.load_fzn_simplified(os.path.join(ROOT, "benchmarks", fzn), device=local_rank)
+        return preprocess.load_fzn_simplified(os.path.join(ROOT, "benchmarks", file_name), device=local_rank)[1]
 
-    def make_session(fixpoint: str, budget: int):
+    fzn, budget_event, budget_sweep = WORKLOADS[args.workload]
+    tcn = main_tcn = load_workload(args.workload)
+
+    def make_session(fixpoint: str, budget: int, tcn=None):
         """Session + whether its cell is linked to every other rank's."""
+        tcn = tcn if tcn is not None else main_tcn
         linked = world > 1 and args.exchange == "peer"
         per_rank_budget = budget if (world == 1 or linked) else max(1, budget // world)  # unlinked ranks count on their own
         cfg = capi.make_config(fixpoint=FP_CODE[fixpoint], stop_after_n_nodes_total=per_rank_budget, stop_after_n_nodes=args.cutnodes,
@@ -294,13 +335,15 @@ def main() -> int:
         sync()
         t0 = time.perf_counter()
         keys = ("nodes", "num_deductions", "store_writes", "kernel_ns", "fixpoint_iterations", "wait_time_ns", "eps_stolen_subproblems",
-                "num_blocks_done", "cumulative_time_block_ns", "eps_solved_subproblems", "eps_skipped_subproblems")
+                "num_blocks_done", "cumulative_time_block_ns", "eps_solved_subproblems", "eps_skipped_subproblems", "active_lane_evaluations")
         tot = {k: 0 for k in keys}
+        tot["start_times"] = []
         last = None
         for _ in range(steps):
             last = one_step(sess, linked)
             for k in keys:
                 tot[k] += last[k]
+            tot["start_times"].append(last.get("host_start_time", 0.0))
         sync()
         elapsed = time.perf_counter() - t0
         g = dict(tot)
@@ -308,9 +351,17 @@ def main() -> int:
             t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-            agg = torch.tensor([tot["nodes"], tot["num_deductions"], tot["store_writes"]], dtype=torch.int64, device=tdev)
+            agg = torch.tensor([tot["nodes"], tot["num_deductions"], tot["store_writes"], tot["active_lane_evaluations"], tot["eps_solved_subproblems"],
+                                tot["eps_skipped_subproblems"], tot["eps_stolen_subproblems"], tot["kernel_ns"]], dtype=torch.int64, device=tdev)
             dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-            g["nodes"], g["num_deductions"], g["store_writes"] = (int(x) for x in agg.tolist())
+            (g["nodes"], g["num_deductions"], g["store_writes"], g["active_lane_evaluations"], g["eps_solved_subproblems"], g["eps_skipped_subproblems"],
+             g["eps_stolen_subproblems"], g["kernel_ns"]) = (int(x) for x in agg.tolist())
+            # start skew of a step: spread of the ranks' kernel-launch times (host clock), worst step
+            st = torch.tensor(tot["start_times"] or [0.0], dtype=torch.float64, device=tdev)
+            hi, lo = st.clone(), st.clone()
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            g["start_skew_ms_max"] = float((hi - lo).max().item()) * 1000.0
         return elapsed, tot, g, last
 
     scale = world if args.scaling == "weak" else 1
@@ -325,6 +376,8 @@ def main() -> int:
     row = {"kernel_ms": tot["kernel_ns"] * 1e-6 / steps, "nodes": tot["nodes"] / steps, "propagations": tot["num_deductions"] / steps,
            "wait_share": tot["wait_time_ns"] / max(1, tot["cumulative_time_block_ns"]),
            "stolen_subproblems": tot["eps_stolen_subproblems"] / steps, "blocks_done": tot["num_blocks_done"] / steps,
+           "eps_solved": tot["eps_solved_subproblems"] / steps, "eps_skipped": tot["eps_skipped_subproblems"] / steps,
+           "launch_latency_ms": last.get("host_launch_latency_s", 0.0) * 1000.0,
            "first_block_idle_ms": last["min_block_ns"] * 1e-6, "last_block_ms": last["max_block_ns"] * 1e-6, "workgroups": blocks}
     per_rank = tdist.gather_rank_rows(row, dist if world > 1 else None, tdev)
 
@@ -348,39 +401,50 @@ def main() -> int:
                           "memory": capi.MEM_KINDS[l2["mem_kind"]], "note": notes[other] + "; same search tree"})
             sess2.close()
 
+    # the other BASELINE.json configurations (N = 1): accap_a3 (configs[2]), trains15 (configs[3]'s instance) and the synthetic 100k x 500k network
+    # (configs[4], the store in global memory: the HBM-bound roofline point), a few short steps each with its own roofline record
+    others = []
+    if world == 1 and args.other_steps > 0:
+        session.close()  # one persistent search at a time
+        info0 = capi.device_info(local_rank)
+        for name in ("accap_a3", "trains15", "synthetic"):
+            if name == args.workload:
+                continue
+            t_load = time.perf_counter()
+            tcn2 = load_workload(name)
+            t_load = time.perf_counter() - t_load
+            for fp in (("event", "wac1") if name == "synthetic" else ("event",)):
+                b2 = WORKLOADS[name][1] if fp == "event" else WORKLOADS[name][2]
+                sess2, _ = make_session(fp, b2, tcn2)
+                pl2 = sess2.plan()
+                e2, t2, g2, l2 = timed(sess2, False, args.other_steps, 1)
+                ks2 = t2["kernel_ns"] * 1e-9 / args.other_steps
+                roof2 = roofline_record(info0, l2["mem_kind"], t2["num_deductions"] / args.other_steps, t2["store_writes"] / args.other_steps, ks2)
+                attach_counters(roof2, name, fp, ks2)
+                others.append({"workload": f"{WORKLOADS[name][0]}{'' if args.no_simplify or name == 'synthetic' else ' (simplified network)'}: {tcn2.n_vars} interval variables x {tcn2.n_props} ternary propagators",
+                               "fixpoint": fp, "steps": args.other_steps, "nodes_total": b2, "nodes_per_sec": g2["nodes"] / e2, "propagations_per_sec": g2["num_deductions"] / e2,
+                               "active_lane_evaluations_per_sec": g2["active_lane_evaluations"] / e2, "ms_per_step": e2 * 1000.0 / args.other_steps,
+                               "workgroups": l2["num_blocks"], "threads": l2["threads_per_block"], "memory": capi.MEM_KINDS[l2["mem_kind"]], "lds_bytes_per_workgroup": l2["shared_bytes"],
+                               "subproblems_power": pl2["subproblems_power"], "kernel_opt": pl2["kernel_opt"], "roofline": roof2, "load_and_simplify_s": t_load})
+                sess2.close()
+
     if rank == 0:
         kernel_s = tot["kernel_ns"] * 1e-9 / steps                 # average launch duration of solve_kernel (HIP events on its stream, rank 0)
         props = tot["num_deductions"] / steps                     # propagations of one launch, rank 0
         writes = tot["store_writes"] / steps
         info = capi.device_info(local_rank)
-        lds_peak = info["compute_units"] * LDS_BYTES_PER_CLK_CU * info["clock_khz"] * 1e3 / 1e9
-        in_lds = last["mem_kind"] != 0
-        # algorithmic bytes per propagation = 16 B record + 3 x 8 B domains (+ 8 B per narrowed bound).  The level
-        # that serves the domains bounds the kernel's memory side: LDS when the store is LDS resident (records from L2), HBM when
-        # the store lives in global memory.  Every fraction is achieved / peak of THAT level, so it cannot exceed 1.
-        dom_gbps = (props * DOMAIN_BYTES + writes * 8) / max(kernel_s, 1e-12) / 1e9
-        rec_gbps = props * RECORD_BYTES / max(kernel_s, 1e-12) / 1e9
-        if in_lds:
-            roof = {"bound": "lds", "achieved": dom_gbps, "peak": lds_peak, "unit": "GB/s", "frac": dom_gbps / lds_peak,
-                    "records_from_l2": {"achieved": rec_gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": rec_gbps / L2_PEAK_GBPS}}
-        else:
-            alg = dom_gbps + rec_gbps
-            roof = {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBPS}
-        roof.update({"traffic": None, "kernel": "tb::solve_kernel", "avg_launch_ms": kernel_s * 1000.0,
-                     "algorithmic_bytes_per_launch": props * (RECORD_BYTES + DOMAIN_BYTES) + writes * 8,
-                     "note": "integer propagation: no MFMA.  achieved = algorithmic bytes of the level named in `bound` / average launch duration "
-                             "(HIP events around the launch, this run).  The kernel is instruction-issue bound, not memory bound: see `issue`."})
-        prof = profile_figures(args.workload, args.fixpoint)
-        if prof:
-            roof["traffic_source"] = prof.get("source")
-            roof["hbm_counters"] = {k: prof[k] for k in ("hbm_bytes_per_launch", "hbm_gbps", "hbm_frac_of_peak", "launch_ms") if k in prof}
-            roof["issue"] = {k: prof[k] for k in ("valu_busy", "salu_busy", "lds_busy", "wait_any_share", "wait_inst_any_share",
-                                                  "valu_per_64_propagations", "salu_per_64_propagations") if k in prof}
-            roof["issue"]["note"] = "binding resource; rocprofv3 --pmc SQ_* passes of this command, not measured in this run"
+        roof = roofline_record(info, last["mem_kind"], props, writes, kernel_s)
+        roof["note"] = ("integer propagation: no MFMA.  achieved = algorithmic bytes of the level named in `bound` / average launch duration "
+                        "(HIP events around the launch, this run).  The kernel is instruction-issue bound, not memory bound: see `issue`.")
+        attach_counters(roof, args.workload, args.fixpoint, kernel_s)
         out = {
             "metric": "propagations/sec (+ nodes/sec) on wordpress7_500.fzn" if args.workload == "wordpress7_500" else f"propagations/sec (+ nodes/sec) on {fzn}",
             "value": glob["num_deductions"] / elapsed, "unit": "propagations/s",
             "nodes_per_sec": glob["nodes"] / elapsed,
+            # `value` counts wave iterations x 64 as the reference does (barebones:958-960); this is the same count without the idle lanes of partly
+            # filled slices (class padding, the network's last slice)
+            "active_lane_evaluations_per_sec": glob["active_lane_evaluations"] / elapsed,
+            "evaluations_per_node": {"counted_x64": glob["num_deductions"] / max(1, glob["nodes"]), "active_lanes": glob["active_lane_evaluations"] / max(1, glob["nodes"])},
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1000.0 / steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32",
@@ -398,11 +462,17 @@ def main() -> int:
             out["multi_gpu"] = {"exchange": "peer cells over xGMI" if linked else "host relay",
                                 "dist": {"backend": dist.get_backend(), "world_size": dist.get_world_size()}, "per_rank": per_rank,
                                 "kernel_ms_max_over_mean": max(ks) / max(1e-9, sum(ks) / len(ks)),
+                                "eps_solved_per_step": glob["eps_solved_subproblems"] / steps, "eps_skipped_per_step": glob["eps_skipped_subproblems"] / steps,
+                                "stolen_per_step": glob["eps_stolen_subproblems"] / steps, "start_skew_ms_max": glob.get("start_skew_ms_max"),
+                                # step time is the slowest rank's (what `value` divides by); the rate the kernels sustained while they ran:
+                                "nodes_per_sec_sum_over_kernel_time": glob["nodes"] / max(1e-9, glob["kernel_ns"] * 1e-9 / world),
                                 "note": "fixed node budget for all GPUs together (every device counts its own nodes, its poller folds them into rank 0's cell once per poll period); wait_share = workgroup-time without a subproblem"}
         else:
             out["balance"] = per_rank[0]
         for side in sides:
             out[f"{side['fixpoint']}_mode"] = side
+        if others:
+            out["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tcn, plan["subproblems_power"], args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = {"propagations": out["value"] / max(out["cpu_baseline"]["value"], 1e-9),

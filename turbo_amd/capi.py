@@ -137,9 +137,13 @@ def lib() -> C.CDLL:
         L.tb_session_progress.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.tb_session_debug_last_store.restype = C.c_int
         L.tb_session_debug_last_store.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
-        L.tb_session_debug_path.restype = C.c_int
-        L.tb_session_debug_path.argtypes = [C.c_void_p, C.c_int32, C.POINTER(TbDebugPath), C.c_int32, C.c_void_p]
+        # (TURBO_HIP_LIB may name an older build of the engine for a same-box A/B: entry points added since are bound when present)
+        if hasattr(L, "tb_session_debug_path"):
+            L.tb_session_debug_path.restype = C.c_int
+            L.tb_session_debug_path.argtypes = [C.c_void_p, C.c_int32, C.POINTER(TbDebugPath), C.c_int32, C.c_void_p]
         for name in ("tb_session_start", "tb_session_stop", "tb_session_arm", "tb_session_unlink_peers"):
+            if name == "tb_session_unlink_peers" and not hasattr(L, name):
+                continue
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [C.c_void_p]
         L.tb_session_poll.restype = C.c_int

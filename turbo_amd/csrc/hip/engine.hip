@@ -219,7 +219,8 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   p.threads = T;
   // (the event kernels have an instantiation of their own for workgroups of at most two waves: 7 waves per SIMD -- 72 VGPRs -- there,
   //  6 -- 84 VGPRs -- for the 256-thread ones, whose workgroups per CU are limited by LDS before registers: trains15 2.88e7 -> 3.12e7 nodes/s)
-  p.tmax = (event && T <= 128) ? 128 : (T <= 256 ? 256 : 1024);
+  // (the 128-thread instantiation has its workgroup size compiled in, kernels.hpp: block_threads -- 64-thread event workgroups take the 256 one)
+  p.tmax = (event && T == 128) ? 128 : (T <= 256 ? 256 : 1024);
   const size_t lds = (size_t)caps.lds_per_cu;
   // slab = domains + one entailment byte per slice, rounded to an even number of intervals so that every slab of a
   // stack (stores, snapshots) starts 16-byte aligned and copies as 16-byte words

@@ -170,6 +170,16 @@ __device__ __forceinline__ unsigned long long mask_nz(unsigned x) {
   return m;
 }
 
+// Threads of the workgroup.  TB != 0: a compile-time constant -- the two-wave event kernels of the search are only ever launched with exactly
+// 128 threads (engine.hip: plan_launch), and with the size known the strides, trip counts and alignment cases of every block-wide copy and scan fold
+// away instead of being hoisted into SGPRs that stay live (and spill) through the whole persistent loop.
+template <int TB> __device__ __forceinline__ int block_threads() { return TB != 0 ? TB : (int)blockDim.x; }
+// A value the optimiser may not reason about: what is computed from it stays where it is written.  The persistent kernel is one huge loop nest, and
+// everything loop invariant -- per-lane addresses of the block-wide copies, `1 << lane`, trip counts -- is otherwise hoisted to its top and kept (in
+// scratch, or in lanes of a spill register) for the whole search, at the expense of the registers the hot loops need.
+__device__ __forceinline__ int here(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int here_s(int x) { asm volatile("" : "+s"(x)); return x; }  // ... a wave-uniform one
+
 __device__ __forceinline__ int ld(const int* p) { return __hip_atomic_load(p, TB_RLX, TB_WG); }
 __device__ __forceinline__ void st(int* p, int v) { __hip_atomic_store(p, v, TB_RLX, TB_WG); }
 
@@ -552,7 +562,7 @@ __device__ __forceinline__ bool mark_var(const DevProblem& P, unsigned* dirty, i
 }
 // the tail of the lists longer than 11, cooperatively: one lane at a time is broadcast, the 64 lanes stride over its list
 __device__ __forceinline__ bool mark_tail(const DevProblem& P, unsigned* dirty, unsigned long long mask, int deg, int off, int ev, int self) {
-  const int lane = threadIdx.x & 63;
+  const int lane = here(threadIdx.x) & 63;
   bool did = false;
   while (mask) {
     const int l = __builtin_ctzll(mask);
@@ -712,7 +722,7 @@ __device__ __forceinline__ Itv lean_load(int2* store, int ni, const LeanOperand<
 template <int C, int CLS>
 __device__ __forceinline__ unsigned lean_class_run_t(const RunEnv& E, const int cls_dyn, const int kinds, const int4 pr, const bool act, int2* store, const int ni, unsigned& run_writes, unsigned& wave_writes, int& nar_all) {
   const int cls = CLS >= 0 ? CLS : cls_dyn;
-  const int lane = threadIdx.x & 63, s = E.s;
+  const int lane = here(threadIdx.x) & 63, s = E.s;
   const int kx = kinds & 3, ky = (kinds >> 2) & 3, kz = (kinds >> 4) & 3;  // wave-uniform
   const LeanOperand<C> ox = lean_operand<C>(store, ni, pr.y, act, kx), oy = lean_operand<C>(store, ni, pr.z, act, ky), oz = lean_operand<C>(store, ni, pr.w, act, kz);
   const int vx = ox.v, vy = oy.v, vz = oz.v;  // idle lanes look at variable 0 (a constant) and move nothing
@@ -880,10 +890,10 @@ __host__ __device__ inline size_t dirty_region_bytes(int dirty_words) { return (
 // waves: 250 slice runs per node asynchronously against 82 with a single wave).
 // Inside a round a wave still iterates each slice to its local fixpoint (WAC1), and a slice sees the narrowings other
 // waves have already made in the same round.
-template <int C>
+template <int C, int TB = 0>
 __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
                                               const EventState& es, ThreadCounters& tc, bool& all_entailed) {
-  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = T >> 6;
+  const int tid = here(threadIdx.x), T = block_threads<TB>(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = T >> 6;
   const int n = P.n_props, W = es.words, S = P.n_slices;
   const bool prof = (knobs(P) & 0x10000) != 0;
   long long tp0 = 0;
@@ -1389,7 +1399,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
 struct FpResult { int rounds; int all_entailed; unsigned writes; };
 // SL: the store (and the entailment bits behind it) lives in LDS, `store_ref` is then its LDS offset; otherwise the store is the
 // workgroup's slab in global memory and `gstore` points to it.
-template <int C, int MEM>
+template <int C, int MEM, int TB = 0>
 static __device__ TB_FIX_ATTR FpResult fixpoint_event_call(const DevProblem* Pp, unsigned sh_off, unsigned store_off, int2* gstore, unsigned props_off, const int4* gprops,
                                                      unsigned dirty_off, unsigned list_off, unsigned writes_in) {
   BlockShared& sh = *lds_ptr<BlockShared>(sh_off);
@@ -1404,7 +1414,7 @@ static __device__ TB_FIX_ATTR FpResult fixpoint_event_call(const DevProblem* Pp,
   tc.writes = writes_in;
   bool ae = false;
   FpResult r;
-  r.rounds = fixpoint_event<C>(constant_problem(Pp), sh, store, props, es, tc, ae);
+  r.rounds = fixpoint_event<C, TB>(constant_problem(Pp), sh, store, props, es, tc, ae);
   r.all_entailed = ae ? 1 : 0;
   r.writes = tc.writes;
   return r;
@@ -1412,11 +1422,13 @@ static __device__ TB_FIX_ATTR FpResult fixpoint_event_call(const DevProblem* Pp,
 
 // ---- small helpers -------------------------------------------------------------------------------
 
+
 // Block-wide copy of n intervals.  Both sides are 16-byte aligned (slabs are laid out in multiples of 2
 // intervals), so the body moves 16 B per lane with four independent loads in flight: a snapshot of a
 // 25k-variable store is ~12 memory round trips per thread instead of ~100.
+template <int TB = 0>
 __device__ __forceinline__ void copy_store(int2* dst, const int2* src, int n) {
-  const int T = blockDim.x, tid = threadIdx.x;
+  const int T = block_threads<TB>(), tid = here(threadIdx.x);  // (per-lane addresses computed here, at each copy)
   if ((reinterpret_cast<size_t>(dst) | reinterpret_cast<size_t>(src)) & 15) {  // odd-sized caller buffers (best store, tb_propagate batches)
     for (int i = tid; i < n; i += T) dst[i] = src[i];
     return;
@@ -1519,9 +1531,9 @@ __device__ __forceinline__ bool push_decision(const DevProblem& P, BlockShared& 
 // input_order_split / lattice_smallest_split (barebones:240-349) by one strided scan, a wave-level
 // min reduction (DPP/bpermute shuffles) and one LDS round per strategy.
 // Ends with a barrier; sh.found tells whether a decision was pushed at sh.depth-1.
-template <int C>
+template <int C, int TB = 0>
 __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Decision* dec, const int2* store) {
-  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+  const int tid = here(threadIdx.x), T = block_threads<TB>(), lane = tid & 63, wave = tid >> 6, nw = T >> 6;
   for (;;) {
     const int s = sh.cur_strategy;  // uniform: read after a barrier
     if (s >= P.n_strats) { if (tid == 0) sh.found = 0; __syncthreads(); return; }
@@ -1591,6 +1603,7 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
 // Streaming: hand the solution in `store` to the host through the ring (GridData::produce_solution,
 // gpu_dive_and_solve.hpp:100-114, without the print lock: a ticket orders the producers, the host consumes in
 // ticket order).  Uniform call; sh.ticket was taken by thread 0.
+template <int TB = 0>
 __device__ __forceinline__ void produce_solution(const DevProblem& P, BlockShared& sh, const int2* store, Mailbox* mbox) {
   const int tid = threadIdx.x;
   const unsigned long long ticket = (unsigned long long)sh.ticket;
@@ -1606,7 +1619,7 @@ __device__ __forceinline__ void produce_solution(const DevProblem& P, BlockShare
   __syncthreads();
   if (sh.ticket >= 0) {
     const int slot = (int)(ticket % (unsigned long long)r.slots);
-    copy_store(r.data + (size_t)slot * P.vext, store, P.vext);
+    copy_store<TB>(r.data + (size_t)slot * P.vext, store, P.vext);
     __threadfence_system();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&r.seq[slot], ticket + 1ull, __ATOMIC_RELEASE, TB_SYS);
@@ -1829,18 +1842,18 @@ __device__ __forceinline__ void skip_subtree(const DevProblem& P, BlockShared& s
 
 struct NodeTimers { long long t_last; };
 
-template <bool EVENT, int C, bool RM, int MEM>
+template <bool EVENT, int C, bool RM, int MEM, int TB = 0>
 __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
                                                     int2* best_store, Mailbox* mbox, ThreadCounters& tc) {
   const int tid = threadIdx.x;
   BlockStats& bs = sh.bs;
-  long long t0 = 0;
-  if (tid == 0) { t0 = wall_clock64(); bs.timers[TB_T_SEARCH] += t0 - sh.t_mark; }
+  // (thread 0's clock at the phase boundary lives in LDS, sh.t_mark: a register pair held through the fixpoint ended up in scratch)
+  if (tid == 0) { const long long t0 = wall_clock64(); bs.timers[TB_T_SEARCH] += t0 - sh.t_mark; sh.t_mark = t0; }
   bool all_entailed = false;
   int iters;
   if constexpr (EVENT) {
     constexpr bool SL = MEM >= TB_MEM_STORE_SHARED, PL = MEM == TB_MEM_TCN_SHARED;
-    const FpResult r = fixpoint_event_call<C, MEM>(&P, lds_off(&sh), SL ? lds_off(store) : 0u, SL ? nullptr : store, PL ? lds_off(props) : 0u, PL ? nullptr : props,
+    const FpResult r = fixpoint_event_call<C, MEM, TB>(&P, lds_off(&sh), SL ? lds_off(store) : 0u, SL ? nullptr : store, PL ? lds_off(props) : 0u, PL ? nullptr : props,
                                                    lds_off(es.dirty), lds_off(es.list), tc.writes);
     iters = r.rounds; all_entailed = r.all_entailed != 0; tc.writes = r.writes;
   } else iters = fixpoint<RM, C>(P, sh, store, props, es.unent, tc, all_entailed);
@@ -1855,7 +1868,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
   // pad_why keeps 1 + the first offending slice.
   if (EVENT && (knobs(P) & 0x1000000) && !failed && !aborted) {
     const int lane = threadIdx.x & 63;
-    for (int s = threadIdx.x >> 6; s < P.n_slices; s += blockDim.x >> 6) {
+    for (int s = threadIdx.x >> 6; s < P.n_slices; s += block_threads<TB>() >> 6) {
       const int i = s * 64 + lane;
       const bool act = lane < glob(P.slice_real)[s];  // (idle padding at the end of a class is not a propagator)
       const int4 pr = props[i];
@@ -1886,7 +1899,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
 #endif
   if (tid == 0) {
     const long long t1 = wall_clock64();
-    bs.timers[TB_T_FIXPOINT] += t1 - t0;
+    bs.timers[TB_T_FIXPOINT] += t1 - sh.t_mark;
     sh.t_mark = t1;
     int leaf = failed ? 1 : 0, sol = 0;
     bool stream = false;
@@ -1953,10 +1966,12 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
   }
   __syncthreads();
   if (sh.sol) {  // uniform
-    for (int rep = reps_of(P, 8); rep > 1; --rep) copy_store(best_store, store, P.vext);
-    copy_store(best_store, store, P.vext);
+    // (the workgroup's slab of g_best is located here, where a solution is kept: not a pointer that lives through every round of every node)
+    if (best_store == nullptr) best_store = glob(P.g_best) + (size_t)here_s(blockIdx.x) * P.vext;
+    for (int rep = reps_of(P, 8); rep > 1; --rep) copy_store<TB>(best_store, store, P.vext);
+    copy_store<TB>(best_store, store, P.vext);
     __syncthreads();
-    if (sh.ticket >= 0) produce_solution(P, sh, store, mbox);
+    if (sh.ticket >= 0) produce_solution<TB>(P, sh, store, mbox);
   }
 }
 
@@ -1964,13 +1979,13 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
 // copy of each instead of one per call site, registers allocated for their own loops, and the persistent search loop keeps only
 // a handful of values alive across them.  (The sweeping kernels stay inlined: their problem description is a by-value kernel
 // argument, which a call would have to copy to memory.)
-template <int C, int MEM>
+template <int C, int MEM, int TB = 0>
 static __device__ TB_NODE_ATTR unsigned propagate_node_event(const DevProblem* Pp, unsigned sh_off, unsigned store_off, int2* gstore, unsigned props_off, const int4* gprops,
                                                       unsigned dirty_off, unsigned list_off, int2* best_store, Mailbox* mbox, unsigned writes) {
   BlockShared& sh = *lds_ptr<BlockShared>(sh_off);
   int2* store = MEM >= TB_MEM_STORE_SHARED ? lds_ptr<int2>(store_off) : glob(gstore);
   const int4* props = MEM == TB_MEM_TCN_SHARED ? lds_ptr<const int4>(props_off) : glob(gprops);
-  best_store = glob(best_store);
+  if (best_store != nullptr) best_store = glob(best_store);
   EventState es;
   es.dirty = lds_ptr<unsigned>(dirty_off); es.list = lds_ptr<int>(list_off);
   es.succ = glob(constant_problem(Pp).succ);  // (outlined variants keep the successor records in global memory)
@@ -1978,26 +1993,26 @@ static __device__ TB_NODE_ATTR unsigned propagate_node_event(const DevProblem* P
   es.words = constant_problem(Pp).dirty_words; es.cap = constant_problem(Pp).chg_cap;
   ThreadCounters tc;
   tc.writes = writes;
-  propagate_node_impl<true, C, false, MEM>(constant_problem(Pp), sh, store, props, es, best_store, glob(mbox), tc);
+  propagate_node_impl<true, C, false, MEM, TB>(constant_problem(Pp), sh, store, props, es, best_store, glob(mbox), tc);
   return tc.writes;
 }
-template <int C, bool SL>
+template <int C, bool SL, int TB = 0>
 static __device__ TB_SPLIT_ATTR void split_event(const DevProblem* Pp, unsigned sh_off, Decision* dec, unsigned store_off, const int2* gstore) {
-  split<C>(constant_problem(Pp), *lds_ptr<BlockShared>(sh_off), glob(dec), SL ? lds_ptr<const int2>(store_off) : glob(gstore));
+  split<C, TB>(constant_problem(Pp), *lds_ptr<BlockShared>(sh_off), glob(dec), SL ? lds_ptr<const int2>(store_off) : glob(gstore));
 }
 
-template <bool EVENT, int C, bool RM, int MEM>
+template <bool EVENT, int C, bool RM, int MEM, int TB = 0>
 __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
                                                int2* best_store, Mailbox* mbox, ThreadCounters& tc) {
   constexpr bool SL = MEM >= TB_MEM_STORE_SHARED, PL = MEM == TB_MEM_TCN_SHARED;
-  if constexpr (EVENT) tc.writes = propagate_node_event<C, MEM>(&P, lds_off(&sh), SL ? lds_off(store) : 0u, SL ? nullptr : store, PL ? lds_off(props) : 0u, PL ? nullptr : props,
+  if constexpr (EVENT) tc.writes = propagate_node_event<C, MEM, TB>(&P, lds_off(&sh), SL ? lds_off(store) : 0u, SL ? nullptr : store, PL ? lds_off(props) : 0u, PL ? nullptr : props,
                                                                 lds_off(es.dirty), lds_off(es.list), best_store, mbox, tc.writes);
-  else propagate_node_impl<EVENT, C, RM, MEM>(P, sh, store, props, es, best_store, mbox, tc);
+  else propagate_node_impl<EVENT, C, RM, MEM, TB>(P, sh, store, props, es, best_store, mbox, tc);
 }
-template <bool EVENT, int C, bool SL>
+template <bool EVENT, int C, bool SL, int TB = 0>
 __device__ __forceinline__ void split_node(const DevProblem& P, BlockShared& sh, Decision* dec, int2* store) {
-  if constexpr (EVENT) split_event<C, SL>(&P, lds_off(&sh), dec, SL ? lds_off(store) : 0u, SL ? nullptr : store);
-  else split<C>(P, sh, dec, store);
+  if constexpr (EVENT) split_event<C, SL, TB>(&P, lds_off(&sh), dec, SL ? lds_off(store) : 0u, SL ? nullptr : store);
+  else split<C, TB>(P, sh, dec, store);
 }
 
 // ---- the persistent search kernel ----------------------------------------------------------------
@@ -2031,7 +2046,9 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
   // dispatch does not reliably invalidate that cache (observed: stale per-slice words on a re-used address, 14 of 30 searches of
   // pat11 went wrong), so every wave drops it once, here.
   __builtin_amdgcn_s_dcache_inv();
-  const DevProblem& P = EVENT ? *problem : by_value;
+  // (the two-wave event kernels are only ever launched with exactly 128 threads: block_threads)
+  constexpr int TB = (EVENT && TMAX == 128) ? 128 : 0;
+  const DevProblem& P = EVENT ? constant_problem(problem) : by_value;  // (constant address space: every field is fetched with a scalar load where it is used)
   // OPT: event kernels -- the store layout (0 plain, 1 COMPACT, 2 COMPACT16); sweeps -- bit 0 entailed-slice removal, bits 1-2 the layout
   constexpr int C = EVENT ? OPT : (OPT >> 1);
   constexpr bool RM = !EVENT && (OPT & 1) != 0;
@@ -2052,18 +2069,19 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
   es.succ = glob(P.succ);
   if (MEM == TB_MEM_TCN_SHARED) {
     int4* lprops = reinterpret_cast<int4*>(smem + SH_BYTES + store_bytes + dirty_bytes);
-    for (int i = tid; i < P.n_slices * 64; i += blockDim.x) lprops[i] = glob(P.props)[i];  // whole slices: the array is padded
+    for (int i = tid; i < P.n_slices * 64; i += block_threads<TB>()) lprops[i] = glob(P.props)[i];  // whole slices: the array is padded
     props = lprops;
     if (EVENT) {  // the successor records too: a run then starts without a trip to L2
       int4* lsucc = lprops + (size_t)P.n_slices * 64;
-      for (int i = tid; i < P.n_slices * 64; i += blockDim.x) lsucc[i] = glob(P.succ)[i];
+      for (int i = tid; i < P.n_slices * 64; i += block_threads<TB>()) lsucc[i] = glob(P.succ)[i];
       es.succ = lsucc;
     }
   }
-  for (int i = tid; i < 2 * P.dirty_words; i += blockDim.x) es.dirty[i] = 0;
-  int2* snap = glob(P.g_snap) + (size_t)b * P.snapshot_levels * VX;
-  int2* best_store = glob(P.g_best) + (size_t)b * VX;
-  Decision* dec = glob(P.g_dec) + (size_t)b * P.max_depth;
+  for (int i = tid; i < 2 * P.dirty_words; i += block_threads<TB>()) es.dirty[i] = 0;
+  // This workgroup's slabs of the snapshot stack and of the decision stack are located where a node needs them (after its fixpoint), from an
+  // opaque copy of the workgroup index: as loop invariants they were hoisted to the top of the search and spilled for its whole duration.
+  auto snap_of = [&]() { return glob(P.g_snap) + (size_t)here_s(b) * P.snapshot_levels * P.vext; };
+  auto dec_of = [&]() { return glob(P.g_dec) + (size_t)here_s(b) * P.max_depth; };
   BlockStats& bs = sh.bs;
   ThreadCounters tc;
   if (tid == 0) {
@@ -2088,11 +2106,11 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
   // takes no snapshot, keeps no decision (the child is chosen by a bit of the subproblem index) and a leaf there skips the subtree.
   while (sh.has_work && !sh.stop) {
     // C. restore the root
-    copy_store(store, glob(P.root_store), VX);  // the root slab is laid out like a workgroup slab
+    copy_store<TB>(store, glob(P.root_store), VX);  // the root slab is laid out like a workgroup slab
     if (EVENT && tid == 0) { sh.ev_all = P.root_fixpoint ? 0 : 1; sh.chg_count[0] = 0; }  // a root that is not a fixpoint: every slice runs once
     if (RM && !P.root_fixpoint) {  // nothing is known to be entailed yet (the event fixpoint does this in its root pass)
       __syncthreads();
-      for (int s = tid; s < P.n_slices; s += blockDim.x) es.unent[s] = 1;
+      for (int s = tid; s < P.n_slices; s += block_threads<TB>()) es.unent[s] = 1;
     }
     if (tid == 0) {
       sh.cur_strategy = 0; sh.next_unassigned = 0; sh.depth = 0; sh.bot = 0;
@@ -2126,8 +2144,10 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
         if (sh.stop) break;
       }
       // II. propagate
-      propagate_node<EVENT, C, RM, MEM>(P, sh, store, props, es, best_store, mbox, tc);
+      propagate_node<EVENT, C, RM, MEM, TB>(P, sh, store, props, es, nullptr, mbox, tc);
       if (sh.stop) break;
+      int2* const snap = snap_of();
+      Decision* const dec = dec_of();
       // III. branch
       if (!sh.leaf) {
         const int d0 = sh.depth;
@@ -2135,13 +2155,13 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
         long long tp = 0;
         if (prof && tid == 0) tp = wall_clock64();
         if (!diving) {
-          if (d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * VX, store, VX);  // d0 == 0: barebones:785-791
-          if ((pk(P) & 0x4) && d0 < P.snapshot_levels) copy_store(snap + (size_t)d0 * VX, store, VX);  // tuning: cost of the snapshot
+          if (d0 < P.snapshot_levels) copy_store<TB>(snap + (size_t)d0 * VX, store, VX);  // d0 == 0: barebones:785-791
+          if ((pk(P) & 0x4) && d0 < P.snapshot_levels) copy_store<TB>(snap + (size_t)d0 * VX, store, VX);  // tuning: cost of the snapshot
           if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
           __syncthreads();
         }
         if (prof && tid == 0) { const long long t = wall_clock64(); bs.timers[TB_T_PREPROCESSING] += t - tp; tp = t; }  // profiling: snapshot push
-        split_node<EVENT, C, (MEM >= TB_MEM_STORE_SHARED)>(P, sh, dec, store);
+        split_node<EVENT, C, (MEM >= TB_MEM_STORE_SHARED), TB>(P, sh, dec, store);
         if (prof && tid == 0) bs.timers[TB_T_SELECT_FP_FUNCTIONS] += wall_clock64() - tp;  // profiling: variable selection
         if (sh.stop) break;
         if (tid == 0) {
@@ -2173,12 +2193,12 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
         const int depth = sh.new_depth;
         if (depth == -1) { exhausted = true; break; }
         const int lvl = (depth - 1) < (P.snapshot_levels - 1) ? (depth - 1) : (P.snapshot_levels - 1);
-        for (int rep = reps_of(P, 6); rep > 0; --rep) copy_store(store, snap + (size_t)lvl * VX, VX);
+        for (int rep = reps_of(P, 6); rep > 0; --rep) copy_store<TB>(store, snap + (size_t)lvl * VX, VX);
         if (tid == 0) { sh.bot = 0; sh.depth = depth; }
         __syncthreads();
         // re-apply decisions[lvl .. depth-2].current(): distinct decisions may hit the same variable, the
         // atomic min/max make the order irrelevant (the reference loops to a fixpoint, barebones:839-851)
-        for (int i = lvl + tid; i < depth - 1; i += blockDim.x) {
+        for (int i = lvl + tid; i < depth - 1; i += block_threads<TB>()) {
           const Decision& di = dec_at(P, sh, dec, i);
           const int2 ch = di.child[di.cur];
           raise_lb<C>(store, P.n_int, di.var, ch.x);
@@ -2216,7 +2236,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
     h.has_work = sh.has_work; h.nodes = (int)bs.nodes;
     glob(P.g_path_hdr)[b] = h;
   }
-  if (P.g_last != nullptr) copy_store(glob(P.g_last) + (size_t)b * VX, store, VX);  // test aid: the store this workgroup stopped on
+  if (P.g_last != nullptr) copy_store<TB>(glob(P.g_last) + (size_t)b * VX, store, VX);  // test aid: the store this workgroup stopped on
 
   // fold what is left of the per-lane write counters into the workgroup's statistics
   __syncthreads();

@@ -78,7 +78,9 @@ def run_linked(session, dist=None, period_s: float = 0.0002, max_seconds: float 
     session.arm()
     if dist is not None and dist.get_world_size() > 1:
         dist.barrier()
+    t_released = time.time()  # (one host: the ranks share this clock)
     session.start()
+    t_started = time.time()
     t0 = time.perf_counter()
     while True:
         _, done = session.poll()
@@ -88,6 +90,10 @@ def run_linked(session, dist=None, period_s: float = 0.0002, max_seconds: float 
             session.stop()
         time.sleep(period_s)
     out = session.finish()
+    # when this rank's kernel was launched (host clock) and how long the launch call took after the barrier released it: the ranks of a step
+    # start within the spread of these times, and a fixed node budget for the group is consumed by whoever runs
+    out[2]["host_start_time"] = t_started
+    out[2]["host_launch_latency_s"] = t_started - t_released
     if dist is not None and dist.get_world_size() > 1:
         dist.barrier()
     return out
