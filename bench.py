@@ -224,6 +224,7 @@ def main() -> int:
     ap.add_argument("--cutnodes", type=int, default=0, help="additionally cap every workgroup at this many nodes (the reference's -cutnodes)")
     ap.add_argument("--or-nodes", type=int, default=0, help="workgroups per GPU (0 = fill the GPU)")
     ap.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = the engine's choice)")
+    ap.add_argument("--subproblems-power", type=int, default=-1, help="2^d EPS subproblems (-1 = the reference's rule: 2^d >= 300 x workgroups x GPUs)")
     ap.add_argument("--side-steps", type=int, default=2, help="steps of each of the other fixpoints (wac1, ac1, event) timed beside the headline (0 = skip)")
     ap.add_argument("--other-steps", type=int, default=2,
                     help="steps of each of the OTHER BASELINE configurations (accap_a3, trains15, synthetic 100k x 500k) timed after the headline, N = 1 only (0 = skip)")
@@ -299,7 +300,8 @@ def main() -> int:
         linked = world > 1 and args.exchange == "peer"
         per_rank_budget = budget if (world == 1 or linked) else max(1, budget // world)  # unlinked ranks count on their own
         cfg = capi.make_config(fixpoint=FP_CODE[fixpoint], stop_after_n_nodes_total=per_rank_budget, stop_after_n_nodes=args.cutnodes,
-                               or_nodes=args.or_nodes, threads_per_block=args.threads, timeout_ms=600000, device=local_rank, rank=rank, world_size=world, debug=args.debug_bits)
+                               or_nodes=args.or_nodes, threads_per_block=args.threads, timeout_ms=600000, device=local_rank, rank=rank, world_size=world, debug=args.debug_bits,
+                               subproblems_power=args.subproblems_power)
         sess = capi.Session(tcn, cfg)  # inputs uploaded to HBM here, outside the timed region
         tdist.agree_on_plan(sess, dist, tdev)
         if linked:

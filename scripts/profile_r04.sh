@@ -1,0 +1,42 @@
+#!/bin/bash
+# usage (on the GPU box, through gpurun): scripts/profile_r04.sh [tag]
+# 1. kernel trace of the DEFAULT bench command (headline wordpress7_500 + side rows + other_workloads + cpu baseline + reference invocation);
+# 2. counter-only passes (no tracing domains, one counter set per pass) of the headline per fixpoint: two SQ sets, instruction cache, GRBM clock,
+#    FETCH_SIZE, WRITE_SIZE, L2 hit / miss -- `--reference-seconds 0 --other-steps 0`: no child process, one search kernel per pass;
+# 3. the same memory-side passes for the synthetic 100k x 500k network (configs[4]: store in global memory), wac1 and event, stores inside
+#    the Infinity Cache (256 x 1024 threads) and beyond it (256-thread workgroups);
+# 4. scripts/summarize_r04.py -> profiles/<tag>_kernel_stats.txt, profiles/<tag>_counters.json.
+tag=${1:-r04}
+root=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd $root
+out=gpurun_out/prof_$tag
+rm -rf $out && mkdir -p $out
+rocprofv3 --kernel-trace --stats -d $out/trace -o t -- python3 bench.py > $out/bench_traced.log 2> $out/bench_traced.err
+pass() {  # pass <dir> <counters...> -- <bench args>
+  d=$1; shift; c=""
+  while [ "$1" != "--" ]; do c="$c $1"; shift; done; shift
+  rocprofv3 --pmc $c -d $out/$d -o p -- python3 bench.py "$@" > $out/$d.log 2>&1
+}
+for fp in event wac1; do
+  args="--steps 2 --warmup 1 --side-steps 0 --other-steps 0 --reference-seconds 0 --no-cpu-baseline --fixpoint $fp"
+  pass ${fp}_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU -- $args
+  pass ${fp}_sq2 SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_WAIT_INST_LDS -- $args
+  pass ${fp}_icache SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE -- $args
+  pass ${fp}_grbm GRBM_GUI_ACTIVE -- $args
+  pass ${fp}_fetch FETCH_SIZE -- $args
+  pass ${fp}_write WRITE_SIZE -- $args
+  pass ${fp}_tcc TCC_HIT_sum TCC_MISS_sum -- $args
+done
+i=0
+for cfg in "wac1 0" "event 0" "wac1 256"; do
+  set -- $cfg
+  i=$((i+1))
+  args="--workload synthetic --fixpoint $1 --threads $2 --steps 2 --warmup 1 --side-steps 0 --other-steps 0 --reference-seconds 0 --no-cpu-baseline"
+  python3 bench.py $args > $out/syn${i}_plain.log 2>&1
+  pass syn${i}_fetch FETCH_SIZE -- $args
+  pass syn${i}_write WRITE_SIZE -- $args
+  pass syn${i}_tcc TCC_HIT_sum TCC_MISS_sum -- $args
+  pass syn${i}_ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -- $args
+done
+python3 scripts/summarize_r04.py $tag $out
+mkdir -p gpurun_out/profiles_$tag && cp profiles/${tag}_kernel_stats.txt profiles/${tag}_counters.json gpurun_out/profiles_$tag/

@@ -342,6 +342,26 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert all(r["nodes"] > 0 for r in rec["multi_gpu"]["per_rank"])
 
 
+def test_bench_two_ranks_complete_subproblems_and_steal_inside_a_step():
+    """The N > 1 bench path where the queues matter: on the headline instance and on trains15 no workgroup ever finishes a
+    subproblem inside a step (measured: 0 solved in 3 M nodes at 2^10 .. 2^16 subproblems), so those steps never touch the work queue after the first
+    fetch.  accap_a3 at 2^12 subproblems does: most of its subproblems are a few hundred nodes, the shares of 2048 run out within the step, and the rank
+    whose queue is empty first takes work from the other one's (stolen > 0); no subproblem is counted twice.  Both ranks on cuda:0, gloo rendezvous."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--share-device", "--dist-backend", "gloo",
+           "--workload", "accap_a3", "--or-nodes", "128", "--subproblems-power", "12", "--nodes-total", "40000000", "--no-cpu-baseline", "--side-steps", "0", "--other-steps", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    m = rec["multi_gpu"]
+    assert m["exchange"] == "peer cells over xGMI"
+    assert 0 < m["eps_solved_per_step"] + m["eps_skipped_per_step"] <= 4096, m  # (every subproblem at most once, whichever rank took it)
+    assert m["eps_solved_per_step"] > 0 and m["stolen_per_step"] > 0, m
+    assert sum(r["stolen_subproblems"] for r in m["per_rank"]) == m["stolen_per_step"]
+    assert m["start_skew_ms_max"] is not None and m["nodes_per_sec_sum_over_kernel_time"] > 0
+    assert all(r["nodes"] > 0 and r["eps_solved"] > 0 for r in m["per_rank"])
+
+
 def test_bench_refuses_to_report_fewer_gpus_than_asked():
     """Two ranks on a one-GPU box without --share-device: rank 1 has no device, the run fails -- it never prints n_gpus != --gpus."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}

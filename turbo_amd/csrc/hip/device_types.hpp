@@ -6,6 +6,12 @@
 
 #include "../../../include/turbo_hip.h"
 
+#ifdef TB_TUNING
+#define TB_DBG_WORDS 32
+#else
+#define TB_DBG_WORDS 4
+#endif
+
 namespace tb {
 
 // lala LightBranch (barebones_dive_and_solve.hpp:135,355-393): one entry of the decision stack.
@@ -117,7 +123,8 @@ struct BlockStats {
   int depth_max, exhaustive, num_blocks_done, best_bound;
   long long best_sub;               // subproblem index that produced best_store (-1: none)
   int why, pad_why;                 // debugging: reasons that cleared `exhaustive` (bit mask)
-  int dbg[32];                      // tuning build: first violation found by the self-check of the event fixpoint
+  int dbg[TB_DBG_WORDS];            // tuning build: census of the event fixpoint / first violation found by its self-check (production keeps 4 words: the
+                                    // block sits in every workgroup's LDS, where 1280-byte granules decide how many workgroups a CU holds)
 };
 
 // Test aid (tb_config.reserved[0] & 0x800000, tb_session_debug_path): where a workgroup stood when it left the kernel.

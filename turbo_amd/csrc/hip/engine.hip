@@ -91,6 +91,7 @@ struct LaunchPlan {
 // behind the Booleans and takes no room in the slab at all: the records that read it carry its VALUE in the operand field (sign bit set,
 // kernels.hpp: load_dom), the strategy lists skip it, decode_slab puts it back.  Narrowing a constant is a failure; whoever tries raises the flag.
 struct Layout {
+  bool renumbered = false;  // plain layout under a locality permutation (renumber_for_locality: an experiment, TB_GLOBAL_RENUMBER)
   bool compact = false;
   bool c16 = false;  // COMPACT16: the non-Boolean variables as two 16-bit bounds in one word (kernels.hpp: load_dom<2>)
   int n_vars = 0, n_int = 0, n_bool = 0;
@@ -184,7 +185,29 @@ void decode_slab(const Layout& L, const unsigned char* slab, tb_itv* orig_out) {
   }
 }
 
+// Experiment for stores in global memory ("renumber the variables so that a slice's gathers fall in fewer 64-byte lines"):
+// breadth-first order over the variable / propagator graph in the caller's propagator order -- the operands of consecutive propagators get
+// neighbouring ids, eight intervals to a line.  Plain layout only; off unless TB_GLOBAL_RENUMBER is set (measured r04 on the synthetic 100k x 500k
+// network, whose operands are uniform random: see DESIGN.md section 7).
+void renumber_for_locality(Layout* L, int32_t n_props, const tb_prop* props) {
+  const int V = L->n_vars;
+  std::vector<int> order((size_t)V, -1);
+  int next = 0;
+  for (int32_t i = 0; i < n_props; ++i)
+    for (int v : {props[i].x, props[i].y, props[i].z})
+      if (order[(size_t)v] < 0) order[(size_t)v] = next++;
+  for (int v = 0; v < V; ++v) if (order[(size_t)v] < 0) order[(size_t)v] = next++;
+  L->perm = order;
+  for (int v = 0; v < V; ++v) L->inv[(size_t)order[(size_t)v]] = v;
+  L->renumbered = true;
+}
+
 inline size_t align16(size_t x) { return (x + 15) / 16 * 16; }
+// LDS is handed out in granules of 320 dwords on gfx950 (160 KiB / 128): a workgroup asking for 12 336 B occupies 12 800 B, and 12 -- not 13 -- of
+// them share a CU, whatever hipOccupancyMaxActiveBlocksPerMultiprocessor answers.  Measured r04 (wordpress7_500, 128-thread event workgroups): 12 336 B
+// and 11 568 B per workgroup run at 4.27e7 and 4.35e7 nodes/s, 11 504 B (nine granules: 14 workgroups per CU) at 4.64e7.
+constexpr size_t LDS_GRANULE = 1280;
+inline size_t lds_footprint(size_t bytes) { return (bytes + LDS_GRANULE - 1) / LDS_GRANULE * LDS_GRANULE; }
 
 // Which memory holds what (the MemoryKind decision of memory_gpu.hpp:56-83 with CDNA4 numbers:
 // 160 KiB of LDS per CU, wave64, at most 32 waves per CU) and how many workgroups to launch
@@ -204,7 +227,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     // A store that leaves room for a single workgroup per CU: make that workgroup wide enough to fill the CU's 16 wave
     // slots (trains15 simplified, 87 KB store: 4.9e6 -> 7.3e6 nodes/s going from 512 to 1024 threads).
     const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64, event) * 8) + dirty_region_bytes(((n_props + 63) / 64 + 31) / 32) + 4096 + SH_BYTES;
-    while (T < 1024 && slab <= (size_t)caps.lds_per_cu && std::min<size_t>((size_t)caps.lds_per_cu / slab, (size_t)(2048 / T)) * (size_t)(T / 64) < 16) T *= 2;
+    while (T < 1024 && slab <= (size_t)caps.lds_per_cu && std::min<size_t>((size_t)caps.lds_per_cu / lds_footprint(slab), (size_t)(2048 / T)) * (size_t)(T / 64) < 16) T *= 2;
   }
   bool small_wg = false;
   if (auto_threads && T == 256 && !cfg.only_global_memory && (event || n_props < 2048)) {
@@ -212,8 +235,9 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     // slabs fit in LDS, workgroups of two waves beat 7 of four -- accap_a3, 14 per CU: 4.5e7 -> 7.0e7 nodes/s (event), 3.1e7 -> 5.3e7 (wac1);
     // wordpress7_500 with its constants out of the slab (Layout), same box: 7 x 256 threads 3.38e7, 8 x 128 3.22e7, 10 x 128 3.71e7,
     // 12 x 128 3.95e7.  trains15 (6 slabs fit) keeps its four waves.
-    const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64, event) * 8) + dirty_region_bytes(((n_props + 63) / 64 + 31) / 32) + align16(256 * 4) + SH_BYTES;
-    if (slab * 10 <= (size_t)caps.lds_per_cu) { T = 128; small_wg = true; }
+    // (with the shortest change list the planner may pick, see below)
+    const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64, event) * 8) + dirty_region_bytes(((n_props + 63) / 64 + 31) / 32) + align16(32 * 4) + SH_BYTES;
+    if (lds_footprint(slab) * 10 <= (size_t)caps.lds_per_cu) { T = 128; small_wg = true; }
   }
   if (T != 64 && T != 128 && T != 256 && T != 512 && T != 1024) return fail(TB_ERR_INVALID, "threads_per_block must be 64, 128, 256, 512 or 1024");
   p.threads = T;
@@ -232,29 +256,43 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   // (256 entries: a node is entered with a handful of changed variables -- the decision, the objective bound, the decisions replayed
   //  above the deepest snapshot; a longer list only costs LDS that a sixth workgroup per CU can use, trains15)
   p.chg_cap = std::min(256, std::max(64, n_vars / 4));
+  const size_t fixed = SH_BYTES;
+  int bpc_max = std::min(cfg.reserved[2] > 0 ? cfg.reserved[2] : (small_wg ? 16 : 8), 2048 / T);  // 32 waves per CU (reserved[2]: tuning knob)
+  if (bpc_max < 1) bpc_max = 1;
+  if (event && !cfg.only_global_memory) {
+    // The change list is the one elastic part of an event workgroup's LDS: a node is entered with a handful of changed variables (the decision,
+    // the objective bound, the decisions replayed above the deepest snapshot), and an overflowing list only costs that node a pass over every
+    // slice.  So its capacity (256 entries by default) gives way, down to 32 entries, when that puts one more workgroup on a CU -- LDS comes in
+    // granules (lds_footprint), and what the registers allow is 7 waves per SIMD for both event kernels: wordpress7_500 12 -> 14 workgroups per CU
+    // (+8.7 % nodes/s), trains15 6 -> 7 (+4.7 %).
+    const size_t base = fixed + align16((size_t)vext * 8) + dirty_region_bytes(dirty_words);
+    const int reg_cap = std::max(1, 28 / std::max(1, T / 64));
+    auto per_cu = [&](int cap) { return std::min<int>({bpc_max, reg_cap, (int)((size_t)caps.lds_per_cu / lds_footprint(base + align16((size_t)cap * 4)))}); };
+    int best_cap = p.chg_cap;
+    for (int cap : {192, 128, 96, 64, 48, 32})
+      if (cap < best_cap && per_cu(cap) > per_cu(best_cap)) best_cap = cap;
+    p.chg_cap = best_cap;
+  }
   if (cfg.reserved[1] > 0) p.chg_cap = cfg.reserved[1];  // tuning knob
   const size_t dirty_b = dirty_region_bytes(dirty_words) + align16((size_t)p.chg_cap * 4);
   // (event mode keeps the successor records next to the bytecodes: 32 bytes per propagator)
   const size_t store_b = align16((size_t)vext * 8) + dirty_b, props_b = (size_t)n_slices * 64 * (event ? 32 : 16);  // padded to whole slices
-  const size_t fixed = SH_BYTES;
-  int bpc_max = std::min(cfg.reserved[2] > 0 ? cfg.reserved[2] : (small_wg ? 16 : 8), 2048 / T);  // 32 waves per CU (reserved[2]: tuning knob)
-  if (bpc_max < 1) bpc_max = 1;
   if (cfg.only_global_memory) {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
-  } else if (!event && !lay.compact && (fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
+  } else if (!event && !lay.compact && lds_footprint(fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
     // (records in LDS: the plain sweeps on small networks only.  The event kernels and the compact layouts have no such instantiation:
     //  their records come out of L2 fast enough, see below, and a third memory kind for them is a quarter of the library's compile time.)
     p.mem_kind = TB_MEM_TCN_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b + props_b);
   // (event mode, measured on accap_a3: the records in LDS at the price of 3 workgroups per CU instead of 7 -- 1.39e7 against 4.50e7 nodes/s.
   //  The records come out of L2 fast enough; what a CU needs is subproblems in flight.)
-  } else if ((fixed + store_b) * (size_t)bpc_max <= lds) {
+  } else if (lds_footprint(fixed + store_b) * (size_t)bpc_max <= lds) {
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b);
-  } else if (fixed + store_b <= lds && !(event && (int)(lds / (fixed + store_b)) < 4 && !(cfg.reserved[0] & 0x40000))) {
+  } else if (fixed + store_b <= lds && !(event && (int)(lds / lds_footprint(fixed + store_b)) < 4 && !(cfg.reserved[0] & 0x40000))) {
     // (event mode: a store that leaves fewer than 4 workgroups per CU goes to global memory instead: what a CU needs is
     //  subproblems in flight -- trains15, compact slab of 50 KB: 1.77e7 nodes/s with 3 workgroups per CU in LDS, 2.04e7 with 7
     //  working on slabs in global memory (L2 / Infinity Cache resident); wordpress7_500 r02: 1.2-1.5x.  choose_layout first tries
     //  the COMPACT layout, which usually brings the store back into LDS)
-    p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / (fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
+    p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / lds_footprint(fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
   } else {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
   }
@@ -1227,6 +1265,8 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     // add tail latency; re-plan so that the subproblem count follows the real workgroup count
     int occ = 0;
     if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->plan.kernel_event != 0, s->plan.kernel_opt, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
+    // (the occupancy query does not round the LDS request up to its allocation granule: 13 workgroups of 12 336 B "fit" a CU that holds 12)
+    if (s->plan.shared_bytes > 0) occ = std::min<int>(occ > 0 ? occ : 1 << 20, (int)((size_t)s->caps.lds_per_cu / lds_footprint((size_t)s->plan.shared_bytes)));
     if (occ > 0 && (long long)occ * s->caps.cus < (long long)s->plan.num_blocks) {
       tb_config capped = s->cfg;
       capped.or_nodes = (uint64_t)occ * (uint64_t)s->caps.cus;
@@ -1238,6 +1278,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
       if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->plan.kernel_event != 0, s->plan.kernel_opt, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     }
   }
+  if (s->plan.mem_kind == TB_MEM_GLOBAL && !s->lay.compact && n_rec == n_props && std::getenv("TB_GLOBAL_RENUMBER") != nullptr) renumber_for_locality(&s->lay, n_props, props);
   const LaunchPlan& plan = s->plan;
   const Layout& lay = s->lay;
   DevProblem& P = s->P;
@@ -1251,7 +1292,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     i_off[(size_t)k] = (int32_t)i_vars.size();
     // (a constant kept out of the slab keeps its position in the list -- positions break ties -- as -1: assigned, never a candidate)
     auto entry = [&](int32_t v) { const int i = lay.perm[(size_t)v]; return i >= lay.n_slab() ? -1 : i; };
-    if (strat_off[k] == strat_off[k + 1] && lay.compact) for (int32_t v = 0; v < n_vars; ++v) i_vars.push_back(entry(v));
+    if (strat_off[k] == strat_off[k + 1] && (lay.compact || lay.renumbered)) for (int32_t v = 0; v < n_vars; ++v) i_vars.push_back(entry(v));
     else for (int32_t j = strat_off[k]; j < strat_off[k + 1]; ++j) i_vars.push_back(entry(strat_vars[j]));
   }
   i_off[(size_t)n_strats] = (int32_t)i_vars.size();
@@ -1715,9 +1756,11 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
     st.exhaustive = st.exhaustive && x.exhaustive;
     st.reserved[0] |= x.why;
     if (st.reserved[1] == 0) st.reserved[1] = x.pad_why;
+#ifdef TB_TUNING
     if ((x.why & 0x300) && x.dbg[1] != 0 && s->cfg.verbose)
       std::fprintf(stderr, "%% self-check: workgroup %zu node %d slice %d lane %d word0 %#x x=%d [%d,%d] y=%d [%d,%d] z=%d [%d,%d]\n", b, x.dbg[11], x.pad_why - 1, x.dbg[0],
                    (unsigned)x.dbg[1], x.dbg[2], x.dbg[5], x.dbg[6], x.dbg[3], x.dbg[7], x.dbg[8], x.dbg[4], x.dbg[9], x.dbg[10]);
+#endif
     for (int t = 0; t < TB_NUM_TIMERS; ++t)
       if (t != TB_T_FIRST_BLOCK_IDLE && t != TB_T_LATEST_BEST_OBJ_FOUND) st.timers_ns[t] += (int64_t)((double)x.timers[t] * ns_per_tick);
     st.cumulative_time_block_ns += (int64_t)((double)x.timers[TB_T_FIRST_BLOCK_IDLE] * ns_per_tick);

@@ -19,7 +19,7 @@
 // Build-time variants of the 256-thread event kernel (experiments): waves per SIMD the register allocator is asked for,
 // software prefetch of the next slice's records (a loss below 5 waves' worth of registers: the prefetched records spill).
 #ifndef TB_EVENT_WAVES_256
-#define TB_EVENT_WAVES_256 6
+#define TB_EVENT_WAVES_256 7  // (r03: 6 -- trains15's slab then left room for six workgroups per CU whatever the registers; with the change list trimmed to the LDS granule, seven fit: +4.7 %)
 #endif
 #ifndef TB_EVENT_WAVES
 #define TB_EVENT_WAVES 7
@@ -2090,7 +2090,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
     bs.eps_solved = bs.eps_skipped = bs.store_writes = bs.stolen = bs.active_evals = 0;
     bs.wait_ticks = 0;
     bs.why = 0; bs.pad_why = 0;
-    for (int i = 0; i < 32; ++i) bs.dbg[i] = 0;
+    for (int i = 0; i < TB_DBG_WORDS; ++i) bs.dbg[i] = 0;
     bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
     sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0;
     sh.n_dec_seg = 0;
