@@ -205,7 +205,8 @@ typedef struct {
   int32_t num_blocks, threads_per_block, mem_kind, shared_bytes, subproblems_power, eps_chunk_log2, snapshot_levels, decision_stack_depth;
   uint64_t eps_local_subproblems;
   int32_t kernel_event, kernel_opt; /* which kernel start() launches: event-driven fixpoint or sweeps; its option flag (event: 0 plain store,
-                                     * 1 COMPACT, 2 COMPACT16; sweeps: 0 plain, 1 entailed-slice removal, 2 COMPACT, 4 COMPACT16) */
+                                     * 1 COMPACT, 2 COMPACT16, 3 plain store in global memory with its most-read intervals in LDS; sweeps: 0 plain,
+                                     * 1 entailed-slice removal, 2 COMPACT, 4 COMPACT16, 6 the hot tier) */
 } tb_plan;
 int tb_session_plan(tb_session* s, tb_plan* plan_out);
 /*

@@ -119,9 +119,10 @@ for fp in ("event", "wac1"):
                               "register spills (scratch); WRITE_SIZE is not calibrated"})
     rec[f"wordpress7_500/{fp}"] = r
 
-for i, (fp, what) in enumerate((("wac1", "256 workgroups x 1024 threads: the stores (205 MB) inside the Infinity Cache"),
-                                ("event", "256 workgroups x 1024 threads, event fixpoint"),
-                                ("wac1", "256-thread workgroups: > 1 GB of stores, beyond the Infinity Cache")), 1):
+for i, (fp, what) in enumerate((("wac1", "256 workgroups x 1024 threads, hot tier (19 456 most-read intervals in LDS): the stores (205 MB) inside the Infinity Cache"),
+                                ("event", "256 workgroups x 1024 threads, hot tier, event fixpoint"),
+                                ("wac1", "256-thread workgroups (no hot tier): > 1 GB of stores, beyond the Infinity Cache"),
+                                ("wac1", "256 workgroups x 1024 threads WITHOUT the hot tier (TB_NO_HOT_TIER: r03's configuration)")), 1):
     b = bench_line(f"syn{i}_plain.log")
     if not b:
         continue
@@ -151,7 +152,7 @@ for i, (fp, what) in enumerate((("wac1", "256 workgroups x 1024 threads: the sto
         if pe:
             r["ea_read_requests_per_propagation"] = ea["TCC_EA0_RDREQ_sum"] / pe
             r["ea_read_requests_32B_share"] = ea.get("TCC_EA0_RDREQ_32B_sum", 0.0) / max(1.0, ea["TCC_EA0_RDREQ_sum"])
-    key = "synthetic/" + fp + ("" if i < 3 else "_beyond_mall")
+    key = "synthetic/" + fp + ("" if i < 3 else ("_beyond_mall" if i == 3 else "_no_hot_tier"))
     rec[key] = r
 json.dump(rec, open(os.path.join(prof, f"{tag}_counters.json"), "w"), indent=1)
 print(json.dumps({k: {a: b for a, b in v.items() if a != "counters"} if isinstance(v, dict) else v for k, v in rec.items()}, indent=1))

@@ -68,6 +68,7 @@ int query_caps(int device, DeviceCaps* caps) {
 
 // ---- launch planning -----------------------------------------------------------------------------
 
+constexpr int HOT_EVENT_OPT = 3, HOT_SWEEP_OPT = 6;  // kernel_opt of a plan with the hot tier (event: the layout; sweeps: layout << 1)
 struct LaunchPlan {
   int threads = 256, tmax = 256;
   int blocks_per_cu = 1, num_blocks = 1;
@@ -79,6 +80,8 @@ struct LaunchPlan {
   int n_slices = 0, dirty_words = 0, vext = 0, chg_cap = 64;
   int kernel_event = 0, kernel_opt = 0;  // template flags of the kernels this plan launches (solve and root propagation alike)
   int compact = 0, n_int = 0, unent_off = 0;  // store layout (Layout below)
+  bool hot = false;  // store in global memory with its first HOT_VARS intervals in LDS (kernels.hpp: layout 3); the search kernel only
+  int prop_opt() const { return hot ? 0 : kernel_opt; }  // template flag of the batch-propagation kernel on the same slabs (the plain layout)
 };
 
 // Store layout of a session.  COMPACT: the variables whose root domain lies within 0..1 are renumbered behind the
@@ -202,6 +205,18 @@ void renumber_for_locality(Layout* L, int32_t n_props, const tb_prop* props) {
   L->renumbered = true;
 }
 
+// Hot tier of a store in global memory (kernels.hpp: layout 3): the variables are numbered by how many propagator operands read them, most read
+// first, so that the HOT_VARS intervals that live in LDS are the ones gathered most often (ties keep the caller's order).
+void renumber_by_reads(Layout* L, int32_t n_props, const tb_prop* props) {
+  const int V = L->n_vars;
+  std::vector<int> reads((size_t)V, 0), order((size_t)V);
+  for (int32_t i = 0; i < n_props; ++i) { reads[(size_t)props[i].x]++; reads[(size_t)props[i].y]++; reads[(size_t)props[i].z]++; }
+  for (int v = 0; v < V; ++v) order[(size_t)v] = v;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return reads[(size_t)a] > reads[(size_t)b]; });
+  for (int i = 0; i < V; ++i) { L->perm[(size_t)order[(size_t)i]] = i; L->inv[(size_t)i] = order[(size_t)i]; }
+  L->renumbered = true;
+}
+
 inline size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 // LDS is handed out in granules of 320 dwords on gfx950 (160 KiB / 128): a workgroup asking for 12 336 B occupies 12 800 B, and 12 -- not 13 -- of
 // them share a CU, whatever hipOccupancyMaxActiveBlocksPerMultiprocessor answers.  Measured r04 (wordpress7_500, 128-thread event workgroups): 12 336 B
@@ -277,8 +292,15 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   const size_t dirty_b = dirty_region_bytes(dirty_words) + align16((size_t)p.chg_cap * 4);
   // (event mode keeps the successor records next to the bytecodes: 32 bytes per propagator)
   const size_t store_b = align16((size_t)vext * 8) + dirty_b, props_b = (size_t)n_slices * 64 * (event ? 32 : 16);  // padded to whole slices
+  // Hot tier (r04): a plain store in global memory, 1024-thread workgroups (one per CU, whose LDS would otherwise hold a few KB of bitmaps): the first
+  // HOT_VARS intervals live in LDS.  (TB_NO_HOT_TIER: A/B runs.)
+  auto hot_tier = [&]() {
+    if (lay.compact || T != 1024 || n_vars <= HOT_VARS || cfg.entailed_prop_removal || std::getenv("TB_NO_HOT_TIER") != nullptr) return false;
+    return fixed + (size_t)HOT_VARS * 8 + dirty_b <= lds;
+  };
   if (cfg.only_global_memory) {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
+    if (hot_tier()) { p.hot = true; p.blocks_per_cu = 1; p.shared_bytes = (int)(fixed + (size_t)HOT_VARS * 8 + dirty_b); }
   } else if (!event && !lay.compact && lds_footprint(fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
     // (records in LDS: the plain sweeps on small networks only.  The event kernels and the compact layouts have no such instantiation:
     //  their records come out of L2 fast enough, see below, and a third memory kind for them is a quarter of the library's compile time.)
@@ -295,6 +317,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / lds_footprint(fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
   } else {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
+    if (hot_tier()) { p.hot = true; p.blocks_per_cu = 1; p.shared_bytes = (int)(fixed + (size_t)HOT_VARS * 8 + dirty_b); }
   }
   long long blocks = (long long)p.blocks_per_cu * caps.cus;
   if (cfg.or_nodes != 0) blocks = std::min<long long>(blocks, (long long)cfg.or_nodes);
@@ -330,7 +353,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   p.snapshot_levels = std::max(1, std::min(L, p.max_depth));
   p.kernel_event = event ? 1 : 0;
   // sweeps: entailed-slice removal (bit 0) or a compact layout (2: COMPACT, 4: COMPACT16) -- not both, to keep the number of kernels down
-  p.kernel_opt = event ? p.compact : (cfg.entailed_prop_removal != 0 ? 1 : p.compact * 2);
+  p.kernel_opt = p.hot ? (event ? HOT_EVENT_OPT : HOT_SWEEP_OPT) : (event ? p.compact : (cfg.entailed_prop_removal != 0 ? 1 : p.compact * 2));
   *plan = p;
   return TB_OK;
 }
@@ -791,7 +814,9 @@ int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
 // DISPATCH_KERNEL adds the 128-thread event instantiations of the search kernel.
 #define DISPATCH_KERNEL(FN, mem, tmax, event, opt, ...)                                 \
   do {                                                                                  \
-    if ((tmax) == 128) {                                                                \
+    if ((opt) == HOT_EVENT_OPT && (event)) FN<TB_MEM_GLOBAL, 1024, true, 3> __VA_ARGS__;    /* hot tier (kernels.hpp: layout 3): 1024 threads, GLOBAL only */ \
+    else if ((opt) == HOT_SWEEP_OPT && !(event)) FN<TB_MEM_GLOBAL, 1024, false, 6> __VA_ARGS__; \
+    else if ((tmax) == 128) {                                                                \
       const int dk_mem = (mem), dk_opt = (opt);                                         \
       if (dk_opt == 2) DISPATCH_MEM(FN, 128, true, 2, dk_mem, __VA_ARGS__);             \
       else if (dk_opt) DISPATCH_MEM(FN, 128, true, 1, dk_mem, __VA_ARGS__);             \
@@ -1189,7 +1214,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   P.fixpoint = cfg.fixpoint; P.wac1_threshold = (int)std::min<uint64_t>(cfg.wac1_threshold, 0x7fffffffu);
   P.mem_kind = plan.mem_kind; P.debug = cfg.reserved[0];
   const bool event = cfg.fixpoint == 2;
-  const int compact = plan.kernel_opt;  // the kernels' fourth template flag
+  const int compact = plan.prop_opt();  // the batch kernel's fourth template flag
   {
     int occ = 0;
     if ((rc = prepare_kernel(false, plan.mem_kind, plan.tmax, event, compact, plan.shared_bytes, plan.threads, &occ)) != TB_OK) return rc;
@@ -1278,7 +1303,8 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
       if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->plan.kernel_event != 0, s->plan.kernel_opt, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     }
   }
-  if (s->plan.mem_kind == TB_MEM_GLOBAL && !s->lay.compact && n_rec == n_props && std::getenv("TB_GLOBAL_RENUMBER") != nullptr) renumber_for_locality(&s->lay, n_props, props);
+  if (s->plan.hot) renumber_by_reads(&s->lay, n_props, props);
+  else if (s->plan.mem_kind == TB_MEM_GLOBAL && !s->lay.compact && n_rec == n_props && std::getenv("TB_GLOBAL_RENUMBER") != nullptr) renumber_for_locality(&s->lay, n_props, props);
   const LaunchPlan& plan = s->plan;
   const Layout& lay = s->lay;
   DevProblem& P = s->P;
@@ -1419,7 +1445,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   // The node is still visited and counted; it just finds nothing left to do.  (tb_config.reserved[0] & 0x2000000 keeps the
   // caller's store, for A/B runs.)  An inconsistent root is left as it is: every subproblem then fails on its first node.
   if (n_props > 0 && !(s->cfg.reserved[0] & 0x2000000)) {
-    const bool event = s->plan.kernel_event != 0; const int opt = s->plan.kernel_opt;
+    const bool event = s->plan.kernel_event != 0; const int opt = s->plan.prop_opt();
     int occ = 0;
     if ((rc = prepare_kernel(false, plan.mem_kind, plan.tmax, event, opt, plan.shared_bytes, plan.threads, &occ)) != TB_OK) return rc;
     PropagateOut* d_out = nullptr;

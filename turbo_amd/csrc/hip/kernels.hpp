@@ -104,6 +104,8 @@ struct alignas(16) BlockShared {
   BlockStats bs;  // written by thread 0 only
 };
 
+constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 15) / 16 * 16);
+
 __device__ __forceinline__ bool dead_node(const BlockShared& sh) {
   static_assert(offsetof(BlockShared, abort) == offsetof(BlockShared, bot) + 4 && offsetof(BlockShared, bot) % 8 == 0, "bot and abort are read as one 8-byte word");
   return __hip_atomic_load(reinterpret_cast<const long long*>(&sh.bot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0ll;
@@ -194,9 +196,27 @@ __device__ __forceinline__ void st(int* p, int v) { __hip_atomic_store(p, v, TB_
 //                 root domain within -32768..32767: half the bytes per integer, twice the workgroups per CU for a network like trains15
 // A 16-bit bound cannot be narrowed with one 32-bit atomic max / min (the other half shares the word), so COMPACT16 narrows with a
 // compare-and-swap loop; narrowings are two orders of magnitude rarer than reads.
+//   3  HOT        the PLAIN layout of a store in global memory whose first HOT_VARS intervals live in LDS instead (r04; the 1024-thread kernels of
+//                 networks too large for LDS, e.g. the synthetic 100k x 500k one: a store of 800 KB per workgroup is gathered at random -- three of four
+//                 gathers miss the XCD's L2 and each moves a 64-byte line for 8 useful bytes -- while the 160 KB of LDS of its CU sit idle).  The host
+//                 numbers the most-read variables first (engine.hip: renumber_by_reads); an access picks its address space per lane and goes out as one
+//                 FLAT instruction (the hardware routes each lane by aperture).  The slab in global memory keeps room for all variables: block copies
+//                 (snapshots, best store) gather the hot part from LDS.
+constexpr int HOT_VARS = 19456;  // 152 KB of intervals, right behind the control block (with the bitmaps and the change list: 159 KB of the 160)
+template <class T>
+__device__ __forceinline__ T* hot_or_cold(T* cold, int v) {  // (generic pointers on both sides: a flat access)
+  T* hot = const_cast<T*>(reinterpret_cast<const T*>(lds_ptr<int2>((unsigned)SH_BYTES) + v));
+  return v < HOT_VARS ? hot : cold;
+}
 template <int C>
 __device__ __forceinline__ Itv load_int(const int2* store, int v) {  // an integer (non-Boolean) variable of the layout
   Itv d;
+  if (C == 3) {
+    const long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(hot_or_cold(store + v, v)), TB_RLX, TB_WG);
+    d.lb = (int)(raw & 0xffffffffll);
+    d.ub = (int)(raw >> 32);
+    return d;
+  }
   if (C == 2) {
     const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + v, TB_RLX, TB_WG);
     d.lb = (int)(short)(w & 0xffffu);
@@ -221,6 +241,7 @@ __device__ __forceinline__ int field_value(int v) { return (int)((unsigned)v << 
 template <int C>
 __device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v) {
   if (C == 0) return load_int<0>(store, v);
+  if (C == 3) return load_int<3>(store, v);
   const bool isk = v < 0;
   const int kv = field_value(v);
   if (C == 2) {
@@ -269,15 +290,18 @@ __device__ __forceinline__ void cas_lower_ub16(unsigned* w, int val) {
 template <int C>
 __device__ __forceinline__ void raise_int_lb(int2* store, int v, int val) {
   if (C == 2) { cas_raise_lb16(reinterpret_cast<unsigned*>(store) + v, val); return; }
+  if (C == 3) { (void)__hip_atomic_fetch_max(&hot_or_cold(store + v, v)->x, val, TB_RLX, TB_WG); return; }
   (void)__hip_atomic_fetch_max(&store[v].x, val, TB_RLX, TB_WG);
 }
 template <int C>
 __device__ __forceinline__ void lower_int_ub(int2* store, int v, int val) {
   if (C == 2) { cas_lower_ub16(reinterpret_cast<unsigned*>(store) + v, val); return; }
+  if (C == 3) { (void)__hip_atomic_fetch_min(&hot_or_cold(store + v, v)->y, val, TB_RLX, TB_WG); return; }
   (void)__hip_atomic_fetch_min(&store[v].y, val, TB_RLX, TB_WG);
 }
 template <int C>
 __device__ __forceinline__ void raise_lb(int2* store, int ni, int v, int val) {
+  if (C == 3) { raise_int_lb<3>(store, v, val); return; }
   if (C && v < 0) return;  // a constant kept out of the slab (load_dom)
   if (C && v >= ni) {
     const int b = v - ni;
@@ -288,6 +312,7 @@ __device__ __forceinline__ void raise_lb(int2* store, int ni, int v, int val) {
 }
 template <int C>
 __device__ __forceinline__ void lower_ub(int2* store, int ni, int v, int val) {
+  if (C == 3) { lower_int_ub<3>(store, v, val); return; }
   if (C && v < 0) return;
   if (C && v >= ni) {
     const int b = v - ni;
@@ -1426,6 +1451,32 @@ static __device__ TB_FIX_ATTR FpResult fixpoint_event_call(const DevProblem* Pp,
 // Block-wide copy of n intervals.  Both sides are 16-byte aligned (slabs are laid out in multiples of 2
 // intervals), so the body moves 16 B per lane with four independent loads in flight: a snapshot of a
 // 25k-variable store is ~12 memory round trips per thread instead of ~100.
+// Block copies of a HOT store (layout 3): the first HOT_VARS intervals of the working store live in LDS.  HS: the source is the working store,
+// HD: the destination is.
+template <int TB, bool HS, bool HD>
+__device__ __forceinline__ void copy_store_hot(int2* dst, const int2* src, int n) {
+  const int T = block_threads<TB>(), tid = here(threadIdx.x);
+  int4* d4 = reinterpret_cast<int4*>(dst);
+  const int4* s4 = reinterpret_cast<const int4*>(src);
+  int4* h4 = reinterpret_cast<int4*>(lds_ptr<int2>((unsigned)SH_BYTES));
+  const int n4 = n >> 1;  // (slabs are laid out in multiples of two intervals)
+  for (int i = tid; i < n4; i += T) {
+    const bool hot = i < HOT_VARS / 2;
+    const int4 v = (HS && hot) ? h4[i] : s4[i];
+    if (HD && hot) h4[i] = v; else d4[i] = v;
+  }
+}
+template <int TB>
+__device__ __forceinline__ void copy_store(int2* dst, const int2* src, int n);
+// the working store of layout C written to / filled from a slab in global memory
+template <int C, int TB>
+__device__ __forceinline__ void store_out(int2* dst, const int2* store, int n) {
+  if constexpr (C == 3) copy_store_hot<TB, true, false>(dst, store, n); else copy_store<TB>(dst, store, n);
+}
+template <int C, int TB>
+__device__ __forceinline__ void store_in(int2* store, const int2* src, int n) {
+  if constexpr (C == 3) copy_store_hot<TB, false, true>(store, src, n); else copy_store<TB>(store, src, n);
+}
 template <int TB = 0>
 __device__ __forceinline__ void copy_store(int2* dst, const int2* src, int n) {
   const int T = block_threads<TB>(), tid = here(threadIdx.x);  // (per-lane addresses computed here, at each copy)
@@ -1603,7 +1654,7 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
 // Streaming: hand the solution in `store` to the host through the ring (GridData::produce_solution,
 // gpu_dive_and_solve.hpp:100-114, without the print lock: a ticket orders the producers, the host consumes in
 // ticket order).  Uniform call; sh.ticket was taken by thread 0.
-template <int TB = 0>
+template <int TB = 0, int C = 0>
 __device__ __forceinline__ void produce_solution(const DevProblem& P, BlockShared& sh, const int2* store, Mailbox* mbox) {
   const int tid = threadIdx.x;
   const unsigned long long ticket = (unsigned long long)sh.ticket;
@@ -1619,7 +1670,7 @@ __device__ __forceinline__ void produce_solution(const DevProblem& P, BlockShare
   __syncthreads();
   if (sh.ticket >= 0) {
     const int slot = (int)(ticket % (unsigned long long)r.slots);
-    copy_store<TB>(r.data + (size_t)slot * P.vext, store, P.vext);
+    store_out<C, TB>(r.data + (size_t)slot * P.vext, store, P.vext);
     __threadfence_system();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&r.seq[slot], ticket + 1ull, __ATOMIC_RELEASE, TB_SYS);
@@ -1968,10 +2019,10 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
   if (sh.sol) {  // uniform
     // (the workgroup's slab of g_best is located here, where a solution is kept: not a pointer that lives through every round of every node)
     if (best_store == nullptr) best_store = glob(P.g_best) + (size_t)here_s(blockIdx.x) * P.vext;
-    for (int rep = reps_of(P, 8); rep > 1; --rep) copy_store<TB>(best_store, store, P.vext);
-    copy_store<TB>(best_store, store, P.vext);
+    for (int rep = reps_of(P, 8); rep > 1; --rep) store_out<C, TB>(best_store, store, P.vext);
+    store_out<C, TB>(best_store, store, P.vext);
     __syncthreads();
-    if (sh.ticket >= 0) produce_solution<TB>(P, sh, store, mbox);
+    if (sh.ticket >= 0) produce_solution<TB, C>(P, sh, store, mbox);
   }
 }
 
@@ -2028,7 +2079,6 @@ __device__ __forceinline__ void end_of_dive(const DevProblem& P, BlockShared& sh
   if (P.has_eps_strategy) { sh.cur_strategy = sh.cur_strategy > 1 ? sh.cur_strategy : 1; sh.next_unassigned = 0; }
 }
 
-constexpr int SH_BYTES = (int)((sizeof(BlockShared) + 15) / 16 * 16);
 
 // The event-driven variant is latency bound: its 256-thread form asks the register allocator for 7 waves per
 // SIMD (<= 72 VGPRs) so that 7 workgroups are resident per CU when their stores fit (wordpress7_500: 7 x 22.7 KB of
@@ -2055,9 +2105,10 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
   const int tid = threadIdx.x, b = blockIdx.x;
-  // LDS: [control block][store slab: vext x 8 B (STORE/TCN_SHARED)][dirty bitmap][change list][bytecodes (TCN_SHARED)]
+  // LDS: [control block][store slab: vext x 8 B (STORE/TCN_SHARED) | the hot tier of a store in global memory (layout 3)][dirty bitmap][change list][bytecodes (TCN_SHARED)]
   const int VX = P.vext;
-  const size_t store_bytes = MEM >= TB_MEM_STORE_SHARED ? (((size_t)VX * 8 + 15) / 16) * 16 : 0;
+  static_assert(C != 3 || MEM == TB_MEM_GLOBAL, "the hot tier belongs to stores in global memory");
+  const size_t store_bytes = MEM >= TB_MEM_STORE_SHARED ? (((size_t)VX * 8 + 15) / 16) * 16 : (C == 3 ? (size_t)HOT_VARS * 8 : 0);
   const size_t dirty_bytes = dirty_region_bytes(P.dirty_words) + (((size_t)P.chg_cap * 4 + 15) / 16) * 16;
   int2* store = MEM >= TB_MEM_STORE_SHARED ? reinterpret_cast<int2*>(smem + SH_BYTES) : glob(P.g_store) + (size_t)b * VX;
   EventState es;
@@ -2106,7 +2157,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
   // takes no snapshot, keeps no decision (the child is chosen by a bit of the subproblem index) and a leaf there skips the subtree.
   while (sh.has_work && !sh.stop) {
     // C. restore the root
-    copy_store<TB>(store, glob(P.root_store), VX);  // the root slab is laid out like a workgroup slab
+    store_in<C, TB>(store, glob(P.root_store), VX);  // the root slab is laid out like a workgroup slab
     if (EVENT && tid == 0) { sh.ev_all = P.root_fixpoint ? 0 : 1; sh.chg_count[0] = 0; }  // a root that is not a fixpoint: every slice runs once
     if (RM && !P.root_fixpoint) {  // nothing is known to be entailed yet (the event fixpoint does this in its root pass)
       __syncthreads();
@@ -2155,8 +2206,8 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
         long long tp = 0;
         if (prof && tid == 0) tp = wall_clock64();
         if (!diving) {
-          if (d0 < P.snapshot_levels) copy_store<TB>(snap + (size_t)d0 * VX, store, VX);  // d0 == 0: barebones:785-791
-          if ((pk(P) & 0x4) && d0 < P.snapshot_levels) copy_store<TB>(snap + (size_t)d0 * VX, store, VX);  // tuning: cost of the snapshot
+          if (d0 < P.snapshot_levels) store_out<C, TB>(snap + (size_t)d0 * VX, store, VX);  // d0 == 0: barebones:785-791
+          if ((pk(P) & 0x4) && d0 < P.snapshot_levels) store_out<C, TB>(snap + (size_t)d0 * VX, store, VX);  // tuning: cost of the snapshot
           if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
           __syncthreads();
         }
@@ -2193,7 +2244,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
         const int depth = sh.new_depth;
         if (depth == -1) { exhausted = true; break; }
         const int lvl = (depth - 1) < (P.snapshot_levels - 1) ? (depth - 1) : (P.snapshot_levels - 1);
-        for (int rep = reps_of(P, 6); rep > 0; --rep) copy_store<TB>(store, snap + (size_t)lvl * VX, VX);
+        for (int rep = reps_of(P, 6); rep > 0; --rep) store_in<C, TB>(store, snap + (size_t)lvl * VX, VX);
         if (tid == 0) { sh.bot = 0; sh.depth = depth; }
         __syncthreads();
         // re-apply decisions[lvl .. depth-2].current(): distinct decisions may hit the same variable, the
@@ -2236,7 +2287,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
     h.has_work = sh.has_work; h.nodes = (int)bs.nodes;
     glob(P.g_path_hdr)[b] = h;
   }
-  if (P.g_last != nullptr) copy_store<TB>(glob(P.g_last) + (size_t)b * VX, store, VX);  // test aid: the store this workgroup stopped on
+  if (P.g_last != nullptr) store_out<C, TB>(glob(P.g_last) + (size_t)b * VX, store, VX);  // test aid: the store this workgroup stopped on
 
   // fold what is left of the per-lane write counters into the workgroup's statistics
   __syncthreads();
