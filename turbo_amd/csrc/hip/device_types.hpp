@@ -123,6 +123,9 @@ struct BlockStats {
   int depth_max, exhaustive, num_blocks_done, best_bound;
   long long best_sub;               // subproblem index that produced best_store (-1: none)
   int why, pad_why;                 // debugging: reasons that cleared `exhaustive` (bit mask)
+#ifdef TB_TUNING
+  unsigned reg[72];                 // tuning build: how often a wave passed each region marker of the search kernel (kernels.hpp: TB_REGION)
+#endif
   int dbg[TB_DBG_WORDS];            // tuning build: census of the event fixpoint / first violation found by its self-check (production keeps 4 words: the
                                     // block sits in every workgroup's LDS, where 1280-byte granules decide how many workgroups a CU holds)
 };

@@ -1749,6 +1749,13 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
   long long best_block = -1;
   long long first_idle = -1, last_idle = 0, wait_ticks = 0;
 #ifdef TB_TUNING
+  if (s->cfg.verbose && std::getenv("TB_PRINT_REGIONS") != nullptr) {  // region census of the search kernel (kernels.hpp: TB_REGION; scripts/region_budget.py)
+    unsigned long long r[72] = {0}, nodes = 0;
+    for (size_t b = 0; b < B; ++b) { for (int i = 0; i < 72; ++i) r[i] += bst[b].reg[i]; nodes += bst[b].nodes; }
+    std::fprintf(stderr, "%% regions nodes=%llu", nodes);
+    for (int i = 0; i < 72; ++i) std::fprintf(stderr, " %d=%llu", i, r[i]);
+    std::fprintf(stderr, "\n");
+  }
   if ((s->cfg.reserved[0] & 0x10000) && s->cfg.verbose) {  // wave 0's time inside the rounds of the event fixpoint (kernels.hpp: TB_PROF_MARK)
     double d[32] = {0};
     unsigned long long nodes = 0;

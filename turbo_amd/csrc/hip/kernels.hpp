@@ -141,6 +141,17 @@ __device__ __forceinline__ constexpr int pk(const DevProblem&) {
 #endif
 __device__ __forceinline__ int reps_of(const DevProblem& P, int phase) { return ((pk(P) >> 8) & 0xff) == phase ? 2 : 1; }
 
+// Regions of the search kernel for the instruction budget (scripts/region_budget.py): a -DTB_REGION_MARKERS build is the production kernel with an
+// assembler comment at each point -- static instruction counts between two markers, in layout order -- and the tuning build counts how often a
+// wave passes each point (BlockStats::reg; wave-uniform points only).
+#if defined(TB_REGION_MARKERS)
+#define TB_REGION(id) asm volatile("; TBREGION " #id)
+#elif defined(TB_TUNING)
+#define TB_REGION(id) do { if ((threadIdx.x & 63) == 0) (void)__hip_atomic_fetch_add(&sh.bs.reg[id], 1u, TB_RLX, TB_WG); } while (0)
+#else
+#define TB_REGION(id) do { } while (0)
+#endif
+
 // LDS pointers across a call boundary: a pointer argument of a non-inlined function is GENERIC (flat_load / flat_atomic, both
 // counters, an aperture check per access) unless its address space travels with it.  The outlined functions below take 32-bit LDS
 // offsets and rebuild address-space-3 pointers, from which the compiler infers ds_* instructions for everything inlined under them.
@@ -648,10 +659,11 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
 // run, not after each narrowing.  Up to two successors per operand travel with the record (DevProblem::succ) and need no
 // memory access; the others come from the variable's 32-byte adjacency record, one L2 round trip for the whole wave.
 // Returns true (wave-uniform) when something was marked.
-__device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* nxt, int s, const int4 pr, const int4 sc, int nar_all, int* census = nullptr) {
+__device__ __forceinline__ bool mark_successors(const DevProblem& P, BlockShared& sh, unsigned* nxt, int s, const int4 pr, const int4 sc, int nar_all, int* census = nullptr) {
   const int priv = (pr.x >> 8) & 7;  // operands private to this slice are flagged at pack time
   int ex = (priv & 1) ? 0 : (nar_all & 3), ey = (priv & 2) ? 0 : ((nar_all >> 2) & 3), ez = (priv & 4) ? 0 : ((nar_all >> 4) & 3);
   if (!wave_any((ex | ey | ez) != 0)) return false;
+  TB_REGION(39);
   bool did = false;
 #ifdef TB_TUNING
   if (census != nullptr) {  // knob 0x10000: runs with something to mark [12], lanes with something to mark [15], ... through the adjacency records [13] / lanes [16], ... with a tail [14]
@@ -667,6 +679,7 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* n
   if (ez & ~ovz) did |= mark_packed(nxt, (unsigned)sc.z, sc.w >> 12, ez & ~ovz);
   ex &= ovx; ey &= ovy; ez &= ovz;
   if (wave_any((ex | ey | ez) != 0)) {
+    TB_REGION(40);
 #ifdef TB_TUNING
     const long long t_var = census != nullptr ? clock64() : 0;  // [21]: time in this branch; [22], [23]: lanes marking their x / their y or z through it
     if (census != nullptr) {
@@ -696,6 +709,7 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, unsigned* n
     if (census != nullptr) { const long long t_ = clock64(); if ((threadIdx.x & 63) == 0) census[21] += (int)((t_ - t_var) >> 4); }
 #endif
   }
+  TB_REGION(41);
   return wave_any(did);
 }
 
@@ -924,6 +938,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   long long tp0 = 0;
   if (tid == 0 && prof) tp0 = wall_clock64();
   // ---- initial dirty set (bitmap 0): everything, or the slices of the variables changed since the last fixpoint
+  TB_REGION(2);
   const int cnt = ld(&sh.chg_count[0]);
   const bool all = ld(&sh.ev_all) != 0 || cnt > es.cap;
   // Entailed-slice removal: a slice whose 64 propagators were all entailed when it last ran stays entailed in the
@@ -941,6 +956,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   } else {
     for (int rep = reps_of(P, 1); rep > 0; --rep)
     for (int e0 = wave * 64; e0 < cnt; e0 += T) {  // one lane per entry; long lists are finished cooperatively
+      TB_REGION(3);
       const int e = e0 + lane;
       const int entry = e < cnt ? es.list[e] : 0;
       const int ev = e < cnt ? ((entry >> 30) & 3) : 0;
@@ -951,6 +967,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       if (mm) (void)mark_tail(P, bm0, mm, deg, off, ev, -1);
     }
   }
+  TB_REGION(59);
   if (tid == 0) { st(&sh.unent[0], 0); st(&sh.flag[0], 0); st(&sh.flag[1], 0); }
   __syncthreads();
   if (tid == 0) { st(&sh.ev_all, 0); st(&sh.chg_count[0], 0); }
@@ -968,6 +985,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
 #endif
   for (;; ++rounds) {
     const int k = rounds % 3;
+    TB_REGION(4);
     unsigned* cur = es.dirty + (rounds & 1) * W;
     unsigned* nxt = es.dirty + ((rounds + 1) & 1) * W;
     bool marked = false;  // wave-uniform: this wave marked something for the next round
@@ -1026,6 +1044,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       if (s >= 0) sc_cur = (es.succ + (size_t)s * 64)[lane];
 #endif
       while (s >= 0) {
+        TB_REGION(5);
         const int s_next = next_slice();
 #if TB_SC_PREFETCH
         const int4 sc = sc_cur;
@@ -1063,6 +1082,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             unsigned iters = 0;
             unsigned run_writes_lean = 0;  // per lane
             for (;;) {
+              TB_REGION(6);
               // predicates as integers on the raw bit pairs (bit 0 of yb / zb: lb raised, bit 1: ub lowered), one vote each
               const unsigned yb = __hip_atomic_load(wy, TB_RLX, TB_WG) >> ys, zb = __hip_atomic_load(wz, TB_RLX, TB_WG) >> zs;
               const unsigned ny = zb & ~yb & 2u & am, nz = yb & ~zb & 1u & am;             // y.ub := 0 / z.lb := 1
@@ -1083,6 +1103,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
               if (ld(&sh.bot)) break;
             }
+            TB_REGION(7);
             {  // (tuning build: the class / useless-run filters of the census, as for the other runs below)
               const int want = (knobs(P) >> 28) & 15;
               if (rep == reps_of(P, 3) && (want == 0 || want - 1 == K_LEQ_T) && (!(knobs(P) & 0x40) || mask_nz(acc) == 0ull)) {
@@ -1105,6 +1126,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             }
             for (int mrep = (pk(P) & 0x1) ? 2 : 1; mrep > 0; --mrep)
             if (mask_nz(acc) != 0ull) {
+              TB_REGION(8);
               // successors: the slots hold the readers interested in exactly these events (y.ub lowered / z.lb raised), pre-filtered
               const bool my_ny = (acc & 2u) != 0u, my_nz = (acc & 1u) != 0u;
               unsigned ty = my_ny ? (unsigned)sc.y : 0xffffffffu;
@@ -1114,11 +1136,13 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               // bound of Y move onto kv later, whoever moves it wakes that slice.)
               const bool cond = my_ny && ((sc.w >> 30) & 1) != 0;
               if (wave_any(cond)) {
+                TB_REGION(9);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // my write of y, then this read: the chain run does the same with roles reversed
                 const Itv Yc = load_int<C>(store, cond ? (int)(ty >> 16) : 0);
                 const int kv = (int)(short)((((unsigned)sc.w >> 3) & 0x3fffu) | ((((unsigned)sc.w >> 28) & 3u) << 14));
                 if (cond) ty = (kv == Yc.lb || kv == Yc.ub) ? (ty | 0xffff0000u) : 0xffffffffu;
               }
+              TB_REGION(45);
               bool did = false;
               if ((ty & 0xffffu) != 0xffffu) { mark_slice(nxt, (int)(ty & 0xffffu)); did = true; }
               if ((ty >> 16) != 0xffffu) { mark_slice(nxt, (int)(ty >> 16)); did = true; }
@@ -1126,6 +1150,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               if ((tz >> 16) != 0xffffu) { mark_slice(nxt, (int)(tz >> 16)); did = true; }
               const int ey = (my_ny && ((sc.w >> 17) & 1)) ? EV_UB : 0, ez = (my_nz && ((sc.w >> 2) & 1)) ? EV_LB : 0;
               if (wave_any((ey | ez) != 0)) {  // more than two interested readers: the variable's adjacency record
+                TB_REGION(10);
                 const int base_w = C == 2 ? P.n_int : P.n_int * 2;  // first Boolean word of the slab
                 const int vy = P.n_int + ((((int)((unsigned)sc.x & 0xffffu)) - base_w) << 4) + (ys >> 1);
                 const int vz = P.n_int + ((((int)((unsigned)sc.x >> 16)) - base_w) << 4) + (zs >> 1);
@@ -1136,12 +1161,15 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                 if (my) did |= mark_tail(P, nxt, my, dy, oy, ey, s);
                 if (mz) did |= mark_tail(P, nxt, mz, dz, oz, ez, s);
               }
+              TB_REGION(46);
               marked |= wave_any(did);
             }
+            TB_REGION(11);
             TB_PROF_MARK(2);
             TB_PROF_COUNT(4);
             continue;
           }
+          TB_REGION(12);
           const int4 pr_first = props[s * 64 + lane];  // the arrays are padded to whole slices
 #if defined(TB_TUNING) || TB_DOUBLE_PHASE
           int4 pr_again = pr_first;
@@ -1159,6 +1187,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
           if (C && key == KEY_LEQT_BB) {
             // y <= z on two Booleans, straight on their 2-bit encodings (bit 0: lb raised to 1, bit 1: ub lowered to 0):
             // z.ub = 0 forces y.ub = 0, y.lb = 1 forces z.lb = 1; entailed once y.ub = 0 or z.lb = 1.
+            TB_REGION(42);
             const BoolRef ry = bool_ref<C>(store, P.n_int, pr.z, act), rz = bool_ref<C>(store, P.n_int, pr.w, act);
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               const unsigned yb = bool_bits(ry), zb = bool_bits(rz);
@@ -1186,6 +1215,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             // groups at once: every lane carries its group's bounds, a ballot masked with the group's lanes says whether some
             // false b_i sits on a bound, and the bounds step over the excluded values in registers -- no memory traffic; then
             // every b_i outside the new bounds becomes false and, if y is assigned, its b_i true.  Same fixpoint, one pass.
+            TB_REGION(13);
             const BoolRef rx = bool_ref<C>(store, P.n_int, pr.y, act);
             const int yv = act ? pr.z : 0;
             const int w0u = info.x;
@@ -1206,6 +1236,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             const bool by_range = (info.y & 0x400) != 0;
             bool chain_marked = false;
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
+              TB_REGION(14);
               const unsigned xb = bool_bits(rx);
               const Itv Y = load_int<C>(store, yv);
               const bool t = act && (xb & 1u), f = act && (xb & 2u), u = act && xb == 0u;
@@ -1266,10 +1297,12 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                 // BECOME a bound looks at its b once more, after that write: of the two, at least one sees the other's store (LDS operations of a wave
                 // execute in order, and the writer's come before this read in the same instruction stream).  A b found false now means one more pass.
                 if (wave_any(cyl | cyu)) {
+                  TB_REGION(15);
                   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (relaxed accesses to different addresses: the compiler may not hoist the read)
                   const bool became_bound = act && !f && !set0 && ((lb != Y.lb && kc == lb) || (ub != Y.ub && kc == ub));
                   if (became_bound && (bool_bits(rx) & 2u)) again = true;
                 }
+                TB_REGION(47);
                 run_writes += (unsigned)(set0 | set1) + (unsigned)cyl + (unsigned)cyu;
                 // (y is reported by the lane that wrote it, or by every lane of the group when y's readers are dealt out over their records)
                 const bool y_rep = writer || ((sc.w >> 20) & 1) != 0;
@@ -1280,9 +1313,11 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               // confirmation pass is needed; otherwise a b made false for one lane may still have to act through another one.
               ch = again || (single_pass ? false : nar != 0);
             });
+            TB_REGION(16);
             if (by_range) marked |= wave_any(chain_marked);
           } else if (C && (key == KEY_EQR_BIC || key == KEY_LEQR_BIC)) {
             // b = (y = k) / b = (y <= k): Boolean truth variable, integer y, constant k (read once per run)
+            TB_REGION(17);
             const bool is_eq = key == KEY_EQR_BIC;
             const BoolRef rx = bool_ref<C>(store, P.n_int, pr.y, act);
             const int yv = act ? pr.z : 0;
@@ -1325,8 +1360,10 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               un_i = act & !ent;
             });
           } else if (info.y & 0x200) {
+            TB_REGION(43);
             wave_iters = lean_class_run<C>(E, __builtin_ctz(key & CLASS_SET_MASK), (int)(key >> 10), pr, act, store, P.n_int, run_writes, wave_writes, nar_all);
           } else {
+            TB_REGION(44);
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               apply<true, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, 0, &nar);
             });
@@ -1339,14 +1376,16 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             tprof = t_;
           }
 #endif
+          TB_REGION(18);
 #ifdef TB_TUNING
-          marked |= mark_successors(P, nxt, s, pr, sc, nar_all, (prof && wave == 0) ? sh.bs.dbg : nullptr);
+          marked |= mark_successors(P, sh, nxt, s, pr, sc, nar_all, (prof && wave == 0) ? sh.bs.dbg : nullptr);
 #else
-          marked |= mark_successors(P, nxt, s, pr, sc, nar_all);
+          marked |= mark_successors(P, sh, nxt, s, pr, sc, nar_all);
 #endif
+          TB_REGION(19);
           TB_PROF_MARK(2);
           TB_PROF_COUNT(4);
-          if (pk(P) & 0x1) marked |= mark_successors(P, nxt, s, pr, sc, nar_all);  // tuning: cost of the marks (idempotent)
+          if (pk(P) & 0x1) marked |= mark_successors(P, sh, nxt, s, pr, sc, nar_all);  // tuning: cost of the marks (idempotent)
           tc.writes += run_writes;
           {  // profiling (tuning build): 0x400000 counts slice runs instead of iterations; bits 28-31 = 1 + class to count only that class (11 = mixed slices)
             const int want = (knobs(P) >> 28) & 15;
@@ -1363,6 +1402,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       }
     }
     for (int rep = reps_of(P, 10); rep > 0; --rep) {  // (tuning: the end of a round twice -- flag, reset, barrier)
+    TB_REGION(20);
     if (lane == 0 && marked) st(&sh.flag[k], 1);
     if (tid == 0) {
       st(&sh.flag[(k + 1) % 3], 0);
@@ -1374,6 +1414,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     TB_PROF_COUNT(5);
     if (!ld(&sh.flag[k]) || dead_node(sh)) break;
   }
+  TB_REGION(21);
   if (lane == 0) tc.writes += wave_writes;
   if (lane == 0 && wave_iters_total != 0) { add_deductions(sh, 64ull * wave_iters_total); add_active(sh, (unsigned long long)wave_active_total); }
   if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += t - tp0; tp0 = t; }  // profiling: rounds
@@ -1388,6 +1429,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   // the bytes at all.  When the witness has become entailed, the slices whose byte is set are examined one by one (their
   // byte is corrected on the way) until a new witness turns up or none is left.
   if (wave == 0 && !dead_node(sh)) {
+    TB_REGION(22);
     auto unentailed_lanes = [&](int first_prop, bool whole_slice) -> unsigned long long {  // wave-uniform result
       const int i = whole_slice ? first_prop + lane : first_prop;
       const bool act = i < n;
@@ -1405,6 +1447,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       for (unsigned long long m = wave_ballot(word != 0); m && !confirmed; m &= m - 1) {
         const int wl = __builtin_ctzll(m);
         for (unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)word, wl); bits && !confirmed; bits &= bits - 1) {
+          TB_REGION(23);
           const int sl = (base + wl) * 32 + __builtin_ctz(bits);
           const unsigned long long un = unentailed_lanes(sl * 64, true);
           if (un) { wit = sl * 64 + __builtin_ctzll(un); confirmed = true; }
@@ -1415,6 +1458,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     if (lane == 0) { st(&sh.witness, confirmed ? wit : -1); st(&sh.unent[0], confirmed ? 1 : 0); }
   }
   __syncthreads();
+  TB_REGION(24);
   all_entailed = !ld(&sh.unent[0]);
   return rounds + 1;
 }
@@ -1586,6 +1630,7 @@ template <int C, int TB = 0>
 __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Decision* dec, const int2* store) {
   const int tid = here(threadIdx.x), T = block_threads<TB>(), lane = tid & 63, wave = tid >> 6, nw = T >> 6;
   for (;;) {
+    TB_REGION(33);
     const int s = sh.cur_strategy;  // uniform: read after a barrier
     if (s >= P.n_strats) { if (tid == 0) sh.found = 0; __syncthreads(); return; }
     const int off = glob(P.strat_off)[s];
@@ -1629,6 +1674,7 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
     if (rep > 1) __syncthreads();  // (tuning: the scan is about to run again and rewrite red_key)
     }
     if (tid == 0) {
+      TB_REGION(34);
       for (int w = 1; w < nw; ++w) {
         best = sh.red_key[w] < best ? sh.red_key[w] : best;
         first = sh.red_first[w] < first ? sh.red_first[w] : first;
@@ -1646,6 +1692,7 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
         sh.skip = 0;
       }
     }
+    TB_REGION(58);
     __syncthreads();
     if (sh.skip) return;
   }
@@ -1898,6 +1945,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
                                                     int2* best_store, Mailbox* mbox, ThreadCounters& tc) {
   const int tid = threadIdx.x;
   BlockStats& bs = sh.bs;
+  TB_REGION(1);
   // (thread 0's clock at the phase boundary lives in LDS, sh.t_mark: a register pair held through the fixpoint ended up in scratch)
   if (tid == 0) { const long long t0 = wall_clock64(); bs.timers[TB_T_SEARCH] += t0 - sh.t_mark; sh.t_mark = t0; }
   bool all_entailed = false;
@@ -1949,12 +1997,14 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
   }
 #endif
   if (tid == 0) {
+    TB_REGION(25);
     const long long t1 = wall_clock64();
     bs.timers[TB_T_FIXPOINT] += t1 - sh.t_mark;
     sh.t_mark = t1;
     int leaf = failed ? 1 : 0, sol = 0;
     bool stream = false;
     if (!failed && all_entailed) {
+      TB_REGION(62);
       leaf = 1;
       if (P.obj_var >= 0) {
         const int obj = load_dom<C>(store, P.n_int, P.obj_var).lb;
@@ -1992,6 +2042,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
         }
       }
     }
+    TB_REGION(64);
     sh.ticket = stream ? (long long)__hip_atomic_fetch_add(&glob(P.ctrl)->sol_ticket, 1ull, TB_RLX, TB_AGENT) : -1ll;
     sh.leaf = leaf;
     sh.sol = sol;
@@ -2003,11 +2054,13 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
     // cell are polled on a wall-clock period by whichever workgroup notices that the poll is due
     bool must_stop = (P.cut_nodes != 0 && bs.nodes >= P.cut_nodes);
     if (P.cut_nodes_total != 0 && (bs.nodes % NODE_BATCH) == 0) {
+      TB_REGION(63);
       // the budget of the whole search: counted per device (agent scope); a single GPU (or one without linked peers, which was
       // given its own share of the budget) checks its own count, linked GPUs are summed by their pollers (poll_outside)
       const unsigned long long mine = __hip_atomic_fetch_add(&glob(P.ctrl)->nodes_local, (unsigned long long)NODE_BATCH, TB_RLX, TB_AGENT) + NODE_BATCH;
       if (P.peers == nullptr && mine >= P.cut_nodes_total) raise_gpu_stop(P);
     }
+    TB_REGION(65);
     const Hot hot = load_hot(glob(P.ctrl));
     maybe_poll(P, mbox, hot, t1);
     if (hot.stop != 0) must_stop = true;
@@ -2016,7 +2069,9 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
     if (must_stop) { bs.exhaustive = 0; sh.stop = 1; bs.why |= 4 | (aborted ? 8 : 0) | ((P.cut_nodes != 0 && bs.nodes >= P.cut_nodes) ? 16 : 0); }
   }
   __syncthreads();
+  TB_REGION(26);
   if (sh.sol) {  // uniform
+    TB_REGION(27);
     // (the workgroup's slab of g_best is located here, where a solution is kept: not a pointer that lives through every round of every node)
     if (best_store == nullptr) best_store = glob(P.g_best) + (size_t)here_s(blockIdx.x) * P.vext;
     for (int rep = reps_of(P, 8); rep > 1; --rep) store_out<C, TB>(best_store, store, P.vext);
@@ -2024,6 +2079,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
     __syncthreads();
     if (sh.ticket >= 0) produce_solution<TB, C>(P, sh, store, mbox);
   }
+  TB_REGION(48);
 }
 
 // Event kernels: the node (fixpoint + bookkeeping + best-store copy) and the variable selection are functions of their own -- one
@@ -2142,6 +2198,9 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
     bs.wait_ticks = 0;
     bs.why = 0; bs.pad_why = 0;
     for (int i = 0; i < TB_DBG_WORDS; ++i) bs.dbg[i] = 0;
+#ifdef TB_TUNING
+    for (int i = 0; i < 72; ++i) bs.reg[i] = 0;
+#endif
     bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
     sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0;
     sh.n_dec_seg = 0;
@@ -2157,6 +2216,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
   // takes no snapshot, keeps no decision (the child is chosen by a bit of the subproblem index) and a leaf there skips the subtree.
   while (sh.has_work && !sh.stop) {
     // C. restore the root
+    TB_REGION(38);
     store_in<C, TB>(store, glob(P.root_store), VX);  // the root slab is laid out like a workgroup slab
     if (EVENT && tid == 0) { sh.ev_all = P.root_fixpoint ? 0 : 1; sh.chg_count[0] = 0; }  // a root that is not a fixpoint: every slice runs once
     if (RM && !P.root_fixpoint) {  // nothing is known to be entailed yet (the event fixpoint does this in its root pass)
@@ -2174,10 +2234,12 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
     __syncthreads();
     bool exhausted = false;  // uniform: the subproblem's tree was searched to the end (barebones:866-870)
     while (!sh.stop) {
+      TB_REGION(28);
       const bool diving = sh.remaining > 0;  // uniform: thread 0 last wrote it before a barrier
       if (!diving) {
         // I. tighten the objective with the incumbent (barebones:756-771)
         if (tid == 0 && P.obj_var >= 0) {
+          TB_REGION(29);
           if (P.use_fixed_bound) { sh.last_obj_ub = P.fixed_bound; embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, P.obj_var, NINF, P.fixed_bound); }
           else {
             const unsigned long long bf = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&glob(P.ctrl)->best_bound), TB_RLX, TB_AGENT);
@@ -2186,36 +2248,43 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
             g = f < g ? f : g;
             g = sh.best_bound < g ? sh.best_bound : g;
             if (g != PINF) {
-              if (g == NINF) { sh.stop = 1; raise_gpu_stop(P); }  // unbounded objective
+              if (g == NINF) { TB_REGION(61); sh.stop = 1; raise_gpu_stop(P); }  // unbounded objective
               else { sh.last_obj_ub = g - 1; embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, P.obj_var, NINF, g - 1); }
             }
           }
         }
+        TB_REGION(49);
         __syncthreads();
         if (sh.stop) break;
       }
       // II. propagate
       propagate_node<EVENT, C, RM, MEM, TB>(P, sh, store, props, es, nullptr, mbox, tc);
       if (sh.stop) break;
+      TB_REGION(30);
       int2* const snap = snap_of();
       Decision* const dec = dec_of();
       // III. branch
       if (!sh.leaf) {
+        TB_REGION(31);
         const int d0 = sh.depth;
         const bool prof = (knobs(P) & 0x10000) != 0;
         long long tp = 0;
         if (prof && tid == 0) tp = wall_clock64();
         if (!diving) {
+          TB_REGION(32);
           if (d0 < P.snapshot_levels) store_out<C, TB>(snap + (size_t)d0 * VX, store, VX);  // d0 == 0: barebones:785-791
           if ((pk(P) & 0x4) && d0 < P.snapshot_levels) store_out<C, TB>(snap + (size_t)d0 * VX, store, VX);  // tuning: cost of the snapshot
           if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
           __syncthreads();
         }
+        TB_REGION(50);
         if (prof && tid == 0) { const long long t = wall_clock64(); bs.timers[TB_T_PREPROCESSING] += t - tp; tp = t; }  // profiling: snapshot push
         split_node<EVENT, C, (MEM >= TB_MEM_STORE_SHARED), TB>(P, sh, dec, store);
+        TB_REGION(51);
         if (prof && tid == 0) bs.timers[TB_T_SELECT_FP_FUNCTIONS] += wall_clock64() - tp;  // profiling: variable selection
         if (sh.stop) break;
         if (tid == 0) {
+          TB_REGION(35);
           if (!sh.found) { sh.leaf = 1; bs.exhaustive = 0; bs.why |= diving ? 1 : 2; }  // unsplittable infinite domains (barebones:688-694)
           else if (diving) {
             --sh.remaining;
@@ -2231,12 +2300,14 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
             if (P.g_path_ub != nullptr && sh.depth <= P.max_depth) glob(P.g_path_ub)[(size_t)b * P.max_depth + (sh.depth - 1)] = sh.last_obj_ub;
           }
         }
+        TB_REGION(52);
         __syncthreads();
       }
       if (sh.leaf) {
         // E. a leaf above the subproblem: skip the whole subtree (barebones:718-741)
-        if (diving) { if (tid == 0) skip_subtree(P, sh); break; }
+        if (diving) { TB_REGION(60); if (tid == 0) skip_subtree(P, sh); break; }
         // IV. backtrack: rope jump, then restore the deepest snapshot and replay (barebones:812-863)
+        TB_REGION(36);
         const int dcur = sh.depth;  // stable: last written before a barrier
         if (dcur == 0) { exhausted = true; break; }
         if (tid == 0) { const Decision& dl = dec_at(P, sh, dec, dcur - 1); sh.new_depth = dl.rope[dl.cur]; }
@@ -2258,28 +2329,34 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
         }
         __syncthreads();
         if (tid == 0) {
+          TB_REGION(37);
           Decision& dd = dec_at(P, sh, dec, depth - 1);
           const int c = ++dd.cur;
           embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
           sh.cur_strategy = sh.snap_strategy;
           sh.next_unassigned = sh.snap_next_unassigned;
         }
+        TB_REGION(53);
         __syncthreads();
       }
     }
+    TB_REGION(54);
     if (tid == 0) {
       if (sh.t_dive != 0) end_of_dive_timer(sh);  // (stopped, or met a leaf, while diving)
       if (exhausted && !sh.stop) bs.eps_solved += 1;
     }
     // G. next subproblem (barebones:877-884)
     if (tid == 0 && !sh.stop) {
+      TB_REGION(55);
       const long long t = wall_clock64();
       bs.timers[TB_T_SEARCH] += t - sh.t_mark;
       sh.has_work = next_subproblem(P, sh, mbox) ? 1 : 0;
       sh.t_mark = wall_clock64();  // time spent waiting for work is not search time (BlockStats::wait_ticks)
     }
+    TB_REGION(56);
     __syncthreads();
   }
+  TB_REGION(57);
   // test aid (tb_config.reserved[0] & 0x800000, tb_session_debug_path): where this workgroup stood when it left
   if (P.g_path_hdr != nullptr && tid == 0) {
     PathHeader h;
