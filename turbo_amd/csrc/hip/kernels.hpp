@@ -170,6 +170,12 @@ template <class T> __device__ __forceinline__ const T* cst(const T* p) { return 
 template <class T> __device__ __forceinline__ T* glob(T* p) { return (T*)(TB_GLB T*)(size_t)p; }  // (through an integer: a generic -> global -> generic cast pair folds away)
 
 __device__ __forceinline__ const DevProblem& constant_problem(const DevProblem* p) { return *(const DevProblem*)(TB_CST const DevProblem*)(size_t)p; }
+__device__ __forceinline__ bool deadline_passed(const DevProblem& P) {
+  TB_CST const DevProblem* p = (TB_CST const DevProblem*)(size_t)&P;
+  asm volatile("" : "+s"(p));
+  const long long d = p->deadline_ticks;  // (a scalar load, in the rare branch)
+  return d != 0 && wall_clock64() > d;
+}
 
 // Wave votes straight on the lane mask a comparison leaves in an SGPR pair (HIP's __any / __ballot take an int: the bool is first
 // turned into 0/1 with a v_cndmask and compared again -- two VALU instructions per vote on an issue-bound kernel).
@@ -192,6 +198,11 @@ template <int TB> __device__ __forceinline__ int block_threads() { return TB != 
 // scratch, or in lanes of a spill register) for the whole search, at the expense of the registers the hot loops need.
 __device__ __forceinline__ int here(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int here_s(int x) { asm volatile("" : "+s"(x)); return x; }  // ... a wave-uniform one
+// The watchdog's deadline, fetched where the watchdog looks at it (once per 1024 wave-local iterations / 256 rounds): read through the constant address
+// space the load is loop invariant, gets hoisted to the top of the persistent kernel and its two registers are spilled -- and reloaded in every pass of
+// every run (r04: four v_readlane per channelling pass).  Behind an opaque pointer it stays in the rare branch.
+struct DevProblem;
+__device__ __forceinline__ bool deadline_passed(const DevProblem& P);
 
 __device__ __forceinline__ int ld(const int* p) { return __hip_atomic_load(p, TB_RLX, TB_WG); }
 __device__ __forceinline__ void st(int* p, int v) { __hip_atomic_store(p, v, TB_RLX, TB_WG); }
@@ -509,7 +520,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
           // watchdog inside the wave-local loop: a slowly converging pair in one slice (x < y < x over 2^31 values) never
           // reaches the block-level check below (wave-uniform counter: scalar work, once per 1024 iterations)
           if ((local_iters % WAVE_WATCHDOG_PERIOD) == 0) {
-            if (lane == 0 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
+            if (lane == 0 && deadline_passed(P)) st(&sh.abort, 1);
             if (ld(&sh.abort)) break;
           }
         }
@@ -524,7 +535,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
       const int k1 = (k + 1) % 3;
       st(&sh.flag[k1], 0); st(&sh.unent[k1], 0);
       // watchdog: a pathological network (x < y < x over 2^31 values) must not outlive the deadline
-      if ((it & 255) == 255 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
+      if ((it & 255) == 255 && deadline_passed(P)) st(&sh.abort, 1);
     }
     __syncthreads();
     ++it;
@@ -645,7 +656,7 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (ld(&E.sh.bot)) break;
     if ((wave_iters % WAVE_WATCHDOG_PERIOD) == 0) {  // watchdog inside the wave-local loop (see fixpoint)
-      if (lane == 0 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&E.sh.abort, 1);
+      if (lane == 0 && deadline_passed(P)) st(&E.sh.abort, 1);
       if (ld(&E.sh.abort)) break;
     }
   }
@@ -863,7 +874,7 @@ __device__ __forceinline__ unsigned lean_class_run_t(const RunEnv& E, const int 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (ld(&E.sh.bot)) break;
     if ((iters % WAVE_WATCHDOG_PERIOD) == 0) {  // watchdog inside the wave-local loop (see fixpoint)
-      if (lane == 0 && E.P.deadline_ticks != 0 && wall_clock64() > E.P.deadline_ticks) st(&E.sh.abort, 1);
+      if (lane == 0 && deadline_passed(E.P)) st(&E.sh.abort, 1);
       if (ld(&E.sh.abort)) break;
     }
   }
@@ -1406,7 +1417,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     if (lane == 0 && marked) st(&sh.flag[k], 1);
     if (tid == 0) {
       st(&sh.flag[(k + 1) % 3], 0);
-      if ((rounds & 255) == 255 && P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks) st(&sh.abort, 1);
+      if ((rounds & 255) == 255 && deadline_passed(P)) st(&sh.abort, 1);
     }
     __syncthreads();  // the narrowings and the marks of this round are visible to everybody
     }
