@@ -54,6 +54,11 @@ typedef struct { int32_t lb, ub; } tb_itv;          /* VStore element: 8 B */
 typedef struct { int32_t op, x, y, z; } tb_prop;    /* PIR bytecode_type: 16 B, 16-B aligned */
 
 /* The scalars of Configuration<> (include/config.hpp:35-59) that reach the GPU path. */
+/* tb_config.fixpoint = 3 (`-fp auto`): the event-driven fixpoint from this many propagators on.  Measured r04 on the reference's regression instances (2 M nodes, full
+ * grid, scripts/r04_auto_threshold.py): sweeps win at 127 and 161 propagators (4.7e7 / 5.4e7 against 3.0e7 nodes/s), the event fixpoint from 342 on (pat7 2.1x, triangular9 1.3x,
+ * accap_a3 961 propagators 1.5x, pennies5 1.45x; bug4, 1009 propagators, is the exception: 0.75x).  r02 had set 2048. */
+#define TB_AUTO_EVENT_MIN_PROPS 320
+
 typedef struct {
   uint64_t timeout_ms;              /* -t; 0 = none */
   uint64_t or_nodes;                /* -or: number of workgroups; 0 = auto (barebones:538-546) */
@@ -67,8 +72,8 @@ typedef struct {
   int32_t subproblems_power;        /* -sub; -1 = auto.  At most 2^28 - 65536 subproblems per GPU (its share is served through a 28-bit queue
                                        word; the reference's 64-bit counter has no limit, its default is 300 per workgroup); at most 2^40 in all */
   int32_t fixpoint;                 /* 0 = AC1, 1 = WAC1 (config.hpp:22-25), 2 = event-driven WAC1 (this engine), 3 = automatic: event-driven from
-                                       2048 propagators on, WAC1 below (a sweep over a few slices is cheaper than any bookkeeping); all of
-                                       them compute the same fixpoint at every node, hence the same search tree */
+                                       TB_AUTO_EVENT_MIN_PROPS propagators on, WAC1 below (a sweep over a few slices is cheaper than any
+                                       bookkeeping); all of them compute the same fixpoint at every node, hence the same search tree */
   int32_t only_global_memory;       /* -globalmem */
   int32_t verbose;
   int32_t has_eps_strategy;         /* strategy 0 is the EPS strategy (barebones:434,747-750) */

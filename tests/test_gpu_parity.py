@@ -441,10 +441,10 @@ def test_synthetic_search_finds_a_solution(synthetic, fixpoint):
 
 
 def test_automatic_fixpoint_picks_by_size_and_keeps_the_tree():
-    """tb_config.fixpoint = 3 (the CLI default): WAC1 sweeps below 2048 propagators, the event-driven fixpoint from there on;
+    """tb_config.fixpoint = 3 (the CLI default): WAC1 sweeps below TB_AUTO_EVENT_MIN_PROPS (320) propagators, the event-driven fixpoint from there on;
     either way the tree is the oracle's."""
-    small = load("test_data/pat7.fzn")
-    assert small.n_props < 2048
+    small = load("test_data/sudoku_opt3.fzn")
+    assert small.n_props < 320
     has_o, best_o, st_o = pyoracle.solve(small, subproblems_power=0)
     has_g, best_g, st_g = capi.solve(small, capi.make_config(or_nodes=1, subproblems_power=0, timeout_ms=60000, fixpoint=3))
     assert has_g == has_o and all(st_g[k] == st_o[k] for k in ("nodes", "fails", "solutions", "depth_max"))

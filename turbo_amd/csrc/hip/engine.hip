@@ -360,7 +360,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
 
 // tb_config.fixpoint = 3: the engine chooses (same fixpoint, same tree either way)
 void resolve_fixpoint(tb_config* cfg, int32_t n_props) {
-  if (cfg->fixpoint == 3) cfg->fixpoint = n_props >= 2048 ? 2 : 1;
+  if (cfg->fixpoint == 3) cfg->fixpoint = n_props >= TB_AUTO_EVENT_MIN_PROPS ? 2 : 1;
 }
 
 int validate_network(int32_t n_vars, const tb_itv* store, int32_t n_props, const tb_prop* props) {

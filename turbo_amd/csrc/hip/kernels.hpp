@@ -170,11 +170,11 @@ template <class T> __device__ __forceinline__ const T* cst(const T* p) { return 
 template <class T> __device__ __forceinline__ T* glob(T* p) { return (T*)(TB_GLB T*)(size_t)p; }  // (through an integer: a generic -> global -> generic cast pair folds away)
 
 __device__ __forceinline__ const DevProblem& constant_problem(const DevProblem* p) { return *(const DevProblem*)(TB_CST const DevProblem*)(size_t)p; }
+// The watchdog's test (once per 1024 wave-local iterations / 256 rounds or sweeps).  (r04 tried fetching the deadline through an opaque constant-address-space
+// pointer so that it would not be hoisted and spilled: neutral on the event kernels, and WRONG for the kernels that take the problem description by value --
+// its address is then not in constant memory: HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION the first time a watchdog branch ran.)
 __device__ __forceinline__ bool deadline_passed(const DevProblem& P) {
-  TB_CST const DevProblem* p = (TB_CST const DevProblem*)(size_t)&P;
-  asm volatile("" : "+s"(p));
-  const long long d = p->deadline_ticks;  // (a scalar load, in the rare branch)
-  return d != 0 && wall_clock64() > d;
+  return P.deadline_ticks != 0 && wall_clock64() > P.deadline_ticks;
 }
 
 // Wave votes straight on the lane mask a comparison leaves in an SGPR pair (HIP's __any / __ballot take an int: the bool is first
@@ -198,9 +198,6 @@ template <int TB> __device__ __forceinline__ int block_threads() { return TB != 
 // scratch, or in lanes of a spill register) for the whole search, at the expense of the registers the hot loops need.
 __device__ __forceinline__ int here(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int here_s(int x) { asm volatile("" : "+s"(x)); return x; }  // ... a wave-uniform one
-// The watchdog's deadline, fetched where the watchdog looks at it (once per 1024 wave-local iterations / 256 rounds): read through the constant address
-// space the load is loop invariant, gets hoisted to the top of the persistent kernel and its two registers are spilled -- and reloaded in every pass of
-// every run (r04: four v_readlane per channelling pass).  Behind an opaque pointer it stays in the rare branch.
 struct DevProblem;
 __device__ __forceinline__ bool deadline_passed(const DevProblem& P);
 

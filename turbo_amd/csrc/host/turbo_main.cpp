@@ -415,10 +415,10 @@ int main(int argc, char** argv) {
   }
   const int n_vars = tf_num_vars(m), n_props = tf_num_props(m);
   {
-    // what the engine will run on this network (tb_config.fixpoint = 3 resolves to the event-driven fixpoint from 2048 propagators
+    // what the engine will run on this network (tb_config.fixpoint = 3 resolves to the event-driven fixpoint from TB_AUTO_EVENT_MIN_PROPS propagators
     // on, to WAC1 sweeps below: tb_plan.kernel_event / kernel_opt of the session): the event kernels always drop entailed slices,
     // the sweeps only with -entailed_removal
-    const bool event = o.fixpoint == Fixpoint::EVENT || (o.fixpoint == Fixpoint::AUTO && n_props >= 2048);
+    const bool event = o.fixpoint == Fixpoint::EVENT || (o.fixpoint == Fixpoint::AUTO && n_props >= TB_AUTO_EVENT_MIN_PROPS);
     p.s("entailed_prop_removal", (event || o.entailed_removal) ? "by_slice_entailment" : "deactivated");
   }
   const int64_t preprocessing_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - start).count();
