@@ -773,10 +773,11 @@ __device__ __forceinline__ unsigned lean_class_run_t(const RunEnv& E, const int 
   const int kx = kinds & 3, ky = (kinds >> 2) & 3, kz = (kinds >> 4) & 3;  // wave-uniform
   const LeanOperand<C> ox = lean_operand<C>(store, ni, pr.y, act, kx), oy = lean_operand<C>(store, ni, pr.z, act, ky), oz = lean_operand<C>(store, ni, pr.w, act, kz);
   const int vx = ox.v, vy = oy.v, vz = oz.v;  // idle lanes look at variable 0 (a constant) and move nothing
-  // What moved during the run is kept per lane (bits 2k / 2k+1 = lower bound raised / upper bound lowered of operand k, a write count) -- except in
-  // the COMPACT kernels, which keep it as six lane masks in SGPR pairs: there this function is a side path (wordpress7_500: 0.4 of 70 runs per node),
-  // and the per-lane form costs the whole kernel registers: 4.28e7 -> 4.09e7 nodes/s, against 6.4e7 -> 7.8e7 on accap_a3 (COMPACT16), same box.
-  constexpr bool LANE_BITS = C != 1;
+  // What moved during the run is kept per lane (bits 2k / 2k+1 = lower bound raised / upper bound lowered of operand k, a write count), in every layout.
+  // (r03 kept it as six lane masks in SGPR pairs for the COMPACT kernels, where this function is a side path -- 1.4 of 51 runs per node of wordpress7_500 -- because
+  //  the per-lane form cost that kernel 4 % through register allocation then.  r04, with the persistent loop's invariants out of its registers, those masks were what
+  //  spilled around every run: per-lane bits everywhere, 4.76e7 -> 4.93e7 nodes/s same box; the !LANE_BITS form stays for A/B.)
+  constexpr bool LANE_BITS = true;
   int nar_bits = 0;
   unsigned lane_writes = 0;
   unsigned long long mxl = 0, mxu = 0, myl = 0, myu = 0, mzl = 0, mzu = 0;  // (!LANE_BITS) lanes that moved each bound during the run
@@ -996,7 +997,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     TB_REGION(4);
     unsigned* cur = es.dirty + (rounds & 1) * W;
     unsigned* nxt = es.dirty + ((rounds + 1) & 1) * W;
-    bool marked = false;  // wave-uniform: this wave marked something for the next round
+    // "this wave marked something for the next round" goes straight to the round's LDS flag (lane 0, one store per marking run): accumulated in a register it was
+    // a 64-bit lane mask that lived -- and was spilled and reloaded -- through every run of the round
+    auto note_marked = [&](bool did_any) { if (did_any && lane == 0) st(&sh.flag[k], 1); };
 #if defined(TB_TUNING) || TB_DOUBLE_PHASE
     if (reps_of(P, 2) > 1)
       for (int base = 0; base < W; base += 64) {  // the scan once more, without clearing anything
@@ -1170,7 +1173,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                 if (mz) did |= mark_tail(P, nxt, mz, dz, oz, ez, s);
               }
               TB_REGION(46);
-              marked |= wave_any(did);
+              note_marked(wave_any(did));
             }
             TB_REGION(11);
             TB_PROF_MARK(2);
@@ -1322,7 +1325,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               ch = again || (single_pass ? false : nar != 0);
             });
             TB_REGION(16);
-            if (by_range) marked |= wave_any(chain_marked);
+            if (by_range) note_marked(wave_any(chain_marked));
           } else if (C && (key == KEY_EQR_BIC || key == KEY_LEQR_BIC)) {
             // b = (y = k) / b = (y <= k): Boolean truth variable, integer y, constant k (read once per run)
             TB_REGION(17);
@@ -1386,14 +1389,14 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
 #endif
           TB_REGION(18);
 #ifdef TB_TUNING
-          marked |= mark_successors(P, sh, nxt, s, pr, sc, nar_all, (prof && wave == 0) ? sh.bs.dbg : nullptr);
+          note_marked(mark_successors(P, sh, nxt, s, pr, sc, nar_all, (prof && wave == 0) ? sh.bs.dbg : nullptr));
 #else
-          marked |= mark_successors(P, sh, nxt, s, pr, sc, nar_all);
+          note_marked(mark_successors(P, sh, nxt, s, pr, sc, nar_all));
 #endif
           TB_REGION(19);
           TB_PROF_MARK(2);
           TB_PROF_COUNT(4);
-          if (pk(P) & 0x1) marked |= mark_successors(P, sh, nxt, s, pr, sc, nar_all);  // tuning: cost of the marks (idempotent)
+          if (pk(P) & 0x1) note_marked(mark_successors(P, sh, nxt, s, pr, sc, nar_all));  // tuning: cost of the marks (idempotent)
           tc.writes += run_writes;
           {  // profiling (tuning build): 0x400000 counts slice runs instead of iterations; bits 28-31 = 1 + class to count only that class (11 = mixed slices)
             const int want = (knobs(P) >> 28) & 15;
@@ -1411,7 +1414,6 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     }
     for (int rep = reps_of(P, 10); rep > 0; --rep) {  // (tuning: the end of a round twice -- flag, reset, barrier)
     TB_REGION(20);
-    if (lane == 0 && marked) st(&sh.flag[k], 1);
     if (tid == 0) {
       st(&sh.flag[(k + 1) % 3], 0);
       if ((rounds & 255) == 255 && deadline_passed(P)) st(&sh.abort, 1);
