@@ -27,6 +27,14 @@ for fp in event wac1; do
   pass ${fp}_write WRITE_SIZE -- $args
   pass ${fp}_tcc TCC_HIT_sum TCC_MISS_sum -- $args
 done
+for w in accap_a3 trains15; do  # the other LDS-resident BASELINE configurations, event fixpoint
+  args="--workload $w --steps 2 --warmup 1 --side-steps 0 --other-steps 0 --reference-seconds 0 --no-cpu-baseline --fixpoint event"
+  pass ${w}_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU -- $args
+  pass ${w}_sq2 SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_WAIT_INST_LDS -- $args
+  pass ${w}_grbm GRBM_GUI_ACTIVE -- $args
+  pass ${w}_fetch FETCH_SIZE -- $args
+  pass ${w}_write WRITE_SIZE -- $args
+done
 i=0
 for cfg in "wac1 0 hot" "event 0 hot" "wac1 256 hot" "wac1 0 nohot"; do
   set -- $cfg

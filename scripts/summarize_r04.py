@@ -80,7 +80,7 @@ if trace:
 
 rec = {"note": "rocprofv3 --pmc passes of `python3 bench.py --steps 2 --warmup 1 --side-steps 0 --other-steps 0 --reference-seconds 0 --no-cpu-baseline --fixpoint <mode>` "
                "(scripts/profile_r04.sh); one counter set per pass, no tracing domains; per-launch averages of tb::solve_kernel"}
-for fp in ("event", "wac1"):
+for fp, key in (("event", "wordpress7_500/event"), ("wac1", "wordpress7_500/wac1"), ("accap_a3", "accap_a3/event"), ("trains15", "trains15/event")):
     sq1, sq2, ic, grbm, fetch, write, tcc = (counters(f"{fp}_{k}") for k in ("sq1", "sq2", "icache", "grbm", "fetch", "write", "tcc"))
     line = bench_line(f"{fp}_sq1.log")
     if not sq1 or not grbm:
@@ -117,7 +117,7 @@ for fp in ("event", "wac1"):
                   "hbm_gbps": hbm / (ms * 1e-3) / 1e9 if ms else None, "hbm_frac_of_peak": hbm / (ms * 1e-3) / 1e9 / 8000.0 if ms else None,
                   "hbm_note": "memory-side requests of the L2 (Infinity Cache hits included): record stream, snapshot copies, best-store copies and what is left of the "
                               "register spills (scratch); WRITE_SIZE is not calibrated"})
-    rec[f"wordpress7_500/{fp}"] = r
+    rec[key] = r
 
 for i, (fp, what) in enumerate((("wac1", "256 workgroups x 1024 threads, hot tier (19 456 most-read intervals in LDS): the stores (205 MB) inside the Infinity Cache"),
                                 ("event", "256 workgroups x 1024 threads, hot tier, event fixpoint"),
