@@ -1052,9 +1052,11 @@ int32_t plan_records(const tb_config& cfg, const DeviceCaps& caps, int32_t n_var
                      const tb_prop* props, Layout* lay, LaunchPlan* plan, int32_t pinned = -1) {
   if (cfg.fixpoint != 2 || n_props == 0 || plan->mem_kind == TB_MEM_GLOBAL || (cfg.reserved[0] & (0x200000 | 0x20))) return n_props;
   const int32_t n_pad = padded_count(n_props, props, stores);
-  // Worth it where the class-straddling slices are a large share of the network (accap_a3, 16 slices: +21 % nodes/s); on a large
-  // network the few extra slices only add runs (wordpress7_500: -1 %), so the padding must be at least 1/16 of the records.
-  if (n_pad == n_props || (n_pad + 63) / 64 >= 0xfffe || ((long long)(n_pad - n_props) * 16 < n_props && !(cfg.reserved[0] & 0x10))) return n_props;
+  // A slice that mixes two classes takes the generic run (7000 cycles at 7 waves per SIMD on trains15, against 1500 for a class-pure
+  // one).  r03 padded only where the padding was at least 1/16 of the records (wordpress7_500 measured -1 % with it then: the extra
+  // slices added runs); with r04's wake-up filters the runs of the padded network are the cheaper ones everywhere, same box:
+  // wordpress7_500 4.95 -> 5.21e7 nodes/s, trains15 3.58 -> 3.67e7, accap_a3 (padded either way) 8.4e7.  Knob 0x20 switches it off.
+  if (n_pad == n_props || (n_pad + 63) / 64 >= 0xfffe) return n_props;
   Layout l2;
   LaunchPlan p2;
   if (choose_layout(cfg, caps, n_vars, n_stores, stores, n_pad, &l2, &p2, pinned) != TB_OK || p2.mem_kind == TB_MEM_GLOBAL) return n_props;
