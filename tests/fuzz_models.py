@@ -137,13 +137,15 @@ def channelling_network(rng):
     return st, pr
 
 
-def finite_class_network(rng):
+def finite_class_network(rng, scale=1):
     """Random SATISFIABLE network for the lean class runs of the event kernels (kernels.hpp: lean_class_run): a hidden solution, and a
     few classes of constraints that hold in it, each with more than 64 records -- so that the engine's class sort (and padding) makes
     class-pure slices -- over small finite integer domains, Booleans and constants: sums x = y + z (also with a constant sum,
     `0 = y + z`, and with Boolean terms), min / max (also the clause `1 = max(b1, b2)`), y <= z, y > z, y = z, y != z, reified
     comparisons between two variables and against constants, implications between Booleans.  Records share variables (defined
-    variables feed later records), so successor slots overflow and slices re-run each other."""
+    variables feed later records), so successor slots overflow and slices re-run each other.
+    `scale` stretches the integer domains (1: widths up to 40; 8: widths on both sides of 255; 400: values on both sides of +-16383),
+    for the layouts that pack an integer by its width (COMPACT8)."""
     from turbo_amd.frontend import ITV_DTYPE, PROP_DTYPE
     store = [(0, 0), (1, 1), (2, 2)]
     val = [0, 1, 2]
@@ -159,7 +161,7 @@ def finite_class_network(rng):
         return const_of[k]
     ints, bools = [], []
     for _ in range(int(rng.integers(12, 40))):
-        lo = int(rng.integers(-20, 30)); hi = lo + int(rng.integers(0, 40))
+        lo = int(rng.integers(-20 * scale, 30 * scale)); hi = lo + int(rng.integers(0, 40 * min(scale, 8)))
         ints.append(new_var(lo, hi, int(rng.integers(lo, hi + 1))))
     for _ in range(int(rng.integers(10, 40))):
         bools.append(new_var(0, 1, int(rng.integers(0, 2))))
@@ -175,7 +177,7 @@ def finite_class_network(rng):
         return iv() if r < 0.6 else (bv() if r < 0.9 else const(int(rng.integers(-3, 8))))
 
     def defined(v):  # a fresh integer variable whose hidden value is v
-        x = new_var(v - int(rng.integers(0, 12)), v + int(rng.integers(0, 12)), v)
+        x = new_var(v - int(rng.integers(0, 12 * min(scale, 8))), v + int(rng.integers(0, 12 * min(scale, 8))), v)
         ints.append(x)
         return x
 
@@ -222,7 +224,7 @@ def finite_class_network(rng):
             elif kind == "eq_r":
                 y, z = iv(), anyv(); props.append((6, truth(val[y] == val[z]), y, z))
             else:  # leq_rc
-                y = iv(); k = int(rng.integers(-20, 60)); props.append((7, truth(val[y] <= k), y, const(k)))
+                y = iv(); k = int(rng.integers(-20 * scale, 60 * scale)); props.append((7, truth(val[y] <= k), y, const(k)))
     order = rng.permutation(len(props))
     st = np.array(store, dtype=ITV_DTYPE)
     pr = np.array([props[i] for i in order], dtype=PROP_DTYPE)

@@ -25,7 +25,7 @@ KEEP = 0x800000  # tb_config.reserved[0]: keep every workgroup's last store and 
 CASES = {
     "example_wordpress7_500.fzn": (2_000_000, dict(num_blocks=3584, threads_per_block=128, kernel_event=1, kernel_opt=1, mem_kind=1)),
     "accap_a3.fzn": (1_500_000, dict(num_blocks=3584, threads_per_block=128, kernel_event=1, kernel_opt=0, mem_kind=1)),
-    "trains15.fzn": (800_000, dict(num_blocks=1792, threads_per_block=256, kernel_event=1, kernel_opt=2, mem_kind=1)),
+    "trains15.fzn": (800_000, dict(num_blocks=3072, threads_per_block=128, kernel_event=1, kernel_opt=4, mem_kind=1)),
 }
 
 

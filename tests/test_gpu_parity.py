@@ -22,6 +22,7 @@ HEADLINE = ["example_wordpress7_500.fzn", "accap_a3.fzn", "trains15.fzn",
             "unsolved_bugs_data/bigdom.fzn"]  # bigdom: objective near 2^31 (the reference lists it as an unsolved 32-bit hazard)
 COMPACT = 0x100000  # tb_config.reserved[0]: force the 2-bit Boolean store layout of the event kernels
 COMPACT16 = COMPACT | 0x10000000  # ... and its 16-bit integer tier when every non-Boolean variable fits (COMPACT otherwise)
+COMPACT8 = COMPACT | 0x30000000  # ... and its two-byte tier for integers at most 255 wide (r04; COMPACT16 or COMPACT when not eligible)
 
 
 def load(rel):
@@ -74,7 +75,7 @@ def check_batch(tcn, stores, **cfg):
 
 
 @pytest.mark.parametrize("rel", [r[0] for r in ROWS] + HEADLINE)
-@pytest.mark.parametrize("fixpoint,debug", [(0, 0), (1, 0), (2, 0), (2, COMPACT), (2, COMPACT16)], ids=["ac1", "wac1", "event", "event_compact", "event_compact16"])
+@pytest.mark.parametrize("fixpoint,debug", [(0, 0), (1, 0), (2, 0), (2, COMPACT), (2, COMPACT16), (2, COMPACT8)], ids=["ac1", "wac1", "event", "event_compact", "event_compact16", "event_compact8"])
 def test_root_fixpoint_bit_exact(rel, fixpoint, debug):
     tcn = load(rel)
     check_batch(tcn, tcn.store[None, :], fixpoint=fixpoint, debug=debug)
@@ -85,7 +86,7 @@ def test_root_fixpoint_bit_exact(rel, fixpoint, debug):
 @pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pennies5.fzn",
                                  "test_data/triangular9.fzn", "test_data/bug4.fzn", "accap_a3.fzn", "unsolved_bugs_data/bigdom.fzn"])
 @pytest.mark.parametrize("mode", ["wac1", "ac1", "globalmem", "t1024", "event", "event_globalmem", "event_t1024",
-                                  "event_compact", "event_compact_globalmem", "event_compact_t1024", "wac1_rm", "ac1_rm", "globalmem_rm"])
+                                  "event_compact", "event_compact_globalmem", "event_compact_t1024", "wac1_rm", "ac1_rm", "globalmem_rm", "event_compact8"])
 def test_random_nodes_bit_exact(rel, mode):
     tcn = load(rel)
     stores = random_nodes(tcn, 48, seed=zlib.crc32(rel.encode()) % 1000)
@@ -93,7 +94,7 @@ def test_random_nodes_bit_exact(rel, mode):
            "t1024": dict(fixpoint=1, threads_per_block=1024), "event": dict(fixpoint=2),
            "event_globalmem": dict(fixpoint=2, only_global_memory=1), "event_t1024": dict(fixpoint=2, threads_per_block=1024),
            "event_compact": dict(fixpoint=2, debug=COMPACT), "event_compact_globalmem": dict(fixpoint=2, only_global_memory=1, debug=COMPACT),
-           "event_compact_t1024": dict(fixpoint=2, threads_per_block=1024, debug=COMPACT),
+           "event_compact_t1024": dict(fixpoint=2, threads_per_block=1024, debug=COMPACT), "event_compact8": dict(fixpoint=2, debug=COMPACT8),
            "wac1_rm": dict(fixpoint=1, entailed_prop_removal=1), "ac1_rm": dict(fixpoint=0, entailed_prop_removal=1),
            "globalmem_rm": dict(fixpoint=1, only_global_memory=1, entailed_prop_removal=1)}[mode]
     check_batch(tcn, stores, **cfg)
@@ -107,8 +108,8 @@ def test_wordpress_nodes_bit_exact():
     check_batch(tcn, stores, fixpoint=2, debug=0x80000)  # the same without it
 
 
-@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT), (1, "rm"), (0, "rm"), (2, COMPACT16), (1, COMPACT16)],
-                         ids=["wac1", "event", "event_compact", "wac1_rm", "ac1_rm", "event_compact16", "wac1_compact16"])
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT), (1, "rm"), (0, "rm"), (2, COMPACT16), (1, COMPACT16), (2, COMPACT8)],
+                         ids=["wac1", "event", "event_compact", "wac1_rm", "ac1_rm", "event_compact16", "wac1_compact16", "event_compact8"])
 @pytest.mark.parametrize("rel,expected", FAST)
 def test_sequential_tree_identical(rel, expected, fixpoint, debug):
     rm, debug = (1, 0) if debug == "rm" else (0, debug)
@@ -125,8 +126,8 @@ def test_sequential_tree_identical(rel, expected, fixpoint, debug):
 
 @pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pat7.fzn", "test_data/sudoku_opt_p0.fzn"])
 @pytest.mark.parametrize("power", [3, 6])
-@pytest.mark.parametrize("fixpoint,levels,debug", [(1, 0, 0), (2, 0, 0), (2, 1, 0), (2, 3, 0), (2, 0, COMPACT), (2, 1, COMPACT), (1, 0, "rm"), (1, 1, "rm")],
-                         ids=["wac1", "event", "event_recompute", "event_3levels", "event_compact", "event_compact_recompute", "wac1_rm", "wac1_rm_recompute"])
+@pytest.mark.parametrize("fixpoint,levels,debug", [(1, 0, 0), (2, 0, 0), (2, 1, 0), (2, 3, 0), (2, 0, COMPACT), (2, 1, COMPACT), (1, 0, "rm"), (1, 1, "rm"), (2, 0, COMPACT8), (2, 1, COMPACT8)],
+                         ids=["wac1", "event", "event_recompute", "event_3levels", "event_compact", "event_compact_recompute", "wac1_rm", "wac1_rm_recompute", "event_compact8", "event_compact8_recompute"])
 def test_sequential_eps_identical(rel, power, fixpoint, levels, debug):
     rm, debug = (1, 0) if debug == "rm" else (0, debug)
     """One workgroup walking 2^d subproblems in index order == the oracle's sequential dive-and-solve
@@ -140,7 +141,7 @@ def test_sequential_eps_identical(rel, power, fixpoint, levels, debug):
     np.testing.assert_array_equal(best_g, best_o)
 
 
-@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT), (1, "rm"), (2, COMPACT16)], ids=["wac1", "event", "event_compact", "wac1_rm", "event_compact16"])
+@pytest.mark.parametrize("fixpoint,debug", [(1, 0), (2, 0), (2, COMPACT), (1, "rm"), (2, COMPACT16), (2, COMPACT8)], ids=["wac1", "event", "event_compact", "wac1_rm", "event_compact16", "event_compact8"])
 @pytest.mark.parametrize("rel,expected", ROWS)
 def test_parallel_objective_matches_known_answer(rel, expected, fixpoint, debug):
     rm, debug = (1, 0) if debug == "rm" else (0, debug)
@@ -219,7 +220,7 @@ def test_random_networks_with_wide_and_infinite_domains(mode):
                 np.testing.assert_array_equal(got[i], exp, err_msg=f"seed {seed} store {i}")
 
 
-@pytest.mark.parametrize("mode", ["wac1", "event", "event_compact", "event_compact_unsorted", "event_compact16"])
+@pytest.mark.parametrize("mode", ["wac1", "event", "event_compact", "event_compact_unsorted", "event_compact16", "event_compact8"])
 def test_channelling_networks_bit_exact(mode):
     """Fuzz of the jointly evaluated channelling slices: consecutive constants (bit-scan walks), gaps and duplicates (stepping
     walks), shared truth variables (confirmation pass), several groups per slice, readers dealt over a group's lanes, successor
@@ -228,7 +229,8 @@ def test_channelling_networks_bit_exact(mode):
     # (unsorted: the records keep the caller's order inside a class, test knob 0x8000000 -- a y may come back after another one
     #  inside a slice, which the joint evaluation does not handle: such slices must fall back to the generic run)
     cfg = {"wac1": dict(fixpoint=1), "event": dict(fixpoint=2), "event_compact": dict(fixpoint=2, debug=COMPACT),
-           "event_compact_unsorted": dict(fixpoint=2, debug=COMPACT | 0x8000000), "event_compact16": dict(fixpoint=2, debug=COMPACT16)}[mode]
+           "event_compact_unsorted": dict(fixpoint=2, debug=COMPACT | 0x8000000), "event_compact16": dict(fixpoint=2, debug=COMPACT16),
+           "event_compact8": dict(fixpoint=2, debug=COMPACT8)}[mode]
     for seed in range(60):
         rng = np.random.default_rng(1000 + seed)
         store, props = channelling_network(rng)
@@ -260,14 +262,15 @@ def test_channelling_networks_bit_exact(mode):
 
 
 @pytest.mark.parametrize("chunk", range(3))
-@pytest.mark.parametrize("mode", ["event_compact", "event_compact16", "event_compact_globalmem", "event_compact_4waves", "event"])
+@pytest.mark.parametrize("mode", ["event_compact", "event_compact16", "event_compact8", "event_compact8_4waves", "event_compact_globalmem", "event_compact_4waves", "event"])
 def test_element_models_tree_identical(chunk, mode):
     """Fuzz of the r04 wake-up filters (engine.hip: Chains, conditional wake-up in pack_succ): models shaped like wordpress7_500 -- index
     variables over 70-260 positions read by several element constraints -- whose index chains span several slices.  One workgroup must
     walk the oracle's tree, node for node, up to a node budget, and stop on the same store, with one subproblem and with 2^4; the
     root and random nodes must reach the oracle's fixpoint."""
     from fuzz_models import element_model
-    cfg = {"event_compact": dict(debug=COMPACT), "event_compact16": dict(debug=COMPACT16), "event_compact_globalmem": dict(debug=COMPACT, only_global_memory=1),
+    cfg = {"event_compact": dict(debug=COMPACT), "event_compact16": dict(debug=COMPACT16), "event_compact8": dict(debug=COMPACT8),
+           "event_compact8_4waves": dict(debug=COMPACT8, threads_per_block=256), "event_compact_globalmem": dict(debug=COMPACT, only_global_memory=1),
            "event_compact_4waves": dict(debug=COMPACT, threads_per_block=256), "event": dict()}[mode]
     dbg = cfg.pop("debug", 0)
     for seed in range(3000 + chunk * 8, 3000 + chunk * 8 + 8):
@@ -320,7 +323,7 @@ def test_compact_slab_in_global_memory_with_a_ragged_implication_slice():
                 np.testing.assert_array_equal(got[i], exp, err_msg=str(i))
 
 
-@pytest.mark.parametrize("mode", ["wac1", "event", "event_compact", "event_globalmem", "event_compact_globalmem", "event_compact16", "event_compact16_globalmem", "wac1_compact", "wac1_compact16"])
+@pytest.mark.parametrize("mode", ["wac1", "event", "event_compact", "event_globalmem", "event_compact_globalmem", "event_compact16", "event_compact16_globalmem", "wac1_compact", "wac1_compact16", "event_compact8"])
 def test_class_pure_finite_networks_bit_exact(mode):
     """Fuzz of the lean runs of the event kernels: class-pure slices over finite domains in the plain and in the compact layout
     (lean_class_run), Boolean implication slices read from their successor records alone (compact), stores in LDS and in
@@ -329,7 +332,7 @@ def test_class_pure_finite_networks_bit_exact(mode):
     cfg = {"wac1": dict(fixpoint=1), "event": dict(fixpoint=2), "event_compact": dict(fixpoint=2, debug=COMPACT),
            "event_globalmem": dict(fixpoint=2, only_global_memory=1), "event_compact_globalmem": dict(fixpoint=2, debug=COMPACT, only_global_memory=1),
            "event_compact16": dict(fixpoint=2, debug=COMPACT16), "event_compact16_globalmem": dict(fixpoint=2, debug=COMPACT16, only_global_memory=1),
-           "wac1_compact": dict(fixpoint=1, debug=COMPACT), "wac1_compact16": dict(fixpoint=1, debug=COMPACT16)}[mode]
+           "wac1_compact": dict(fixpoint=1, debug=COMPACT), "wac1_compact16": dict(fixpoint=1, debug=COMPACT16), "event_compact8": dict(fixpoint=2, debug=COMPACT8)}[mode]
     for seed in range(60):
         rng = np.random.default_rng(5000 + seed)
         store, props = finite_class_network(rng)

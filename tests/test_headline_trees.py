@@ -22,7 +22,7 @@ COUNTERS = ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems"
 KEEP_LAST = 0x800000  # tb_config.reserved[0]: keep the store every workgroup stopped on
 # (threads per workgroup, event kernel, store layout, memory kind) of bench.py's sessions on an MI355X -- the grid differs (one workgroup here), the
 # kernel instantiation must not (tests/test_gpu_fullgrid_paths.py runs the full grids)
-BENCH_PLANS = {"example_wordpress7_500.fzn/simplified": (128, 1, 1, 1), "accap_a3.fzn/simplified": (128, 1, 0, 1), "trains15.fzn/simplified": (256, 1, 2, 1)}
+BENCH_PLANS = {"example_wordpress7_500.fzn/simplified": (128, 1, 1, 1), "accap_a3.fzn/simplified": (128, 1, 0, 1), "trains15.fzn/simplified": (128, 1, 4, 1)}
 
 
 def sha(a) -> str:
@@ -71,15 +71,16 @@ def test_oracle_reproduces_the_headline_vectors(key):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["wac1", "event", "event_recompute", "wac1_rm", "event_padded", "event_unpadded"])
+@pytest.mark.parametrize("mode", ["wac1", "event", "event_recompute", "wac1_rm", "event_padded", "event_unpadded", "event_no_compact8"])
 @pytest.mark.parametrize("key", sorted(GOLDEN))
 def test_engine_reproduces_the_headline_trees(key, mode):
     """GPU: the same prefix of the tree through the C-ABI, without running the oracle.
-    (event_padded / event_unpadded: every class of records padded to whole slices, or never -- the engine decides by the size of
-    the network otherwise; test knobs 0x10 / 0x20 of tb_config.reserved[0].)"""
+    (event_padded / event_unpadded: every class of records padded to whole slices, or never -- the engine pads when the store stays in
+    LDS with the padded records; test knobs 0x10 / 0x20 of tb_config.reserved[0].  event_no_compact8: sign bit, the two-byte integer tier
+    never taken -- trains15 then runs on COMPACT16 slabs as in r03.)"""
     cfg = {"wac1": dict(fixpoint=1), "event": dict(fixpoint=2), "event_recompute": dict(fixpoint=2, snapshot_levels=1),
            "wac1_rm": dict(fixpoint=1, entailed_prop_removal=1), "event_padded": dict(fixpoint=2, debug_extra=0x10),
-           "event_unpadded": dict(fixpoint=2, debug_extra=0x20)}[mode]
+           "event_unpadded": dict(fixpoint=2, debug_extra=0x20), "event_no_compact8": dict(fixpoint=2, debug_extra=-0x80000000)}[mode]
     extra = cfg.pop("debug_extra", 0)
     tcn = network(key)  # simplified: root fixpoints by the engine itself (tb_propagate) -- the network must come out identical
     check_network(tcn, GOLDEN[key])

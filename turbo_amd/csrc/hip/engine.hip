@@ -97,15 +97,23 @@ struct Layout {
   bool renumbered = false;  // plain layout under a locality permutation (renumber_for_locality: an experiment, TB_GLOBAL_RENUMBER)
   bool compact = false;
   bool c16 = false;  // COMPACT16: the non-Boolean variables as two 16-bit bounds in one word (kernels.hpp: load_dom<2>)
+  // COMPACT8 (kernels.hpp: layout 4): on top of COMPACT16, an integer whose domain is at most 255 wide over the whole batch takes two bytes, its bounds
+  // relative to `base` (the lowest lower bound of the batch).  The wide integers are numbered first (internal ids 0 .. n_wide - 1, a 32-bit word each),
+  // the narrow ones behind them (halfword id + n_wide of the slab).
+  bool c8 = false;
+  int n_wide = 0;
+  std::vector<int> base;  // [n_int] (0 for the wide ones)
+  // what the device calls a reference to variable i: the id, and for a narrow integer of COMPACT8 its base in bits 16-30
+  int ref(int i) const { return (c8 && i >= n_wide && i < n_int) ? (i | ((base[(size_t)i] + 16384) << 16)) : i; }
+  int dev_n_int() const { return c8 ? (n_int | (n_wide << 16)) : n_int; }  // DevProblem::n_int
   int n_vars = 0, n_int = 0, n_bool = 0;
   int n_out = 0;               // constants kept out of the slab: internal ids n_int + n_bool .. n_vars - 1
   std::vector<int> out_value;  // [n_out] their values
   int n_slab() const { return n_int + n_bool; }
   std::vector<int> perm, inv;  // perm[caller's id] = internal id, inv = its inverse
   int bool_words() const { return (n_bool + 15) / 16; }
-  int int_bytes() const { return c16 ? 4 : 8; }
-  int bool_word0() const { return c16 ? n_int : 2 * n_int; }  // first Boolean word, in 32-bit words from the start of the slab
-  int unent_off() const { return n_int * int_bytes() + bool_words() * 4; }
+  int bool_word0() const { return c8 ? (n_int + n_wide + 1) / 2 : (c16 ? n_int : 2 * n_int); }  // first Boolean word, in 32-bit words from the start of the slab
+  int unent_off() const { return (bool_word0() + bool_words()) * 4; }
   // slab size in 8-byte units: the domains, then the "not entailed" marks of the slices -- a byte per slice for the sweeps with entailed-slice
   // removal (every wave writes its own), a bit per slice for the event-driven fixpoint (dirty_words 32-bit words)
   int vext(int n_slices, bool event) const {
@@ -115,7 +123,7 @@ struct Layout {
 };
 
 // (`pinned`: a variable the kernels address by index outside the records -- the objective -- stays in the slab; `outs`: constants leave it)
-Layout make_layout(int32_t n_vars, int32_t n_stores, const tb_itv* stores, bool compact, bool want_c16 = false, bool outs = false, int32_t pinned = -1) {
+Layout make_layout(int32_t n_vars, int32_t n_stores, const tb_itv* stores, bool compact, bool want_c16 = false, bool outs = false, int32_t pinned = -1, bool want_c8 = false) {
   Layout L;
   L.n_vars = n_vars; L.compact = compact;
   L.perm.resize((size_t)n_vars); L.inv.resize((size_t)n_vars);
@@ -137,8 +145,30 @@ Layout make_layout(int32_t n_vars, int32_t n_stores, const tb_itv* stores, bool 
         is_out[(size_t)v] = c ? 1 : 0;
       }
   }
+  // hull of every variable over the batch
+  auto hull_of = [&](int32_t v) {
+    tb_itv h = stores[v];
+    for (int32_t k = 1; k < n_stores; ++k) { const tb_itv d = stores[(size_t)k * (size_t)n_vars + (size_t)v]; h.lb = std::min(h.lb, d.lb); h.ub = std::max(h.ub, d.ub); }
+    return h;
+  };
+  // COMPACT8: all integers within 16 bits, at least one of them narrow (bases within +-16383, ids within 16 bits)
+  std::vector<char> is_narrow((size_t)n_vars, 0);
+  bool c8 = compact && want_c8 && n_stores > 0 && n_vars < 0xffff;
+  if (c8) {
+    int narrow = 0;
+    for (int32_t v = 0; v < n_vars && c8; ++v) {
+      if (is_bool[(size_t)v] || is_out[(size_t)v]) continue;
+      const tb_itv h = hull_of(v);
+      if (h.lb < -32768 || h.ub > 32767 || h.lb > h.ub) { c8 = false; break; }
+      if (h.ub - h.lb <= 255 && h.lb >= -16383 && h.lb <= 16382) { is_narrow[(size_t)v] = 1; ++narrow; }
+    }
+    if (narrow == 0) c8 = false;
+    if (!c8) std::fill(is_narrow.begin(), is_narrow.end(), 0);
+  }
   int next = 0;
-  for (int32_t v = 0; v < n_vars; ++v) if (!is_bool[(size_t)v] && !is_out[(size_t)v]) L.perm[(size_t)v] = next++;
+  if (c8) for (int32_t v = 0; v < n_vars; ++v) if (!is_bool[(size_t)v] && !is_out[(size_t)v] && !is_narrow[(size_t)v]) L.perm[(size_t)v] = next++;
+  L.n_wide = c8 ? next : 0;
+  for (int32_t v = 0; v < n_vars; ++v) if (!is_bool[(size_t)v] && !is_out[(size_t)v] && (!c8 || is_narrow[(size_t)v])) L.perm[(size_t)v] = next++;
   L.n_int = next;
   for (int32_t v = 0; v < n_vars; ++v) if (is_bool[(size_t)v]) L.perm[(size_t)v] = next++;
   L.n_bool = next - L.n_int;
@@ -146,7 +176,17 @@ Layout make_layout(int32_t n_vars, int32_t n_stores, const tb_itv* stores, bool 
   L.n_out = n_vars - L.n_int - L.n_bool;
   for (int32_t v = 0; v < n_vars; ++v) L.inv[(size_t)L.perm[(size_t)v]] = v;
   if (L.n_bool == 0) L.compact = false;
-  if (L.compact && want_c16) {  // every non-Boolean variable of the slab within -32768..32767 in every store of the batch
+  if (L.compact && c8) {
+    L.c8 = true;
+    L.base.assign((size_t)L.n_int, 0);
+    for (int32_t v = 0; v < n_vars; ++v) if (is_narrow[(size_t)v]) L.base[(size_t)L.perm[(size_t)v]] = hull_of(v).lb;
+  } else if (c8) {  // (no Boolean at all: the layout falls back to the plain one, in the caller's numbering)
+    L.n_wide = 0;
+    int nx = 0;
+    for (int32_t v = 0; v < n_vars; ++v) if (!is_bool[(size_t)v] && !is_out[(size_t)v]) L.perm[(size_t)v] = nx++;
+    for (int32_t v = 0; v < n_vars; ++v) L.inv[(size_t)L.perm[(size_t)v]] = v;
+  }
+  if (L.compact && want_c16 && !L.c8) {  // every non-Boolean variable of the slab within -32768..32767 in every store of the batch
     bool ok = true;
     for (int32_t v = 0; v < n_vars && ok; ++v) {
       if (is_bool[(size_t)v] || is_out[(size_t)v]) continue;
@@ -161,11 +201,16 @@ Layout make_layout(int32_t n_vars, int32_t n_stores, const tb_itv* stores, bool 
 void encode_slab(const Layout& L, const tb_itv* orig, unsigned char* slab) {
   tb_itv* ints = reinterpret_cast<tb_itv*>(slab);
   unsigned* ints16 = reinterpret_cast<unsigned*>(slab);
-  unsigned* words = reinterpret_cast<unsigned*>(slab + (size_t)L.n_int * (size_t)L.int_bytes());
+  unsigned short* halves = reinterpret_cast<unsigned short*>(slab);
+  unsigned* words = reinterpret_cast<unsigned*>(slab) + L.bool_word0();
   for (int v = 0; v < L.n_vars; ++v) {
     const int i = L.perm[(size_t)v];
     if (i < L.n_int) {
-      if (L.c16) ints16[i] = ((unsigned)orig[v].lb & 0xffffu) | ((unsigned)orig[v].ub << 16);
+      if (L.c8 && i >= L.n_wide) {
+        // (a store of the batch that is already empty, or outside its own hull, cannot happen: the hull is taken over these very stores)
+        const int lo = std::min(255, std::max(0, orig[v].lb - L.base[(size_t)i])), hi = std::min(255, std::max(0, orig[v].ub - L.base[(size_t)i]));
+        halves[i + L.n_wide] = (unsigned short)(lo | (hi << 8));
+      } else if (L.c16 || L.c8) ints16[i] = ((unsigned)orig[v].lb & 0xffffu) | ((unsigned)orig[v].ub << 16);
       else ints[i] = orig[v];
       continue;
     }
@@ -178,10 +223,15 @@ void encode_slab(const Layout& L, const tb_itv* orig, unsigned char* slab) {
 void decode_slab(const Layout& L, const unsigned char* slab, tb_itv* orig_out) {
   const tb_itv* ints = reinterpret_cast<const tb_itv*>(slab);
   const unsigned* ints16 = reinterpret_cast<const unsigned*>(slab);
-  const unsigned* words = reinterpret_cast<const unsigned*>(slab + (size_t)L.n_int * (size_t)L.int_bytes());
+  const unsigned short* halves = reinterpret_cast<const unsigned short*>(slab);
+  const unsigned* words = reinterpret_cast<const unsigned*>(slab) + L.bool_word0();
   for (int i = 0; i < L.n_vars; ++i) {
     tb_itv d;
-    if (i < L.n_int) { if (L.c16) { d.lb = (int)(short)(ints16[i] & 0xffffu); d.ub = (int)ints16[i] >> 16; } else d = ints[i]; }
+    if (i < L.n_int) {
+      if (L.c8 && i >= L.n_wide) { const unsigned h = halves[i + L.n_wide]; d.lb = L.base[(size_t)i] + (int)(h & 0xffu); d.ub = L.base[(size_t)i] + (int)(h >> 8); }
+      else if (L.c16 || L.c8) { d.lb = (int)(short)(ints16[i] & 0xffffu); d.ub = (int)ints16[i] >> 16; }
+      else d = ints[i];
+    }
     else if (i >= L.n_slab()) { d.lb = d.ub = L.out_value[(size_t)(i - L.n_slab())]; }
     else { const int b = i - L.n_int; const unsigned bits = (words[b >> 4] >> ((b & 15) * 2)) & 3u; d.lb = (int)(bits & 1u); d.ub = 1 - (int)(bits >> 1); }
     orig_out[L.inv[(size_t)i]] = d;
@@ -265,7 +315,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   // stack (stores, snapshots) starts 16-byte aligned and copies as 16-byte words
   const int n_slices = (n_props + 63) / 64, dirty_words = (n_slices + 31) / 32, vext = lay.vext(n_slices, event);
   p.n_slices = n_slices; p.dirty_words = dirty_words; p.vext = vext;
-  p.compact = lay.compact ? (lay.c16 ? 2 : 1) : 0; p.n_int = lay.n_int; p.unent_off = lay.unent_off();
+  p.compact = lay.compact ? (lay.c8 ? 4 : (lay.c16 ? 2 : 1)) : 0; p.n_int = lay.dev_n_int(); p.unent_off = lay.unent_off();
   // store slab = domains + one entailment byte per 64-propagator slice; the dirty bitmap and the change list of the
   // event-driven fixpoint always live in LDS (an overflowing change list falls back to running every slice)
   // (256 entries: a node is entered with a handful of changed variables -- the decision, the objective bound, the decisions replayed
@@ -594,7 +644,7 @@ Chains find_chains(int32_t n_vars, int32_t n_props, const tb_prop* props, const 
 // readers interested in "upper bound lowered", the z slots those interested in "lower bound raised" -- already filtered: no interest check
 // at run time -- and bit 17 / bit 2 say that more than two were interested (walk the variable's adjacency record).
 std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacency& adj, const std::vector<int4>& records, const std::vector<int>& value, bool deal_groups,
-                            const Chains& chains, int n_int = 0, bool lean = false, int bool_word0 = 0, bool cond_wake = false) {
+                            const Chains& chains, int n_int = 0, bool lean = false, int bool_word0 = 0, bool cond_wake = false, const Layout* c8 = nullptr) {
   std::vector<int4> out(((size_t)n_props + 63) / 64 * 64, make_int4(-1, -1, -1, 0));
   // Conditional wake-up of a chain by "b became false" (lean implication records, `cond_wake`): the rule of `b = (y = k)` reacts to a false b only when k
   // sits on a bound of y, and the lane that lowers b can test that itself (one LDS read) -- when b is the truth variable of exactly one chain record.
@@ -694,7 +744,9 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
         // bound of Y at that moment (whoever moves a bound of Y onto kv later wakes that slice for it)
         if (k == 1 && n == 1 && !over && !chan_rec.empty() && chan_rec[(size_t)vs[1]] >= 0) {
           const int r = chan_rec[(size_t)vs[1]];
-          const int Y = props[r].y, kv = value[(size_t)props[r].z];
+          const int Y = props[r].y;
+          int kv = value[(size_t)props[r].z];
+          if (c8 != nullptr && Y >= c8->n_wide && Y < c8->n_int) kv -= c8->base[(size_t)Y];  // COMPACT8: the run compares with the bytes of a narrow Y as they are stored
           if ((unsigned)(r / 64) == o[0] && Y >= 0 && Y < n_int && Y < 0xffff && kv >= -32768 && kv <= 32767) {
             slots[1] = o[0] | ((unsigned)Y << 16);
             fl |= (int)((((unsigned)kv & 0x3fffu) << 3) | ((((unsigned)kv >> 14) & 3u) << 28) | (1u << 30));
@@ -818,7 +870,8 @@ int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
     else if ((opt) == HOT_SWEEP_OPT && !(event)) FN<TB_MEM_GLOBAL, 1024, false, 6> __VA_ARGS__; \
     else if ((tmax) == 128) {                                                                \
       const int dk_mem = (mem), dk_opt = (opt);                                         \
-      if (dk_opt == 2) DISPATCH_MEM(FN, 128, true, 2, dk_mem, __VA_ARGS__);             \
+      if (dk_opt == 4) FN<TB_MEM_STORE_SHARED, 128, true, 4> __VA_ARGS__;               /* COMPACT8: LDS only */ \
+      else if (dk_opt == 2) DISPATCH_MEM(FN, 128, true, 2, dk_mem, __VA_ARGS__);        \
       else if (dk_opt) DISPATCH_MEM(FN, 128, true, 1, dk_mem, __VA_ARGS__);             \
       else DISPATCH_MEM(FN, 128, true, 0, dk_mem, __VA_ARGS__);                         \
     } else DISPATCH_KERNEL_WIDE(FN, mem, tmax, event, opt, __VA_ARGS__);                \
@@ -828,7 +881,8 @@ int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
     const int dk_mem = (mem), dk_tmax = (tmax), dk_opt = (opt);                         \
     const bool dk_event = (event);                                                      \
     if (dk_tmax <= 256) {                                                               \
-      if (dk_event && dk_opt == 2) DISPATCH_MEM(FN, 256, true, 2, dk_mem, __VA_ARGS__); \
+      if (dk_event && dk_opt == 4) FN<TB_MEM_STORE_SHARED, 256, true, 4> __VA_ARGS__;   \
+      else if (dk_event && dk_opt == 2) DISPATCH_MEM(FN, 256, true, 2, dk_mem, __VA_ARGS__); \
       else if (dk_event && dk_opt) DISPATCH_MEM(FN, 256, true, 1, dk_mem, __VA_ARGS__); \
       else if (dk_event) DISPATCH_MEM(FN, 256, true, 0, dk_mem, __VA_ARGS__);           \
       else if (dk_opt == 4) DISPATCH_MEM(FN, 256, false, 4, dk_mem, __VA_ARGS__);       \
@@ -866,20 +920,35 @@ int choose_layout(const tb_config& cfg, const DeviceCaps& caps, int32_t n_vars, 
   // 2.10e6 nodes/s plain (256 x 1024) against 1.81e6 compact (1280 x 256); trains15 6.77e6 against 7.44e6.
   const bool sweeps_opt_in = cfg.fixpoint != 2 && !cfg.entailed_prop_removal && (cfg.reserved[0] & 0x100000);
   if (rc != TB_OK || (cfg.fixpoint != 2 && !sweeps_opt_in) || (cfg.reserved[0] & 0x80000)) return rc;
-  const bool outs = !(cfg.reserved[0] & 0x40000000);  // constants out of the slab (0x40000000: keep them in, A/B runs and tests)
+#ifdef TB_TUNING  // the run census (0x400000) selects a class with bits 28-31: not layout knobs then
+  const int lk = (cfg.reserved[0] & 0x400000) ? 0 : cfg.reserved[0];
+#else
+  const int lk = cfg.reserved[0];
+#endif
+  const bool outs = !(lk & 0x40000000);  // constants out of the slab (0x40000000: keep them in, A/B runs and tests)
   Layout lc = make_layout(n_vars, n_stores, stores, true, false, outs, pinned);
   if (!lc.compact) return rc;
   LaunchPlan pc;
   if ((rc = plan_launch(cfg, caps, lc, n_props, &pc)) != TB_OK) return rc;
   // COMPACT16 (reserved[0] & 0x10000000 always when eligible, 0x20000000 never): half the bytes per integer variable.  Taken when it
   // puts more workgroups on a CU than COMPACT does, or brings the slab into LDS at all -- trains15: 50 KB -> 29 KB per workgroup.
-  if (!(cfg.reserved[0] & 0x20000000)) {
+  if (!(lk & 0x20000000) || (lk & 0x30000000) == 0x30000000) {
     Layout l16 = make_layout(n_vars, n_stores, stores, true, true, outs, pinned);
     LaunchPlan p16;
     if (l16.c16 && plan_launch(cfg, caps, l16, n_props, &p16) == TB_OK) {
       const bool better = (pc.mem_kind == TB_MEM_GLOBAL && p16.mem_kind != TB_MEM_GLOBAL) ||
                           (pc.mem_kind != TB_MEM_GLOBAL && p16.mem_kind != TB_MEM_GLOBAL && p16.blocks_per_cu > pc.blocks_per_cu);
-      if (better || (cfg.reserved[0] & 0x10000000)) { lc = std::move(l16); pc = p16; }
+      if (better || (lk & 0x30000000) == 0x10000000) { lc = std::move(l16); pc = p16; }
+    }
+  }
+  // COMPACT8 (event kernels; both COMPACT16 bits set: always when eligible, sign bit: never): two bytes per narrow integer.  Taken when it puts more
+  // workgroups on a CU -- trains15: 20.7 KB -> 11.6 KB per slab, seven four-wave workgroups -> eleven two-wave ones.
+  if (cfg.fixpoint == 2 && !(lk & (int)0x80000000u)) {
+    Layout l8 = make_layout(n_vars, n_stores, stores, true, false, outs, pinned, true);
+    LaunchPlan p8;
+    if (l8.c8 && plan_launch(cfg, caps, l8, n_props, &p8) == TB_OK && p8.mem_kind == TB_MEM_STORE_SHARED && p8.tmax <= 256) {
+      const bool better = pc.mem_kind == TB_MEM_GLOBAL || p8.blocks_per_cu * p8.threads > pc.blocks_per_cu * pc.threads || (p8.threads < pc.threads && p8.blocks_per_cu * p8.threads * 4 >= pc.blocks_per_cu * pc.threads * 3);
+      if (better || (lk & 0x30000000) == 0x30000000) { lc = std::move(l8); pc = p8; }
     }
   }
   const bool forced = (cfg.reserved[0] & 0x100000) != 0;
@@ -1072,6 +1141,19 @@ std::vector<int> real_lanes(const std::vector<tb_prop>& props, int n_slices) {
   return r;
 }
 
+// The records as the device reads them: in the COMPACT8 layout every operand that is a narrow integer becomes a reference carrying its base
+// (Layout::ref); the host-side analyses (adjacency, chains, successor records) work on the plain ids.
+std::vector<int4> device_records(const std::vector<int4>& packed, const Layout& lay) {
+  if (!lay.c8) return packed;
+  std::vector<int4> out = packed;
+  for (int4& r : out) {
+    if (r.y >= 0) r.y = lay.ref(r.y);
+    if (r.z >= 0) r.z = lay.ref(r.z);
+    if (r.w >= 0) r.w = lay.ref(r.w);
+  }
+  return out;
+}
+
 // Tables of the event-driven fixpoint (successor records, slice infos, variable adjacency): built from the packed records and uploaded.
 // `root`: the first store of the batch in the internal numbering (finite-domain test of the plain lean runs).
 int upload_event_tables(DevBuffers& bufs, DevProblem& P, const tb_config& cfg, const LaunchPlan& plan, const Layout& lay, int32_t n_rec,
@@ -1088,7 +1170,7 @@ int upload_event_tables(DevBuffers& bufs, DevProblem& P, const tb_config& cfg, c
   // (TB_NO_CHAIN_RANGE / TB_NO_COND_WAKE: A/B runs of the two r04 wake-up filters)
   const bool joint = !(cfg.reserved[0] & 0x4000000);  // channelling slices take the joint run
   const Chains chains = find_chains((int32_t)adj.lists.size(), n_rec, net_props.data(), packed, value, root, lay.compact && joint && std::getenv("TB_NO_CHAIN_RANGE") == nullptr);
-  std::vector<int4> succ = pack_succ(n_rec, net_props.data(), adj, packed, value, joint, chains, lay.n_int, lean, lay.bool_word0(), joint && std::getenv("TB_NO_COND_WAKE") == nullptr);
+  std::vector<int4> succ = pack_succ(n_rec, net_props.data(), adj, packed, value, joint, chains, lay.n_int, lean, lay.bool_word0(), joint && std::getenv("TB_NO_COND_WAKE") == nullptr, lay.c8 ? &lay : nullptr);
   succ.resize((size_t)plan.n_slices * 64, make_int4(-1, -1, -1, 0));
   int4* d_succ = nullptr;
   if ((rc = bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
@@ -1197,7 +1279,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     const Adjacency adj = build_adjacency(n_vars, n_rec, net.props.data(), is_const, value, !(cfg.reserved[0] & 0x80));
     std::vector<int4> packed = pack_props(n_rec, net.props.data(), is_const, value, adj, lay.n_int, lay.n_slab());
     packed.resize((size_t)plan.n_slices * 64, make_int4(K_LEQ_T, 0, 0, 0));
-    if (n_rec) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
+    if (n_rec) { const std::vector<int4> dev = device_records(packed, lay); HIP_TRY(hipMemcpy(d_props, dev.data(), dev.size() * sizeof(int4), hipMemcpyHostToDevice)); }
     // hull of the batch, internal numbering: what "finite domains" means for a batch of stores
     std::vector<tb_itv> hull((size_t)std::max(1, n_vars));
     for (int v = 0; v < n_vars; ++v) {
@@ -1319,13 +1401,13 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   for (int32_t k = 0; k < n_strats; ++k) {
     i_off[(size_t)k] = (int32_t)i_vars.size();
     // (a constant kept out of the slab keeps its position in the list -- positions break ties -- as -1: assigned, never a candidate)
-    auto entry = [&](int32_t v) { const int i = lay.perm[(size_t)v]; return i >= lay.n_slab() ? -1 : i; };
+    auto entry = [&](int32_t v) { const int i = lay.perm[(size_t)v]; return i >= lay.n_slab() ? -1 : lay.ref(i); };  // (COMPACT8: a reference carries the base)
     if (strat_off[k] == strat_off[k + 1] && (lay.compact || lay.renumbered)) for (int32_t v = 0; v < n_vars; ++v) i_vars.push_back(entry(v));
     else for (int32_t j = strat_off[k]; j < strat_off[k + 1]; ++j) i_vars.push_back(entry(strat_vars[j]));
   }
   i_off[(size_t)n_strats] = (int32_t)i_vars.size();
   total_svars = (int32_t)i_vars.size();
-  const int32_t i_obj = obj_var >= 0 ? lay.perm[(size_t)obj_var] : -1;
+  const int32_t i_obj = obj_var >= 0 ? lay.ref(lay.perm[(size_t)obj_var]) : -1;
 
   int4* d_props = nullptr; int2* d_root = nullptr; int *d_vo = nullptr, *d_vl = nullptr, *d_off = nullptr, *d_sv = nullptr;
   if ((rc = s->bufs.alloc(&d_props, (size_t)plan.n_slices * 64)) != TB_OK) return rc;
@@ -1343,7 +1425,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     const Adjacency adj = build_adjacency(n_vars, n_rec, net.props.data(), is_const, value, !(s->cfg.reserved[0] & 0x80));
     std::vector<int4> packed = pack_props(n_rec, net.props.data(), is_const, value, adj, lay.n_int, lay.n_slab());
     packed.resize((size_t)plan.n_slices * 64, make_int4(K_LEQ_T, 0, 0, 0));
-    if (n_rec) HIP_TRY(hipMemcpy(d_props, packed.data(), packed.size() * sizeof(int4), hipMemcpyHostToDevice));
+    if (n_rec) { const std::vector<int4> dev = device_records(packed, lay); HIP_TRY(hipMemcpy(d_props, dev.data(), dev.size() * sizeof(int4), hipMemcpyHostToDevice)); }
     if ((rc = upload_event_tables(s->bufs, s->P, s->cfg, s->plan, s->lay, n_rec, net.props, adj, packed, value, net.store.data())) != TB_OK) return rc;
   }
   s->P.n_slices = s->plan.n_slices; s->P.dirty_words = s->plan.dirty_words; s->P.vext = s->plan.vext; s->P.chg_cap = s->plan.chg_cap;
@@ -1660,7 +1742,7 @@ int tb_session_debug_path(tb_session* s, int32_t workgroup, tb_debug_path* path_
     HIP_TRY(hipMemcpy(ub.data(), s->P.g_path_ub + (size_t)workgroup * (size_t)s->plan.max_depth, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) {
       tb_debug_decision& d = decisions_out[i];
-      d.var = s->lay.inv[(size_t)dec[(size_t)i].var];  // the caller's numbering
+      d.var = s->lay.inv[(size_t)(s->lay.c8 ? (dec[(size_t)i].var & 0xffff) : dec[(size_t)i].var)];  // the caller's numbering (COMPACT8: a decision holds a reference)
       d.child = dec[(size_t)i].cur;
       d.children[0] = tb_itv{dec[(size_t)i].child[0].x, dec[(size_t)i].child[0].y};
       d.children[1] = tb_itv{dec[(size_t)i].child[1].x, dec[(size_t)i].child[1].y};

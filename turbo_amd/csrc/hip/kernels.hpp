@@ -21,6 +21,9 @@
 #ifndef TB_EVENT_WAVES_256
 #define TB_EVENT_WAVES_256 7  // (r03: 6 -- trains15's slab then left room for six workgroups per CU whatever the registers; with the change list trimmed to the LDS granule, seven fit: +4.7 %)
 #endif
+#ifndef TB_EVENT_WAVES_C8
+#define TB_EVENT_WAVES_C8 6  // two-wave workgroups on COMPACT8 slabs: LDS holds eleven or twelve of them per CU (trains15), so 6 waves per SIMD -- 80 VGPRs
+#endif
 #ifndef TB_EVENT_WAVES
 #define TB_EVENT_WAVES 7
 #endif
@@ -221,6 +224,18 @@ __device__ __forceinline__ void st(int* p, int v) { __hip_atomic_store(p, v, TB_
 //                 numbers the most-read variables first (engine.hip: renumber_by_reads); an access picks its address space per lane and goes out as one
 //                 FLAT instruction (the hardware routes each lane by aperture).  The slab in global memory keeps room for all variables: block copies
 //                 (snapshots, best store) gather the hot part from LDS.
+//   4  COMPACT8   [n_wide x u32 {lb:16 | ub:16 << 16}][n_narrow x u16 {lb - base : 8 | ub - base : 8}][Boolean words][entailment bits]  (r04)
+//                 as COMPACT16, and an integer whose root domain is at most 255 wide takes two BYTES: its bounds relative to the root lower bound
+//                 (`base`).  The base travels with every reference to the variable -- an operand field of a record, an entry of a strategy list, the
+//                 objective, a decision -- in bits 16-30 of the field (base + 16384; bits 0-15: the variable), so a load is still one ds_read_b32 and a
+//                 few VALU, and a rule computes on absolute values as everywhere else.  trains15: 4939 of its 5011 integers are narrow, the slab goes from
+//                 20.7 KB to 11.6 KB and two-wave workgroups fit eleven to a CU instead of four-wave ones seven.  `ni` of this layout is
+//                 n_int | n_wide << 16 (the wide integers are numbered first, then the narrow ones, then the Booleans).
+constexpr int C8_BASE_BIAS = 16384;
+template <int C> __device__ __forceinline__ int ni_int(int ni) { return C == 4 ? (ni & 0xffff) : ni; }   // integer variables of the slab
+__device__ __forceinline__ int ni_wide(int ni) { return (int)((unsigned)ni >> 16); }                      // COMPACT8: the wide ones
+// the variable of a reference (COMPACT8: without its base; other layouts: the reference itself).  Not for constants (sign bit set).
+template <int C> __device__ __forceinline__ int var_of(int f) { return C == 4 ? (f & 0xffff) : f; }
 constexpr int HOT_VARS = 19456;  // 152 KB of intervals, right behind the control block (with the bitmaps and the change list: 159 KB of the 160)
 template <class T>
 __device__ __forceinline__ T* hot_or_cold(T* cold, int v) {  // (generic pointers on both sides: a flat access)
@@ -247,11 +262,26 @@ __device__ __forceinline__ Itv load_int(const int2* store, int v) {  // an integ
   d.ub = (int)(raw >> 32);
   return d;
 }
+// COMPACT8: an integer variable from its reference `f` (variable | (base + 16384) << 16); `nw`: the wide integers of the slab.
+// A narrow variable v sits in halfword v + nw of the slab (every wide one before it takes two).
+__device__ __forceinline__ Itv load_int8(const int2* store, int nw, int f) {
+  const int v = f & 0xffff, base = ((f >> 16) & 0x7fff) - C8_BASE_BIAS;
+  const bool wide = v < nw;
+  const int h = v + nw;
+  const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + (wide ? v : (h >> 1)), TB_RLX, TB_WG);
+  const unsigned pair = w >> ((h & 1) * 16);
+  Itv d;
+  d.lb = wide ? (int)(short)(w & 0xffffu) : base + (int)(pair & 0xffu);
+  d.ub = wide ? (int)w >> 16 : base + (int)((pair >> 8) & 0xffu);
+  return d;
+}
 // first 32-bit word of the Boolean words of a COMPACT / COMPACT16 slab
 template <int C>
-__device__ __forceinline__ unsigned* bool_words(int2* store, int ni) { return reinterpret_cast<unsigned*>(store) + (C == 2 ? ni : 2 * ni); }
+__device__ __forceinline__ int bool_word0(int ni) { return C == 4 ? ((ni & 0xffff) + ni_wide(ni) + 1) >> 1 : (C == 2 ? ni : 2 * ni); }
 template <int C>
-__device__ __forceinline__ const unsigned* bool_words(const int2* store, int ni) { return reinterpret_cast<const unsigned*>(store) + (C == 2 ? ni : 2 * ni); }
+__device__ __forceinline__ unsigned* bool_words(int2* store, int ni) { return reinterpret_cast<unsigned*>(store) + bool_word0<C>(ni); }
+template <int C>
+__device__ __forceinline__ const unsigned* bool_words(const int2* store, int ni) { return reinterpret_cast<const unsigned*>(store) + bool_word0<C>(ni); }
 
 // An operand field with the sign bit set is not a variable but the VALUE of a constant the layout keeps out of the slab (engine.hip: Layout,
 // operand_field; COMPACT layouts only): no memory access -- the load below goes to word 0 and is discarded by a select -- and nothing to
@@ -263,6 +293,18 @@ __device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v) {
   if (C == 3) return load_int<3>(store, v);
   const bool isk = v < 0;
   const int kv = field_value(v);
+  if (C == 4) {
+    // one 4-byte load whatever the kind: a wide integer's word, the word holding a narrow one's two bytes, or the Boolean word
+    const int id = v & 0xffff, nw = ni_wide(ni), n_i = ni & 0xffff, base = ((v >> 16) & 0x7fff) - C8_BASE_BIAS;
+    const bool isb = id >= n_i, wide = id < nw;
+    const int b = id - n_i, h = id + nw;
+    const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + (isk ? 0 : (isb ? bool_word0<4>(ni) + (b >> 4) : (wide ? id : (h >> 1)))), TB_RLX, TB_WG);
+    const unsigned bits = (w >> ((b & 15) * 2)) & 3u, pair = w >> ((h & 1) * 16);
+    Itv d;
+    d.lb = isk ? kv : (isb ? (int)(bits & 1u) : (wide ? (int)(short)(w & 0xffffu) : base + (int)(pair & 0xffu)));
+    d.ub = isk ? kv : (isb ? 1 - (int)(bits >> 1) : (wide ? (int)w >> 16 : base + (int)((pair >> 8) & 0xffu)));
+    return d;
+  }
   if (C == 2) {
     // one 4-byte load whatever the kind: the integer's packed bounds, or the Boolean word holding the variable's two bits
     const bool isb = v >= ni;
@@ -306,6 +348,36 @@ __device__ __forceinline__ void cas_lower_ub16(unsigned* w, int val) {
     if (__hip_atomic_compare_exchange_strong(w, &old, nw, TB_RLX, TB_RLX, TB_WG)) break;
   }
 }
+// COMPACT8: narrow one byte of a narrow integer (`sh`: bit position of the byte in the word; the word holds two variables)
+__device__ __forceinline__ void cas_raise_lb8(unsigned* w, int sh, int rel) {
+  const unsigned r = (unsigned)(rel < 0 ? 0 : (rel > 255 ? 255 : rel));  // (beyond the root domain: the domain is empty and the caller has raised the failure flag)
+  unsigned old = __hip_atomic_load(w, TB_RLX, TB_WG);
+  while (((old >> sh) & 0xffu) < r) {
+    const unsigned nw = (old & ~(0xffu << sh)) | (r << sh);
+    if (__hip_atomic_compare_exchange_strong(w, &old, nw, TB_RLX, TB_RLX, TB_WG)) break;
+  }
+}
+__device__ __forceinline__ void cas_lower_ub8(unsigned* w, int sh, int rel) {
+  const unsigned r = (unsigned)(rel < 0 ? 0 : (rel > 255 ? 255 : rel));
+  unsigned old = __hip_atomic_load(w, TB_RLX, TB_WG);
+  while (((old >> sh) & 0xffu) > r) {
+    const unsigned nw = (old & ~(0xffu << sh)) | (r << sh);
+    if (__hip_atomic_compare_exchange_strong(w, &old, nw, TB_RLX, TB_RLX, TB_WG)) break;
+  }
+}
+// COMPACT8: an integer variable through its reference (load_int8)
+__device__ __forceinline__ void raise_int_lb8(int2* store, int nw, int f, int val) {
+  const int v = f & 0xffff, h = v + nw;
+  unsigned* const words = reinterpret_cast<unsigned*>(store);
+  if (v < nw) { cas_raise_lb16(words + v, val); return; }
+  cas_raise_lb8(words + (h >> 1), (h & 1) * 16, val - (((f >> 16) & 0x7fff) - C8_BASE_BIAS));
+}
+__device__ __forceinline__ void lower_int_ub8(int2* store, int nw, int f, int val) {
+  const int v = f & 0xffff, h = v + nw;
+  unsigned* const words = reinterpret_cast<unsigned*>(store);
+  if (v < nw) { cas_lower_ub16(words + v, val); return; }
+  cas_lower_ub8(words + (h >> 1), (h & 1) * 16 + 8, val - (((f >> 16) & 0x7fff) - C8_BASE_BIAS));
+}
 template <int C>
 __device__ __forceinline__ void raise_int_lb(int2* store, int v, int val) {
   if (C == 2) { cas_raise_lb16(reinterpret_cast<unsigned*>(store) + v, val); return; }
@@ -318,27 +390,43 @@ __device__ __forceinline__ void lower_int_ub(int2* store, int v, int val) {
   if (C == 3) { (void)__hip_atomic_fetch_min(&hot_or_cold(store + v, v)->y, val, TB_RLX, TB_WG); return; }
   (void)__hip_atomic_fetch_min(&store[v].y, val, TB_RLX, TB_WG);
 }
+// an integer variable through a reference, in every layout (`ni`: DevProblem::n_int)
+template <int C>
+__device__ __forceinline__ Itv load_ivar(const int2* store, int ni, int f) {
+  if (C == 4) return load_int8(store, ni_wide(ni), f);
+  return load_int<C>(store, f);
+}
+template <int C>
+__device__ __forceinline__ void raise_ivar_lb(int2* store, int ni, int f, int val) {
+  if (C == 4) { raise_int_lb8(store, ni_wide(ni), f, val); return; }
+  raise_int_lb<C>(store, f, val);
+}
+template <int C>
+__device__ __forceinline__ void lower_ivar_ub(int2* store, int ni, int f, int val) {
+  if (C == 4) { lower_int_ub8(store, ni_wide(ni), f, val); return; }
+  lower_int_ub<C>(store, f, val);
+}
 template <int C>
 __device__ __forceinline__ void raise_lb(int2* store, int ni, int v, int val) {
   if (C == 3) { raise_int_lb<3>(store, v, val); return; }
   if (C && v < 0) return;  // a constant kept out of the slab (load_dom)
-  if (C && v >= ni) {
-    const int b = v - ni;
+  if (C && var_of<C>(v) >= ni_int<C>(ni)) {
+    const int b = var_of<C>(v) - ni_int<C>(ni);
     if (val >= 1) (void)__hip_atomic_fetch_or(bool_words<C>(store, ni) + (b >> 4), 1u << ((b & 15) * 2), TB_RLX, TB_WG);
     return;
   }
-  raise_int_lb<C>(store, v, val);
+  raise_ivar_lb<C>(store, ni, v, val);
 }
 template <int C>
 __device__ __forceinline__ void lower_ub(int2* store, int ni, int v, int val) {
   if (C == 3) { lower_int_ub<3>(store, v, val); return; }
   if (C && v < 0) return;
-  if (C && v >= ni) {
-    const int b = v - ni;
+  if (C && var_of<C>(v) >= ni_int<C>(ni)) {
+    const int b = var_of<C>(v) - ni_int<C>(ni);
     if (val <= 0) (void)__hip_atomic_fetch_or(bool_words<C>(store, ni) + (b >> 4), 2u << ((b & 15) * 2), TB_RLX, TB_WG);
     return;
   }
-  lower_int_ub<C>(store, v, val);
+  lower_ivar_ub<C>(store, ni, v, val);
 }
 
 // Per-thread counters kept in registers for the whole kernel and reduced once at the end.
@@ -667,6 +755,7 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
 // run, not after each narrowing.  Up to two successors per operand travel with the record (DevProblem::succ) and need no
 // memory access; the others come from the variable's 32-byte adjacency record, one L2 round trip for the whole wave.
 // Returns true (wave-uniform) when something was marked.
+template <int C>
 __device__ __forceinline__ bool mark_successors(const DevProblem& P, BlockShared& sh, unsigned* nxt, int s, const int4 pr, const int4 sc, int nar_all, int* census = nullptr) {
   const int priv = (pr.x >> 8) & 7;  // operands private to this slice are flagged at pack time
   int ex = (priv & 1) ? 0 : (nar_all & 3), ey = (priv & 2) ? 0 : ((nar_all >> 2) & 3), ez = (priv & 4) ? 0 : ((nar_all >> 4) & 3);
@@ -696,9 +785,9 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, BlockShared
     }
 #endif
     int dx = 0, dy = 0, dz = 0, ox = 0, oy = 0, oz = 0;
-    const bool tx = mark_var(P, nxt, pr.y, s, ex, dx, ox, did);
-    const bool ty = mark_var(P, nxt, pr.z, s, ey, dy, oy, did);
-    const bool tz = mark_var(P, nxt, pr.w, s, ez, dz, oz, did);
+    const bool tx = mark_var(P, nxt, var_of<C>(pr.y), s, ex, dx, ox, did);
+    const bool ty = mark_var(P, nxt, var_of<C>(pr.z), s, ey, dy, oy, did);
+    const bool tz = mark_var(P, nxt, var_of<C>(pr.w), s, ez, dz, oz, did);
     const unsigned long long mx = wave_ballot(tx), my = wave_ballot(ty), mz = wave_ballot(tz);
     bool dt = false;
 #ifdef TB_TUNING
@@ -725,7 +814,7 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, BlockShared
 struct BoolRef { unsigned* word; int shift; };
 template <int C>
 __device__ __forceinline__ BoolRef bool_ref(int2* store, int ni, int v, bool act) {
-  const int b = act ? v - ni : 0;  // idle lanes of a padded slice look at the first Boolean and touch nothing
+  const int b = act ? v - ni_int<C>(ni) : 0;  // idle lanes of a padded slice look at the first Boolean and touch nothing (a Boolean's reference is the variable in every layout)
   BoolRef r;
   r.word = bool_words<C>(store, ni) + (b >> 4);
   r.shift = (b & 15) * 2;
@@ -763,7 +852,7 @@ template <int C>
 __device__ __forceinline__ Itv lean_load(int2* store, int ni, const LeanOperand<C>& o, int kind) {
   if (C && kind == 2) { const unsigned bits = bool_bits(o.b); Itv d; d.lb = (int)(bits & 1u); d.ub = 1 - (int)(bits >> 1); return d; }
   if (C && kind != 1) return load_dom<C>(store, ni, o.v);
-  return load_int<C>(store, o.v);
+  return load_ivar<C>(store, ni, o.v);
 }
 // CLS >= 0: the class is a compile-time constant (the pass loop then holds one class body and no chain of scalar compares); -1: `cls_dyn`.
 template <int C, int CLS>
@@ -1149,7 +1238,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               if (wave_any(cond)) {
                 TB_REGION(9);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // my write of y, then this read: the chain run does the same with roles reversed
-                const Itv Yc = load_int<C>(store, cond ? (int)(ty >> 16) : 0);
+                const Itv Yc = load_ivar<C>(store, P.n_int, (cond ? (int)(ty >> 16) : 0) | (C == 4 ? C8_BASE_BIAS << 16 : 0));  // (COMPACT8: kv is relative to Y's base, pack_succ)
                 const int kv = (int)(short)((((unsigned)sc.w >> 3) & 0x3fffu) | ((((unsigned)sc.w >> 28) & 3u) << 14));
                 if (cond) ty = (kv == Yc.lb || kv == Yc.ub) ? (ty | 0xffff0000u) : 0xffffffffu;
               }
@@ -1162,9 +1251,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               const int ey = (my_ny && ((sc.w >> 17) & 1)) ? EV_UB : 0, ez = (my_nz && ((sc.w >> 2) & 1)) ? EV_LB : 0;
               if (wave_any((ey | ez) != 0)) {  // more than two interested readers: the variable's adjacency record
                 TB_REGION(10);
-                const int base_w = C == 2 ? P.n_int : P.n_int * 2;  // first Boolean word of the slab
-                const int vy = P.n_int + ((((int)((unsigned)sc.x & 0xffffu)) - base_w) << 4) + (ys >> 1);
-                const int vz = P.n_int + ((((int)((unsigned)sc.x >> 16)) - base_w) << 4) + (zs >> 1);
+                const int base_w = bool_word0<C>(P.n_int), n_i = ni_int<C>(P.n_int);  // first Boolean word of the slab
+                const int vy = n_i + ((((int)((unsigned)sc.x & 0xffffu)) - base_w) << 4) + (ys >> 1);
+                const int vz = n_i + ((((int)((unsigned)sc.x >> 16)) - base_w) << 4) + (zs >> 1);
                 int dy = 0, dz = 0, oy = 0, oz = 0;
                 const bool tly = mark_var(P, nxt, vy, s, ey, dy, oy, did);
                 const bool tlz = mark_var(P, nxt, vz, s, ez, dz, oz, did);
@@ -1249,7 +1338,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               TB_REGION(14);
               const unsigned xb = bool_bits(rx);
-              const Itv Y = load_int<C>(store, yv);
+              const Itv Y = load_ivar<C>(store, P.n_int, yv);
               const bool t = act && (xb & 1u), f = act && (xb & 2u), u = act && xb == 0u;
               bool again = false;
               int lb = Y.lb, ub = Y.ub;
@@ -1293,9 +1382,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                 }
                 const bool cyl = writer && lb != Y.lb, cyu = writer && ub != Y.ub;
                 if (cyl | cyu) {
-                  if (cyl) raise_int_lb<C>(store, yv, lb);
-                  if (cyu) lower_int_ub<C>(store, yv, ub);
-                  const Itv now = load_int<C>(store, yv);
+                  if (cyl) raise_ivar_lb<C>(store, P.n_int, yv, lb);
+                  if (cyu) lower_ivar_ub<C>(store, P.n_int, yv, ub);
+                  const Itv now = load_ivar<C>(store, P.n_int, yv);
                   if (now.lb > now.ub) st(&sh.bot, 1);
                   if (by_range) {
                     const int rec = s * 64 + lane - kc, q_max = P.n_slices - 1;
@@ -1335,7 +1424,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             const int kc = sc.z;  // the constant's value travels in the z slots of the successor record (pack_succ)
             wave_iters = run_slice(E, nar_all, [&](bool& ch, bool& un_i, int& nar) {
               const unsigned xb = bool_bits(rx);
-              const Itv Y = load_int<C>(store, yv);
+              const Itv Y = load_ivar<C>(store, P.n_int, yv);
               const bool t = (xb & 1u) != 0, f = (xb & 2u) != 0, u = !t && !f;
               const bool empty_in = (xb == 3u) | (Y.lb > Y.ub);
               bool set1, set0, ent;
@@ -1359,8 +1448,8 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                   if (empty_in | (nyl > nyu)) st(&sh.bot, 1);  // (a narrowed constant is an empty y: same condition)
                   if (!empty_in) {
                     if (set1 | set0) bool_or(rx, set1 ? 1u : 2u);
-                    if (cyl) raise_int_lb<C>(store, yv, nyl);
-                    if (cyu) lower_int_ub<C>(store, yv, nyu);
+                    if (cyl) raise_ivar_lb<C>(store, P.n_int, yv, nyl);
+                    if (cyu) lower_ivar_ub<C>(store, P.n_int, yv, nyu);
                     const int kw = (int)(set1 | set0) + (int)cyl + (int)cyu;
                     run_writes += (unsigned)kw;
                     ch = kw != 0;
@@ -1389,14 +1478,14 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
 #endif
           TB_REGION(18);
 #ifdef TB_TUNING
-          note_marked(mark_successors(P, sh, nxt, s, pr, sc, nar_all, (prof && wave == 0) ? sh.bs.dbg : nullptr));
+          note_marked(mark_successors<C>(P, sh, nxt, s, pr, sc, nar_all, (prof && wave == 0) ? sh.bs.dbg : nullptr));
 #else
-          note_marked(mark_successors(P, sh, nxt, s, pr, sc, nar_all));
+          note_marked(mark_successors<C>(P, sh, nxt, s, pr, sc, nar_all));
 #endif
           TB_REGION(19);
           TB_PROF_MARK(2);
           TB_PROF_COUNT(4);
-          if (pk(P) & 0x1) note_marked(mark_successors(P, sh, nxt, s, pr, sc, nar_all));  // tuning: cost of the marks (idempotent)
+          if (pk(P) & 0x1) note_marked(mark_successors<C>(P, sh, nxt, s, pr, sc, nar_all));  // tuning: cost of the marks (idempotent)
           tc.writes += run_writes;
           {  // profiling (tuning build): 0x400000 counts slice runs instead of iterations; bits 28-31 = 1 + class to count only that class (11 = mixed slices)
             const int want = (knobs(P) >> 28) & 15;
@@ -1579,7 +1668,7 @@ __device__ __forceinline__ int embed0(int2* store, int ni, int* bot, int v, int 
 template <bool EVENT, int C>
 __device__ __forceinline__ void embed0_mark(const DevProblem& P, BlockShared& sh, const EventState& es, int2* store, int* bot, int v, int lb, int ub) {
   const int ev = embed0<C>(store, P.n_int, bot, v, lb, ub);
-  if (EVENT && ev) note_change(sh, es, v, ev);
+  if (EVENT && ev) note_change(sh, es, var_of<C>(v), ev);
 }
 
 // Key to MINIMISE for each variable order (barebones:193-221); ties resolve to the lowest index
@@ -2151,7 +2240,7 @@ __device__ __forceinline__ void end_of_dive(const DevProblem& P, BlockShared& sh
 // LDS; measured 17.9 / 20.5 / 22.3 / 23.4e6 nodes/s with 4 / 5 / 6 / 7); the sweep variants are VALU bound and keep 4.
 // OPT: the COMPACT store layout for the event kernels, entailed-slice removal for the sweeping ones.
 template <int MEM, int TMAX, bool EVENT, int OPT>
-__global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES : ((EVENT && TMAX == 256) ? TB_EVENT_WAVES_256 : (TMAX == 256 ? 5 : 4))) solve_kernel(DevProblem by_value, const DevProblem* __restrict__ problem, Mailbox* mbox) {
+__global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_EVENT_WAVES_C8 : TB_EVENT_WAVES) : ((EVENT && TMAX == 256) ? TB_EVENT_WAVES_256 : (TMAX == 256 ? 5 : 4))) solve_kernel(DevProblem by_value, const DevProblem* __restrict__ problem, Mailbox* mbox) {
   // The problem description is read through a pointer, not passed by value: as kernel arguments its ~70 scalars were all
   // hoisted into SGPRs for the whole persistent loop and 260 of them spilled through VGPR lanes (v_writelane / v_readlane,
   // VALU work on an issue-bound kernel); behind a pointer the compiler loads a field where it is used (scalar cache):
@@ -2165,7 +2254,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
   // (the two-wave event kernels are only ever launched with exactly 128 threads: block_threads)
   constexpr int TB = (EVENT && TMAX == 128) ? 128 : 0;
   const DevProblem& P = EVENT ? constant_problem(problem) : by_value;  // (constant address space: every field is fetched with a scalar load where it is used)
-  // OPT: event kernels -- the store layout (0 plain, 1 COMPACT, 2 COMPACT16); sweeps -- bit 0 entailed-slice removal, bits 1-2 the layout
+  // OPT: event kernels -- the store layout (0 plain, 1 COMPACT, 2 COMPACT16, 3 HOT, 4 COMPACT8); sweeps -- bit 0 entailed-slice removal, bits 1-2 the layout
   constexpr int C = EVENT ? OPT : (OPT >> 1);
   constexpr bool RM = !EVENT && (OPT & 1) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2335,7 +2424,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? TB_EVENT_WAVES 
           const int2 ch = di.child[di.cur];
           raise_lb<C>(store, P.n_int, di.var, ch.x);
           lower_ub<C>(store, P.n_int, di.var, ch.y);
-          if (EVENT) note_change(sh, es, di.var, EV_LB | EV_UB);
+          if (EVENT) note_change(sh, es, var_of<C>(di.var), EV_LB | EV_UB);
         }
         __syncthreads();
         if (tid == 0) {
@@ -2406,7 +2495,7 @@ struct PropagateOut {
 template <int MEM, int TMAX, bool EVENT, int OPT>
 __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* stores, PropagateOut* out, int n_stores) {
   __builtin_amdgcn_s_dcache_inv();  // (see solve_kernel)
-  // OPT: event kernels -- the store layout (0 plain, 1 COMPACT, 2 COMPACT16); sweeps -- bit 0 entailed-slice removal, bits 1-2 the layout
+  // OPT: event kernels -- the store layout (0 plain, 1 COMPACT, 2 COMPACT16, 3 HOT, 4 COMPACT8); sweeps -- bit 0 entailed-slice removal, bits 1-2 the layout
   constexpr int C = EVENT ? OPT : (OPT >> 1);
   constexpr bool RM = !EVENT && (OPT & 1) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
