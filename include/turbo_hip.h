@@ -103,7 +103,8 @@ typedef struct {
                                            0x40000 event mode accepts < 4 workgroups per CU in LDS; 0x80000 never / 0x100000 always
                                            use the compact (2-bit Boolean) store layout of the event kernels (0x100000 with the sweeps and
                                            without entailed_prop_removal: the sweeps on that layout, an opt-in); 0x10000000 always / 0x20000000
-                                           never pack integer variables as 16-bit bounds on top of it (COMPACT16); 0x40000000 keep the non-Boolean singletons
+                                           never pack integer variables as 16-bit bounds on top of it (COMPACT16); both bits: always / 0x80000000 never
+                                           keep the integers at most 255 wide as two bytes relative to their root lower bound (COMPACT8); 0x40000000 keep the non-Boolean singletons
                                            of the root in the slab (by default the compact layouts carry their values in the records); 0x200000 keep the caller's
                                            propagator order instead of sorting the records by class; 0x400000 count slice
                                            runs instead of propagator evaluations; 0x800000 test aid: keep the store every workgroup stopped
@@ -210,7 +211,7 @@ typedef struct {
   int32_t num_blocks, threads_per_block, mem_kind, shared_bytes, subproblems_power, eps_chunk_log2, snapshot_levels, decision_stack_depth;
   uint64_t eps_local_subproblems;
   int32_t kernel_event, kernel_opt; /* which kernel start() launches: event-driven fixpoint or sweeps; its option flag (event: 0 plain store,
-                                     * 1 COMPACT, 2 COMPACT16, 3 plain store in global memory with its most-read intervals in LDS; sweeps: 0 plain,
+                                     * 1 COMPACT, 2 COMPACT16, 3 plain store in global memory with its most-read intervals in LDS, 4 COMPACT8; sweeps: 0 plain,
                                      * 1 entailed-slice removal, 2 COMPACT, 4 COMPACT16, 6 the hot tier) */
 } tb_plan;
 int tb_session_plan(tb_session* s, tb_plan* plan_out);

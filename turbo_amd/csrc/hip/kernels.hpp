@@ -264,11 +264,12 @@ __device__ __forceinline__ Itv load_int(const int2* store, int v) {  // an integ
 }
 // COMPACT8: an integer variable from its reference `f` (variable | (base + 16384) << 16); `nw`: the wide integers of the slab.
 // A narrow variable v sits in halfword v + nw of the slab (every wide one before it takes two).
-__device__ __forceinline__ Itv load_int8(const int2* store, int nw, int f) {
+__device__ __forceinline__ Itv load_int8(const int2* store, int nw, int f, unsigned* raw = nullptr) {
   const int v = f & 0xffff, base = ((f >> 16) & 0x7fff) - C8_BASE_BIAS;
   const bool wide = v < nw;
   const int h = v + nw;
   const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + (wide ? v : (h >> 1)), TB_RLX, TB_WG);
+  if (raw) *raw = w;
   const unsigned pair = w >> ((h & 1) * 16);
   Itv d;
   d.lb = wide ? (int)(short)(w & 0xffffu) : base + (int)(pair & 0xffu);
@@ -288,7 +289,7 @@ __device__ __forceinline__ const unsigned* bool_words(const int2* store, int ni)
 // narrow: a rule that would move a constant has emptied it, and the caller raises the failure flag on the empty candidate.
 __device__ __forceinline__ int field_value(int v) { return (int)((unsigned)v << 1) >> 1; }
 template <int C>
-__device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v) {
+__device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v, unsigned* seen = nullptr) {  // (`seen`, COMPACT8: the word that was read)
   if (C == 0) return load_int<0>(store, v);
   if (C == 3) return load_int<3>(store, v);
   const bool isk = v < 0;
@@ -300,6 +301,7 @@ __device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v) {
     const int b = id - n_i, h = id + nw;
     const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + (isk ? 0 : (isb ? bool_word0<4>(ni) + (b >> 4) : (wide ? id : (h >> 1)))), TB_RLX, TB_WG);
     const unsigned bits = (w >> ((b & 15) * 2)) & 3u, pair = w >> ((h & 1) * 16);
+    if (seen) *seen = w;
     Itv d;
     d.lb = isk ? kv : (isb ? (int)(bits & 1u) : (wide ? (int)(short)(w & 0xffffu) : base + (int)(pair & 0xffu)));
     d.ub = isk ? kv : (isb ? 1 - (int)(bits >> 1) : (wide ? (int)w >> 16 : base + (int)((pair >> 8) & 0xffu)));
@@ -427,6 +429,41 @@ __device__ __forceinline__ void lower_ub(int2* store, int ni, int v, int val) {
     return;
   }
   lower_ivar_ub<C>(store, ni, v, val);
+}
+
+// COMPACT8: both bounds of one operand in ONE compare-and-swap loop -- two LDS round trips per narrowed variable where raise_lb + lower_ub take four.
+// (Measured and dropped: starting the swap from the word the pass has read -- one trip -- keeps three more words live per lane and switches on the operand
+//  kind: 84 -> 128 B of scratch at 80 VGPRs, trains15 4.34e7 -> 3.67e7 nodes/s.)  `cl` / `cu`: which bounds to move.
+__device__ __forceinline__ void narrow_var8(int2* store, int ni, int f, int nl, int nu, bool cl, bool cu) {
+  if (f < 0 || !(cl | cu)) return;  // a constant kept out of the slab
+  const int v = f & 0xffff, n_i = ni & 0xffff, nw = ni_wide(ni);
+  unsigned* const words = reinterpret_cast<unsigned*>(store);
+  if (v >= n_i) {
+    const int b = v - n_i;
+    const unsigned bits = ((cl && nl >= 1) ? 1u : 0u) | ((cu && nu <= 0) ? 2u : 0u);
+    if (bits) (void)__hip_atomic_fetch_or(words + bool_word0<4>(ni) + (b >> 4), bits << ((b & 15) * 2), TB_RLX, TB_WG);
+    return;
+  }
+  unsigned old = __hip_atomic_load(words + (v < nw ? v : ((v + nw) >> 1)), TB_RLX, TB_WG);
+  if (v < nw) {
+    const int tl = nl > 32767 ? 32767 : nl, tu = nu < -32768 ? -32768 : nu;
+    for (;;) {
+      const int cur_l = (int)(short)(old & 0xffffu), cur_u = (int)old >> 16;
+      const int l = (cl && tl > cur_l) ? tl : cur_l, u = (cu && tu < cur_u) ? tu : cur_u;
+      if (l == cur_l && u == cur_u) break;
+      if (__hip_atomic_compare_exchange_strong(words + v, &old, ((unsigned)l & 0xffffu) | ((unsigned)u << 16), TB_RLX, TB_RLX, TB_WG)) break;
+    }
+    return;
+  }
+  const int h = v + nw, sh = (h & 1) * 16, base = ((f >> 16) & 0x7fff) - C8_BASE_BIAS;
+  const int rl = nl - base, ru = nu - base;
+  const unsigned tl = (unsigned)(rl < 0 ? 0 : (rl > 255 ? 255 : rl)), tu = (unsigned)(ru < 0 ? 0 : (ru > 255 ? 255 : ru));  // (beyond the root domain: empty, the caller has raised the flag)
+  for (;;) {
+    const unsigned cur_l = (old >> sh) & 0xffu, cur_u = (old >> (sh + 8)) & 0xffu;
+    const unsigned l = (cl && tl > cur_l) ? tl : cur_l, u = (cu && tu < cur_u) ? tu : cur_u;
+    if (l == cur_l && u == cur_u) break;
+    if (__hip_atomic_compare_exchange_strong(words + (h >> 1), &old, (old & ~(0xffffu << sh)) | (l << sh) | (u << (sh + 8)), TB_RLX, TB_RLX, TB_WG)) break;
+  }
 }
 
 // Per-thread counters kept in registers for the whole kernel and reduced once at the end.
@@ -849,8 +886,9 @@ __device__ __forceinline__ LeanOperand<C> lean_operand(int2* store, int ni, int 
   return o;
 }
 template <int C>
-__device__ __forceinline__ Itv lean_load(int2* store, int ni, const LeanOperand<C>& o, int kind) {
+__device__ __forceinline__ Itv lean_load(int2* store, int ni, const LeanOperand<C>& o, int kind, unsigned* raw = nullptr) {
   if (C && kind == 2) { const unsigned bits = bool_bits(o.b); Itv d; d.lb = (int)(bits & 1u); d.ub = 1 - (int)(bits >> 1); return d; }
+  if (C == 4) return kind != 1 ? load_dom<4>(store, ni, o.v, raw) : load_int8(store, ni_wide(ni), o.v, raw);
   if (C && kind != 1) return load_dom<C>(store, ni, o.v);
   return load_ivar<C>(store, ni, o.v);
 }
@@ -938,12 +976,18 @@ __device__ __forceinline__ unsigned lean_class_run_t(const RunEnv& E, const int 
     }
     if (moved) {
       if ((xl > xu) | (yl > yu) | (zl > zu)) st(&E.sh.bot, 1);
-      if (cxl) raise_lb<C>(store, ni, vx, xl);
-      if (cxu) lower_ub<C>(store, ni, vx, xu);
-      if (cyl) raise_lb<C>(store, ni, vy, yl);
-      if (cyu) lower_ub<C>(store, ni, vy, yu);
-      if (czl) raise_lb<C>(store, ni, vz, zl);
-      if (czu) lower_ub<C>(store, ni, vz, zu);
+      if constexpr (C == 4) {
+        narrow_var8(store, ni, vx, xl, xu, cxl, cxu);
+        narrow_var8(store, ni, vy, yl, yu, cyl, cyu);
+        narrow_var8(store, ni, vz, zl, zu, czl, czu);
+      } else {
+        if (cxl) raise_lb<C>(store, ni, vx, xl);
+        if (cxu) lower_ub<C>(store, ni, vx, xu);
+        if (cyl) raise_lb<C>(store, ni, vy, yl);
+        if (cyu) lower_ub<C>(store, ni, vy, yu);
+        if (czl) raise_lb<C>(store, ni, vz, zl);
+        if (czu) lower_ub<C>(store, ni, vz, zu);
+      }
     }
     if constexpr (LANE_BITS) {
       // what this lane moved in this pass as per-lane bits: kept off the scalar unit, the busiest resource of a network like accap_a3 (84 %;
@@ -1382,8 +1426,11 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                 }
                 const bool cyl = writer && lb != Y.lb, cyu = writer && ub != Y.ub;
                 if (cyl | cyu) {
-                  if (cyl) raise_ivar_lb<C>(store, P.n_int, yv, lb);
-                  if (cyu) lower_ivar_ub<C>(store, P.n_int, yv, ub);
+                  if constexpr (C == 4) narrow_var8(store, P.n_int, yv, lb, ub, cyl, cyu);
+                  else {
+                    if (cyl) raise_ivar_lb<C>(store, P.n_int, yv, lb);
+                    if (cyu) lower_ivar_ub<C>(store, P.n_int, yv, ub);
+                  }
                   const Itv now = load_ivar<C>(store, P.n_int, yv);
                   if (now.lb > now.ub) st(&sh.bot, 1);
                   if (by_range) {
@@ -1448,8 +1495,11 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                   if (empty_in | (nyl > nyu)) st(&sh.bot, 1);  // (a narrowed constant is an empty y: same condition)
                   if (!empty_in) {
                     if (set1 | set0) bool_or(rx, set1 ? 1u : 2u);
-                    if (cyl) raise_ivar_lb<C>(store, P.n_int, yv, nyl);
-                    if (cyu) lower_ivar_ub<C>(store, P.n_int, yv, nyu);
+                    if constexpr (C == 4) narrow_var8(store, P.n_int, yv, nyl, nyu, cyl, cyu);
+                    else {
+                      if (cyl) raise_ivar_lb<C>(store, P.n_int, yv, nyl);
+                      if (cyu) lower_ivar_ub<C>(store, P.n_int, yv, nyu);
+                    }
                     const int kw = (int)(set1 | set0) + (int)cyl + (int)cyu;
                     run_writes += (unsigned)kw;
                     ch = kw != 0;
