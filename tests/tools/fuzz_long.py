@@ -10,13 +10,14 @@ from turbo_amd import capi
 from fuzz_models import random_network, finite_class_network
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 800
-COMPACT, C16 = 0x100000, 0x10100000
+COMPACT, C16, C8 = 0x100000, 0x10100000, 0x30100000
 MODES = {"event_compact": dict(fixpoint=2, debug=COMPACT), "event_compact16": dict(fixpoint=2, debug=C16), "wac1_compact16": dict(fixpoint=1, debug=C16),
-         "event_compact_global": dict(fixpoint=2, debug=COMPACT, only_global_memory=1), "event": dict(fixpoint=2)}
+         "event_compact_global": dict(fixpoint=2, debug=COMPACT, only_global_memory=1), "event": dict(fixpoint=2), "event_compact8": dict(fixpoint=2, debug=C8)}
 bad = 0
 for seed in range(first, first + n):
     rng = np.random.default_rng(seed)
-    store, props = random_network(rng) if seed % 2 == 0 else finite_class_network(rng)[:2]
+    # (finite networks: every fourth seed with domains on both sides of COMPACT8's limits -- width 255, bases beyond +-16383)
+    store, props = random_network(rng) if seed % 2 == 0 else finite_class_network(rng, scale=(1, 8, 1, 400)[(seed // 2) % 4])[:2]
     stores = [store]
     for _ in range(3):
         s = store.copy()

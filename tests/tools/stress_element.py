@@ -13,8 +13,9 @@ from fuzz_models import element_model
 from test_gpu_parity import random_nodes
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 120
-COMPACT, C16 = 0x100000, 0x10100000
-MODES = {"event_compact": dict(debug=COMPACT), "event_compact16": dict(debug=C16), "event_compact_4waves": dict(debug=COMPACT, threads_per_block=256)}
+COMPACT, C16, C8 = 0x100000, 0x10100000, 0x30100000
+MODES = {"event_compact": dict(debug=COMPACT), "event_compact16": dict(debug=C16), "event_compact_4waves": dict(debug=COMPACT, threads_per_block=256),
+         "event_compact8": dict(debug=C8), "event_compact8_4waves": dict(debug=C8, threads_per_block=256)}
 bad = trees = 0
 for seed in range(first, first + n):
     tcn = frontend.Model.from_string(element_model(seed)).tcn()
@@ -39,7 +40,7 @@ for seed in range(first, first + n):
         nodes = random_nodes(tcn, 32, seed=seed, max_decisions=6)
         exp = [pyoracle.propagate(nodes[i], tcn.props) for i in range(nodes.shape[0])]
         stores = np.tile(nodes, (128, 1))
-        for dbg in (COMPACT, C16):
+        for dbg in (COMPACT, C16, C8):
             got, failed, ent, _, _, _ = capi.propagate(tcn.props, stores, capi.make_config(fixpoint=2, debug=dbg, timeout_ms=60000))
             miss = 0
             for j in range(stores.shape[0]):
