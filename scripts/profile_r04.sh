@@ -6,17 +6,24 @@
 # 3. the same memory-side passes for the synthetic 100k x 500k network (configs[4]: store in global memory), wac1 and event, stores inside
 #    the Infinity Cache (256 x 1024 threads) and beyond it (256-thread workgroups);
 # 4. scripts/summarize_r04.py -> profiles/<tag>_kernel_stats.txt, profiles/<tag>_counters.json.
+# usage: scripts/profile_r04.sh [tag] [parts]   parts: any of t (trace) h (headline counters) o (accap_a3 / trains15 counters) s (synthetic); default "thos".
+# Every profiled command runs under its own `timeout` (a profiler that hangs after a fault must not eat the GPU budget: the first final run of this round lost 55
+# minutes that way), and the summary keeps the entries of profiles/<tag>_counters.json whose passes were not run again.
 tag=${1:-r04}
+parts=${2:-thos}
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp && cd $root
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out/trace -o t -- python3 bench.py > $out/bench_traced.log 2> $out/bench_traced.err
+case $parts in *t*)
+timeout 600 rocprofv3 --kernel-trace --stats -d $out/trace -o t -- python3 bench.py > $out/bench_traced.log 2> $out/bench_traced.err; echo "trace rc=$?";;
+esac
 pass() {  # pass <dir> <counters...> -- <bench args>
   d=$1; shift; c=""
   while [ "$1" != "--" ]; do c="$c $1"; shift; done; shift
-  rocprofv3 --pmc $c -d $out/$d -o p -- python3 bench.py "$@" > $out/$d.log 2>&1
+  timeout 420 rocprofv3 --pmc $c -d $out/$d -o p -- python3 bench.py "$@" > $out/$d.log 2>&1 || echo "pass $d: rc=$?"
 }
+case $parts in *h*)
 for fp in event wac1; do
   args="--steps 2 --warmup 1 --side-steps 0 --other-steps 0 --reference-seconds 0 --no-cpu-baseline --fixpoint $fp"
   pass ${fp}_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU -- $args
@@ -26,7 +33,9 @@ for fp in event wac1; do
   pass ${fp}_fetch FETCH_SIZE -- $args
   pass ${fp}_write WRITE_SIZE -- $args
   pass ${fp}_tcc TCC_HIT_sum TCC_MISS_sum -- $args
-done
+done;;
+esac
+case $parts in *o*)
 for w in accap_a3 trains15; do  # the other LDS-resident BASELINE configurations, event fixpoint
   args="--workload $w --steps 2 --warmup 1 --side-steps 0 --other-steps 0 --reference-seconds 0 --no-cpu-baseline --fixpoint event"
   pass ${w}_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU -- $args
@@ -34,7 +43,9 @@ for w in accap_a3 trains15; do  # the other LDS-resident BASELINE configurations
   pass ${w}_grbm GRBM_GUI_ACTIVE -- $args
   pass ${w}_fetch FETCH_SIZE -- $args
   pass ${w}_write WRITE_SIZE -- $args
-done
+done;;
+esac
+case $parts in *s*)
 i=0
 for cfg in "wac1 0 hot" "event 0 hot" "wac1 256 hot" "wac1 0 nohot"; do
   set -- $cfg
@@ -46,7 +57,8 @@ for cfg in "wac1 0 hot" "event 0 hot" "wac1 256 hot" "wac1 0 nohot"; do
   pass syn${i}_write WRITE_SIZE -- $args
   pass syn${i}_tcc TCC_HIT_sum TCC_MISS_sum -- $args
   pass syn${i}_ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -- $args
-done
+done;;
+esac
 unset TB_NO_HOT_TIER
 python3 scripts/summarize_r04.py $tag $out
 mkdir -p gpurun_out/profiles_$tag && cp profiles/${tag}_kernel_stats.txt profiles/${tag}_counters.json gpurun_out/profiles_$tag/

@@ -78,6 +78,10 @@ if trace:
             json.dump(line, open(os.path.join(prof, f"{tag}_bench_line_traced.json"), "w"), indent=1)
     print(open(os.path.join(prof, f"{tag}_kernel_stats.txt")).read())
 
+try:  # entries of an earlier run of this tag stay when their passes were not run again (scripts/profile_r04.sh: parts)
+    earlier = json.load(open(os.path.join(prof, f"{tag}_counters.json")))
+except Exception:
+    earlier = {}
 rec = {"note": "rocprofv3 --pmc passes of `python3 bench.py --steps 2 --warmup 1 --side-steps 0 --other-steps 0 --reference-seconds 0 --no-cpu-baseline --fixpoint <mode>` "
                "(scripts/profile_r04.sh); one counter set per pass, no tracing domains; per-launch averages of tb::solve_kernel"}
 for fp, key in (("event", "wordpress7_500/event"), ("wac1", "wordpress7_500/wac1"), ("accap_a3", "accap_a3/event"), ("trains15", "trains15/event")):
@@ -154,5 +158,10 @@ for i, (fp, what) in enumerate((("wac1", "256 workgroups x 1024 threads, hot tie
             r["ea_read_requests_32B_share"] = ea.get("TCC_EA0_RDREQ_32B_sum", 0.0) / max(1.0, ea["TCC_EA0_RDREQ_sum"])
     key = "synthetic/" + fp + ("" if i < 3 else ("_beyond_mall" if i == 3 else "_no_hot_tier"))
     rec[key] = r
+for k, v in earlier.items():
+    if k not in rec:
+        rec[k] = v
+        if isinstance(v, dict):
+            v.setdefault("measured", "earlier run of this round (kernel unchanged since)")
 json.dump(rec, open(os.path.join(prof, f"{tag}_counters.json"), "w"), indent=1)
 print(json.dumps({k: {a: b for a, b in v.items() if a != "counters"} if isinstance(v, dict) else v for k, v in rec.items()}, indent=1))
