@@ -158,6 +158,9 @@ struct DevProblem {
   const int2* slice_info;  // [n_slices] event kernels, read with scalar loads: {word0 of the slice's records (class set, operand kinds, flags),
                            //  lanes holding a propagator | 0x100: lean implication records (engine.hip: pack_succ)}
   const int* slice_real;  // [n_slices] event kernels: lanes of the slice that hold a propagator (the engine pads every class to whole slices)
+#ifdef TB_TUNING
+  unsigned* slice_census;  // tuning build, knob 0x400000 + verbose: [2 * n_slices] runs of every slice, and those that narrowed nothing (whole grid)
+#endif
   int n_slices;         // ceil(n_props / 64)
   int dirty_words;      // ceil(n_slices / 32)
   int vext;             // int2 elements of a store slab (even): intervals, Boolean words, one "not entailed" byte per slice

@@ -1165,6 +1165,15 @@ int upload_event_tables(DevBuffers& bufs, DevProblem& P, const tb_config& cfg, c
   if ((rc = bufs.alloc(&d_real, real.size())) != TB_OK) return rc;
   HIP_TRY(hipMemcpy(d_real, real.data(), real.size() * sizeof(int), hipMemcpyHostToDevice));
   P.slice_real = d_real;
+#ifdef TB_TUNING
+  P.slice_census = nullptr;
+  if ((cfg.reserved[0] & 0x400000) && cfg.verbose) {
+    unsigned* d_census = nullptr;
+    if ((rc = bufs.alloc(&d_census, (size_t)plan.n_slices * 2)) != TB_OK) return rc;
+    HIP_TRY(hipMemset(d_census, 0, (size_t)plan.n_slices * 2 * sizeof(unsigned)));
+    P.slice_census = d_census;
+  }
+#endif
   // the lean implication records address Boolean words by a 16-bit word index inside the slab
   const bool lean = lay.compact && std::getenv("TB_NO_LEAN") == nullptr && (size_t)lay.bool_word0() + (size_t)lay.bool_words() <= 0x10000;  // (TB_NO_LEAN: A/B runs)
   // (TB_NO_CHAIN_RANGE / TB_NO_COND_WAKE: A/B runs of the two r04 wake-up filters)
@@ -1181,8 +1190,8 @@ int upload_event_tables(DevBuffers& bufs, DevProblem& P, const tb_config& cfg, c
     for (int q = 0; q < plan.n_slices; ++q) {
       int prefix = 0, classed = 0;
       for (int l = 0; l < 64; ++l) { const bool c = ((unsigned)packed[(size_t)q * 64 + l].x >> 16) != 0u; classed += c ? 1 : 0; if (c && prefix == l) ++prefix; }
-      std::fprintf(stderr, "%% slice %d: key %#x w0 %#x real %d lean %d | lanes with a class set %d, as a prefix %d\n", q, (unsigned)info[(size_t)q].x >> 16, (unsigned)info[(size_t)q].x,
-                   info[(size_t)q].y & 0xff, (info[(size_t)q].y >> 8) & 1, classed, prefix);
+      std::fprintf(stderr, "%% slice %d: key %#x w0 %#x real %d lean %d finite %d chain %d | lanes with a class set %d, as a prefix %d\n", q, (unsigned)info[(size_t)q].x >> 16, (unsigned)info[(size_t)q].x,
+                   info[(size_t)q].y & 0xff, (info[(size_t)q].y >> 8) & 1, (info[(size_t)q].y >> 9) & 1, (info[(size_t)q].y >> 10) & 1, classed, prefix);
     }
   int2* d_info = nullptr;
   if ((rc = bufs.alloc(&d_info, info.size())) != TB_OK) return rc;
@@ -1833,6 +1842,21 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
   long long best_block = -1;
   long long first_idle = -1, last_idle = 0, wait_ticks = 0;
 #ifdef TB_TUNING
+  if (s->P.slice_census != nullptr && s->cfg.verbose) {  // per-slice run census: the slices that run most, with their keys
+    std::vector<unsigned> c((size_t)s->plan.n_slices * 2);
+    if (hipMemcpy(c.data(), s->P.slice_census, c.size() * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
+      unsigned long long nodes = 0;
+      for (size_t b = 0; b < B; ++b) nodes += bst[b].nodes;
+      std::vector<int> order((size_t)s->plan.n_slices);
+      for (int i = 0; i < s->plan.n_slices; ++i) order[(size_t)i] = i;
+      std::sort(order.begin(), order.end(), [&](int a, int b2) { return c[(size_t)a * 2] > c[(size_t)b2 * 2]; });
+      const double n = (double)std::max<unsigned long long>(1, nodes);
+      for (int i = 0; i < std::min(40, s->plan.n_slices); ++i) {
+        const int q = order[(size_t)i];
+        std::fprintf(stderr, "%% slice-census %3d: slice %4d runs/node %.3f useless %.3f\n", i, q, c[(size_t)q * 2] / n, c[(size_t)q * 2 + 1] / n);
+      }
+    }
+  }
   if (s->cfg.verbose && std::getenv("TB_PRINT_REGIONS") != nullptr) {  // region census of the search kernel (kernels.hpp: TB_REGION; scripts/region_budget.py)
     unsigned long long r[72] = {0}, nodes = 0;
     for (size_t b = 0; b < B; ++b) { for (int i = 0; i < 72; ++i) r[i] += bst[b].reg[i]; nodes += bst[b].nodes; }

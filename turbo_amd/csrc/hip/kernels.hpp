@@ -1257,6 +1257,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             }
             tc.writes += run_writes_lean;
 #ifdef TB_TUNING
+            if (P.slice_census != nullptr && lane == 0) { atomicAdd(&glob(P.slice_census)[2 * s], 1u); if (mask_nz(acc) == 0ull) atomicAdd(&glob(P.slice_census)[2 * s + 1], 1u); }
+#endif
+#ifdef TB_TUNING
             if (prof && wave == 0) {
               const long long t_ = clock64();
               if (lane == 0) { sh.bs.dbg[1] += (int)((t_ - tprof) >> 4); sh.bs.dbg[6] += (int)((t_ - tprof) >> 4); sh.bs.dbg[11] += 1; }
@@ -1542,6 +1545,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             const unsigned cm = key & CLASS_SET_MASK;
             const int cls_of_slice = (cm & (cm - 1)) ? 10 : __builtin_ctz(cm | 0x400u);
             const bool useless = !wave_any(nar_all != 0);  // the run narrowed nothing
+#ifdef TB_TUNING
+            if (P.slice_census != nullptr && lane == 0) { atomicAdd(&glob(P.slice_census)[2 * s], 1u); if (useless) atomicAdd(&glob(P.slice_census)[2 * s + 1], 1u); }
+#endif
             if (rep == reps_of(P, 3) && (want == 0 || want - 1 == cls_of_slice) && (!(knobs(P) & 0x40) || useless)) {  // 0x40: only the runs that narrowed nothing
               wave_iters_total += (pk(P) & 0x400000) ? 1u : wave_iters;
               wave_active_total += wave_iters * (unsigned)(info.y & 0xff);
