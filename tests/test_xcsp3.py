@@ -111,6 +111,10 @@ R5 = range(0, 6)
                           "<maximum><list> m[1][] </list><condition> (eq,2) </condition></maximum>"
                           "<group><intension> ne(%0,%1) </intension><args> m[0][0] m[0][1] </args><args> m[0][1] m[1][1] </args></group>"),
      count(lambda a, b, c, d: min(a, c) >= 1 and max(c, d) == 2 and a != b and b != d, *[range(4)] * 4)),
+    ("group_variadic", inst('<array id="g" size="[2][3]"> 0..3 </array><var id="t"> 4 5 </var>',
+                            "<group><sum><list> %... </list><condition> (eq,%0) </condition></sum><args> t g[0][] </args><args> 5 g[1][] </args></group>"
+                            "<group><allDifferent> %... </allDifferent><args> g[0][0] g[1][0] g[1][1] </args></group>"),
+     count(lambda a, b, c, d, e, f, t: a + b + c == t and d + e + f == 5 and len({a, d, e}) == 3, *([range(4)] * 6 + [[4, 5]]))),
     ("allequal_count", inst('<array id="a" size="[4]"> 0..2 </array><var id="k"> 0..4 </var><array id="e" size="[2]"> 1..3 </array>',
                             "<allEqual> e[] </allEqual><count><list> a[] </list><values> 0 2 </values><condition> (eq,k) </condition></count>"
                             "<count><list> a[] </list><values> 1 </values><condition> (le,1) </condition></count>"),

@@ -10,7 +10,7 @@
 //                closed or not), <minimum>, <maximum>, <element> (list or <matrix>), <channel> (one or two lists), <noOverlap> (one or
 //                several dimensions), <cumulative> (constant or variable lengths and heights, optional <ends>), <binPacking>
 //                (<condition>, <limits> or <loads>), <knapsack>, <circuit> (sub-circuit semantics, optional <size>), <instantiation>,
-//                <clause>, <slide>, <group> with %i arguments, <block>; conditions with a value, a variable, an interval (in / notin
+//                <clause>, <slide>, <group> with %i and %... arguments, <block>; conditions with a value, a variable, an interval (in / notin
 //                a..b) or a set (in / notin {..})
 //   objectives   <minimize> / <maximize> of type expression, sum, product, minimum, maximum, nValues (optional <coeffs>)
 //
@@ -517,22 +517,31 @@ struct Translator {
   }
   void post_cond(const Val& lhs, const Cond& c) { post_linear({1}, {lhs}, c); }
 
-  static std::string subst(std::string t, const std::vector<std::string>& args) {
+  // `%i`: the i-th argument of the <args> element; `%...`: the arguments behind the highest numbered %i of the whole template (`rest`: its index; all of them
+  // when the template names none).
+  static std::string subst(std::string t, const std::vector<std::string>& args, size_t rest) {
+    if (t.find("%...") != std::string::npos) {
+      std::string tail;
+      for (size_t i = rest; i < args.size(); ++i) tail += args[i] + " ";
+      for (size_t q; (q = t.find("%...")) != std::string::npos;) t.replace(q, 4, tail);
+    }
     for (size_t i = args.size(); i-- > 0;) {
       const std::string key = "%" + std::to_string(i);
       for (size_t q; (q = t.find(key)) != std::string::npos;) t.replace(q, key.size(), args[i]);
     }
-    if (t.find("%...") != std::string::npos) {
-      std::string all;
-      for (auto& a : args) all += a + " ";
-      for (size_t q; (q = t.find("%...")) != std::string::npos;) t.replace(q, 4, all);
-    }
     return t;
   }
-  static std::unique_ptr<Xml> clone_subst(const Xml& n, const std::vector<std::string>& args) {
+  static size_t numbered_params(const Xml& n) {  // 1 + the highest i of a %i in the template, 0 when there is none
+    size_t k = 0;
+    for (size_t p = 0; (p = n.text.find('%', p)) != std::string::npos; ++p)
+      if (p + 1 < n.text.size() && std::isdigit((unsigned char)n.text[p + 1])) k = std::max(k, (size_t)std::stoul(n.text.substr(p + 1)) + 1);
+    for (auto& c : n.kids) k = std::max(k, numbered_params(*c));
+    return k;
+  }
+  static std::unique_ptr<Xml> clone_subst(const Xml& n, const std::vector<std::string>& args, size_t rest) {
     auto c = std::make_unique<Xml>();
-    c->name = n.name; c->attr = n.attr; c->text = subst(n.text, args);
-    for (auto& k : n.kids) c->kids.push_back(clone_subst(*k, args));
+    c->name = n.name; c->attr = n.attr; c->text = subst(n.text, args, rest);
+    for (auto& k : n.kids) c->kids.push_back(clone_subst(*k, args, rest));
     return c;
   }
   static std::string text_of(const Xml& n, const std::string& child) {
@@ -650,7 +659,8 @@ struct Translator {
       const Xml* tmpl = nullptr;
       for (auto& c : n.kids) if (c->name != "args") { tmpl = c.get(); break; }
       if (!tmpl) fail("group without a constraint template");
-      for (auto& c : n.kids) if (c->name == "args") constraint(*clone_subst(*tmpl, words(c->text)));
+      const size_t rest = numbered_params(*tmpl);
+      for (auto& c : n.kids) if (c->name == "args") constraint(*clone_subst(*tmpl, words(c->text), rest));
       return;
     }
     if (k == "intension") {
@@ -1078,9 +1088,7 @@ struct Translator {
       if (!l || !tmpl) fail("slide needs a list and a constraint template");
       std::vector<std::string> items;
       for (auto& v : val_list(l->text)) items.push_back(v.is_const ? std::to_string(v.c) : xcsp_name(v));
-      size_t arity = 0;
-      std::function<void(const Xml&)> scan = [&](const Xml& x) { for (size_t p = 0; (p = x.text.find('%', p)) != std::string::npos; ++p) if (p + 1 < x.text.size() && std::isdigit((unsigned char)x.text[p + 1])) arity = std::max(arity, (size_t)std::stoul(x.text.substr(p + 1)) + 1); for (auto& c : x.kids) scan(*c); };
-      scan(*tmpl);
+      const size_t arity = numbered_params(*tmpl);
       if (arity == 0) fail("slide: the template has no %i argument");
       const int64_t offset = l->get("offset").empty() ? 1 : std::stoll(l->get("offset"));
       if (offset < 1) fail("slide: offset must be at least 1");
@@ -1088,7 +1096,7 @@ struct Translator {
       for (size_t a = 0; circular ? a < items.size() : a + arity <= items.size(); a += (size_t)offset) {
         std::vector<std::string> args;
         for (size_t q = 0; q < arity; ++q) args.push_back(items[(a + q) % items.size()]);
-        constraint(*clone_subst(*tmpl, args));
+        constraint(*clone_subst(*tmpl, args, arity));
       }
       return;
     }
