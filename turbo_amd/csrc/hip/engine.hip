@@ -1129,6 +1129,8 @@ int32_t plan_records(const tb_config& cfg, const DeviceCaps& caps, int32_t n_var
   Layout l2;
   LaunchPlan p2;
   if (choose_layout(cfg, caps, n_vars, n_stores, stores, n_pad, &l2, &p2, pinned) != TB_OK || p2.mem_kind == TB_MEM_GLOBAL) return n_props;
+  // (the extra slices lengthen the bitmaps: not when that costs a workgroup per CU -- LDS comes in granules, plan_launch)
+  if (!(cfg.reserved[0] & 0x10) && p2.blocks_per_cu * p2.threads < plan->blocks_per_cu * plan->threads) return n_props;
   *lay = std::move(l2);
   *plan = p2;
   return n_pad;
