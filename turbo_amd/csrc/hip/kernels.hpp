@@ -575,7 +575,7 @@ __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store
 // With RM (tb_config.entailed_prop_removal) a slice whose byte is 0 is skipped for the whole subtree -- entailed-propagator removal
 // (FixpointSubsetGPU::select, gpu_dive_and_solve.hpp:334, barebones:984; a build option of the reference, off by
 // default) at the granularity of a wave's slice instead of a compacted index array.
-template <bool RM, int C>
+template <bool RM, int C, bool DEEP = false>
 __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, int2* store, const int4* props,
                                         unsigned char* slice_unent, ThreadCounters& tc, bool& all_entailed) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
@@ -591,61 +591,80 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
   for (;;) {
     k = it % 3;
     bool changed = false, un = false;
-    // The bytecode of the next 64-propagator slice is fetched while the current one is evaluated
-    // (software prefetch: the 16-B records come from L2 unless they were staged in LDS).
+    // The bytecode of the next 64-propagator slice is fetched while the current one is evaluated (software prefetch: the 16-B records come from L2 unless
+    // they were staged in LDS) -- and, in the WAC1 sweeps of the 1024-thread kernels (DEEP), those of the next THREE slices of the wave: an evaluation issues
+    // ~40 VALU + ~50 SALU, an L2 round trip under load is several times that, and with the 4 waves per SIMD of those kernels a wave waited for its record
+    // (wordpress7_500: VALU 46 % busy, 54 % of the wave-cycles parked).  r04, same box: wordpress7_500 wac1 1.97e6 -> 2.06e6 nodes/s, the synthetic 100k x 500k network
+    // 7.99e10 -> 8.24e10 propagations/s.  Not for the plain AC1 sweeps (-3 %) nor for the kernels of smaller workgroups, where the 18 more VGPRs cost waves
+    // (accap_a3 -8 %).  The loop is unrolled three times so that the three records need no rotation.
     // (the record array is padded to whole slices with idle records, and the prefetch index is clamped to the last
     //  slice instead of being predicated: an unconditional load lets the wait sink to the first use)
     const int last_base = ((n - 1) >> 6) << 6;
     const int wave_base = __builtin_amdgcn_readfirstlane(tid - lane);  // wave-uniform: slice addressing stays in SGPRs
-    int4 pr_next = idle_record();
-    if (n > 0) pr_next = props[imin(wave_base, last_base) + lane];
+    // one slice of a plain (AC1) sweep
+    auto ac1_step = [&](const int4 pr, const int base) {
+      const int i = base + lane;
+      const bool act = i < n;
+      if (rm) {
+        if (slice_unent[base >> 6] == 0) return;
+        bool ch = false, un_i = false;
+        apply<false, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
+        ++wave_evals;  // iterations x active propagators (gpu_dive_and_solve.hpp:304-306)
+        wave_active += (unsigned)imin(64, n - base);
+        changed |= ch; un |= un_i;
+        if (!wave_any(ch) && !wave_any(un_i) && lane == 0) slice_unent[base >> 6] = 0;
+        return;
+      }
+      apply<false, C>(pr, act, store, P.n_int, &sh.bot, changed, un, tc, dbg);
+    };
+    // WAC1: a wave iterates its 64 propagators to a local fixpoint before moving on (config.cpp:26,
+    // warp_fixpoint at barebones:955; the wave is 64 wide on CDNA).
+    auto wac1_step = [&](const int4 pr, const int base) {
+      const int i = base + lane;
+      const bool act = i < n;
+      if (rm && slice_unent[base >> 6] == 0) return;
+      for (unsigned local_iters = 1;; ++local_iters) {
+        bool ch = false, un_i = false;
+        apply<false, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
+        ++wave_evals;
+        wave_active += (unsigned)imin(64, n - base);
+        if (!wave_any(ch)) {
+          un |= un_i;
+          if (rm && !wave_any(un_i) && lane == 0) slice_unent[base >> 6] = 0;  // 1 -> 0 only: entailment is monotone below a node
+          break;
+        }
+        changed = true;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (ld(&sh.bot)) break;
+        // watchdog inside the wave-local loop: a slowly converging pair in one slice (x < y < x over 2^31 values) never
+        // reaches the block-level check below (wave-uniform counter: scalar work, once per 1024 iterations)
+        if ((local_iters % WAVE_WATCHDOG_PERIOD) == 0) {
+          if (lane == 0 && deadline_passed(P)) st(&sh.abort, 1);
+          if (ld(&sh.abort)) break;
+        }
+      }
+    };
     if (!wac1) {
+      int4 pr_next = idle_record();
+      if (n > 0) pr_next = props[imin(wave_base, last_base) + lane];
       for (int base = wave_base; base < n; base += T) {
-        const int i = base + lane;
-        const bool act = i < n;
         const int4 pr = pr_next;
         pr_next = props[imin(base + T, last_base) + lane];
-        if (rm) {
-          if (slice_unent[base >> 6] == 0) continue;
-          bool ch = false, un_i = false;
-          apply<false, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
-          ++wave_evals;  // iterations x active propagators (gpu_dive_and_solve.hpp:304-306)
-          wave_active += (unsigned)imin(64, n - base);
-          changed |= ch; un |= un_i;
-          if (!wave_any(ch) && !wave_any(un_i) && lane == 0) slice_unent[base >> 6] = 0;
-          continue;
-        }
-        apply<false, C>(pr, act, store, P.n_int, &sh.bot, changed, un, tc, dbg);
+        ac1_step(pr, base);
+      }
+    } else if (!DEEP) {
+      int4 pr_next = props[imin(wave_base, last_base) + lane];
+      for (int base = wave_base; base < n; base += T) {
+        const int4 pr = pr_next;
+        pr_next = props[imin(base + T, last_base) + lane];
+        wac1_step(pr, base);
       }
     } else {
-      // WAC1: a wave iterates its 64 propagators to a local fixpoint before moving on (config.cpp:26,
-      // warp_fixpoint at barebones:955; the wave is 64 wide on CDNA).
-      for (int base = wave_base; base < n; base += T) {
-        const int i = base + lane;
-        const bool act = i < n;
-        const int4 pr = pr_next;
-        pr_next = props[imin(base + T, last_base) + lane];
-        if (rm && slice_unent[base >> 6] == 0) continue;
-        for (unsigned local_iters = 1;; ++local_iters) {
-          bool ch = false, un_i = false;
-          apply<false, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, dbg);
-          ++wave_evals;
-          wave_active += (unsigned)imin(64, n - base);
-          if (!wave_any(ch)) {
-            un |= un_i;
-            if (rm && !wave_any(un_i) && lane == 0) slice_unent[base >> 6] = 0;  // 1 -> 0 only: entailment is monotone below a node
-            break;
-          }
-          changed = true;
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-          if (ld(&sh.bot)) break;
-          // watchdog inside the wave-local loop: a slowly converging pair in one slice (x < y < x over 2^31 values) never
-          // reaches the block-level check below (wave-uniform counter: scalar work, once per 1024 iterations)
-          if ((local_iters % WAVE_WATCHDOG_PERIOD) == 0) {
-            if (lane == 0 && deadline_passed(P)) st(&sh.abort, 1);
-            if (ld(&sh.abort)) break;
-          }
-        }
+      int4 q0 = props[imin(wave_base, last_base) + lane], q1 = props[imin(wave_base + T, last_base) + lane], q2 = props[imin(wave_base + 2 * T, last_base) + lane];  // (n > 0: WAC1 runs above its threshold)
+      for (int base = wave_base; base < n; base += 3 * T) {
+        { const int4 pr = q0; q0 = props[imin(base + 3 * T, last_base) + lane]; wac1_step(pr, base); }
+        if (base + T < n) { const int4 pr = q1; q1 = props[imin(base + 4 * T, last_base) + lane]; wac1_step(pr, base + T); }
+        if (base + 2 * T < n) { const int4 pr = q2; q2 = props[imin(base + 5 * T, last_base) + lane]; wac1_step(pr, base + 2 * T); }
       }
     }
     const bool any_changed = wave_any(changed), any_un = wave_any(un);
@@ -2095,7 +2114,7 @@ __device__ __forceinline__ void skip_subtree(const DevProblem& P, BlockShared& s
 
 struct NodeTimers { long long t_last; };
 
-template <bool EVENT, int C, bool RM, int MEM, int TB = 0>
+template <bool EVENT, int C, bool RM, int MEM, int TB = 0, bool DEEP = false>
 __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
                                                     int2* best_store, Mailbox* mbox, ThreadCounters& tc) {
   const int tid = threadIdx.x;
@@ -2110,7 +2129,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
     const FpResult r = fixpoint_event_call<C, MEM, TB>(&P, lds_off(&sh), SL ? lds_off(store) : 0u, SL ? nullptr : store, PL ? lds_off(props) : 0u, PL ? nullptr : props,
                                                    lds_off(es.dirty), lds_off(es.list), tc.writes);
     iters = r.rounds; all_entailed = r.all_entailed != 0; tc.writes = r.writes;
-  } else iters = fixpoint<RM, C>(P, sh, store, props, es.unent, tc, all_entailed);
+  } else iters = fixpoint<RM, C, DEEP>(P, sh, store, props, es.unent, tc, all_entailed);
   flush_writes(sh, tc, false);
   const bool aborted = ld(&sh.abort) != 0;
   const bool failed = !aborted && ld(&sh.bot) != 0;
@@ -2263,13 +2282,13 @@ static __device__ TB_SPLIT_ATTR void split_event(const DevProblem* Pp, unsigned 
   split<C, TB>(constant_problem(Pp), *lds_ptr<BlockShared>(sh_off), glob(dec), SL ? lds_ptr<const int2>(store_off) : glob(gstore));
 }
 
-template <bool EVENT, int C, bool RM, int MEM, int TB = 0>
+template <bool EVENT, int C, bool RM, int MEM, int TB = 0, bool DEEP = false>
 __device__ __forceinline__ void propagate_node(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es,
                                                int2* best_store, Mailbox* mbox, ThreadCounters& tc) {
   constexpr bool SL = MEM >= TB_MEM_STORE_SHARED, PL = MEM == TB_MEM_TCN_SHARED;
   if constexpr (EVENT) tc.writes = propagate_node_event<C, MEM, TB>(&P, lds_off(&sh), SL ? lds_off(store) : 0u, SL ? nullptr : store, PL ? lds_off(props) : 0u, PL ? nullptr : props,
                                                                 lds_off(es.dirty), lds_off(es.list), best_store, mbox, tc.writes);
-  else propagate_node_impl<EVENT, C, RM, MEM, TB>(P, sh, store, props, es, best_store, mbox, tc);
+  else propagate_node_impl<EVENT, C, RM, MEM, TB, DEEP>(P, sh, store, props, es, best_store, mbox, tc);
 }
 template <bool EVENT, int C, bool SL, int TB = 0>
 __device__ __forceinline__ void split_node(const DevProblem& P, BlockShared& sh, Decision* dec, int2* store) {
@@ -2413,7 +2432,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_
         if (sh.stop) break;
       }
       // II. propagate
-      propagate_node<EVENT, C, RM, MEM, TB>(P, sh, store, props, es, nullptr, mbox, tc);
+      propagate_node<EVENT, C, RM, MEM, TB, (!EVENT && TMAX == 1024)>(P, sh, store, props, es, nullptr, mbox, tc);
       if (sh.stop) break;
       TB_REGION(30);
       int2* const snap = snap_of();
@@ -2594,7 +2613,7 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
     if (EVENT) { if (tid == 0) { sh.ev_all = 1; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; } __syncthreads(); }
     if (!ld(&sh.bot)) {
       if constexpr (EVENT) iters = fixpoint_event<C>(P, sh, store, props, es, tc, all_entailed);
-      else iters = fixpoint<RM, C>(P, sh, store, props, es.unent, tc, all_entailed);
+      else iters = fixpoint<RM, C, (TMAX == 1024)>(P, sh, store, props, es.unent, tc, all_entailed);
     }
     if (MEM >= TB_MEM_STORE_SHARED) copy_store(gstore, store, VX);
     flush_writes(sh, tc, true);
