@@ -111,6 +111,12 @@ typedef struct {
                                            on (tb_session_debug_last_store); 0x1000000 no work stealing between linked GPUs (A/B runs, tests);
                                            0x2000000 do not propagate the root at session creation (every subproblem re-derives its fixpoint, as in r01);
                                        [1] capacity of the event change list; [2] cap on workgroups per CU */
+  int32_t leaf_requires_assignment; /* which leaf rule the search follows.  0 (`-arch barebones`): a node is a solution as soon as every propagator is
+                                       entailed (barebones_dive_and_solve.hpp:988-993) -- the solution may be a box with unassigned variables.
+                                       1 (`-arch gpu`, and the reference's `-arch cpu`): ... and every variable of the store is assigned
+                                       (`is_extractable<AtomicExtraction>`, gpu_dive_and_solve.hpp:333-338, cpu_solving.hpp:33-40); an all-entailed
+                                       node with an open variable is an inner node, the search keeps branching below it.  (Takes the struct's former tail
+                                       padding: sizeof(tb_config) is unchanged, a caller that zero-initialises gets the barebones rule.) */
 } tb_config;
 
 /* Statistics<> (include/statistics.hpp:134-154) + TimingStatistics (statistics.hpp:13-29). */
@@ -132,7 +138,10 @@ typedef struct {
   int64_t min_block_ns, max_block_ns; /* first and last workgroup to leave the kernel (the reference's first_block_idle_time is the min) */
   uint64_t active_lane_evaluations; /* num_deductions counts wave iterations x wave width, as the reference does (barebones:958-960); this is the
                                        same count without the idle lanes of partly filled slices (class padding, the network's last slice) */
+  int64_t prof_ns[4];               /* tuning build with the in-kernel phase timers on (reserved[0] & 0x10000), summed over workgroups, 0 otherwise -- indexed by
+                                       tb_prof: phases of THIS engine, kept apart from the reference's timers (r04 lent them four of those keys) */
 } tb_stats;
+enum tb_prof { TB_PROF_SEEDING = 0, TB_PROF_ROUNDS = 1, TB_PROF_SNAPSHOT_PUSH = 2, TB_PROF_VARIABLE_SELECTION = 3, TB_NUM_PROF = 4 };
 
 enum tb_timer { /* enum class Timer, statistics.hpp:13-29 (same order, 11 timers) */
   TB_T_OVERALL = 0, TB_T_PREPROCESSING = 1, TB_T_SEARCH = 2, TB_T_FIXPOINT = 3, TB_T_TRANSFER_CPU2GPU = 4,

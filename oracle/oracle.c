@@ -309,6 +309,21 @@ static void eng_embed(engine_t* e, int32_t v, int32_t l, int32_t u) {
 
 static inline int splittable(const orc_itv d) { return d.lb != d.ub && !is_inf(d.lb) && !is_inf(d.ub); }
 
+/* VStore::is_extractable<AtomicExtraction> of a store that is not bot: every variable is assigned ("When the problem is extractable, then all
+ * variables are assigned to a single value", hybrid_dive_and_solve.hpp:531).  The `gpu` and `cpu` paths ask it of a node whose propagators are all
+ * entailed before they call it a solution (gpu_dive_and_solve.hpp:333-338, cpu_solving.hpp:33-40); barebones does not (barebones:988-993). */
+static int all_assigned(int32_t n_vars, const orc_itv* store) {
+  for (int32_t v = 0; v < n_vars; ++v)
+    if (store[v].lb != store[v].ub) return 0;
+  return 1;
+}
+/* is this (non-failed) node a solution leaf? */
+static int solution_node(const orc_config* cfg, int32_t n_vars, const orc_itv* store, int32_t n_props, const orc_prop* props) {
+  for (int32_t i = 0; i < n_props; ++i)
+    if (!orc_ask(&props[i], store)) return 0;
+  return !cfg->leaf_requires_assignment || all_assigned(n_vars, store);
+}
+
 static void push_decision(engine_t* e, int32_t val_order, int32_t var) {
   if (e->depth + 1 >= e->dec_cap) {
     e->dec_cap *= 2;
@@ -381,9 +396,7 @@ static int propagate(engine_t* e, int is_dive) {
   int failed = fixpoint(e->n_props, e->props, e->store, e->store_bot, &it, &de);
   int leaf = 0;
   if (!failed) {
-    int ent = 1;
-    for (int32_t i = 0; i < e->n_props && ent; ++i) ent = orc_ask(&e->props[i], e->store);
-    if (ent) {
+    if (solution_node(e->cfg, e->n_vars, e->store, e->n_props, e->props)) {
       leaf = 1;
       int accept;
       if (e->obj_var >= 0) {
@@ -448,8 +461,7 @@ int orc_replay_path(const orc_config* cfg, int32_t n_vars, const orc_itv* root_s
   /* the dive */
   while (remaining > dive_levels_left && !done) {
     failed = fixpoint(n_props, props, e->store, e->store_bot, &it, &de);
-    int ent = !failed;
-    for (int32_t i = 0; i < n_props && ent; ++i) ent = orc_ask(&props[i], e->store);
+    const int ent = !failed && solution_node(cfg, n_vars, e->store, n_props, props);
     if (failed || ent || !split(e)) { mismatch = -2 - (cfg->subproblems_power - remaining); done = 1; break; }
     --remaining; --e->depth;
     const int bit = (int)((subproblem >> remaining) & 1u);
@@ -460,8 +472,7 @@ int orc_replay_path(const orc_config* cfg, int32_t n_vars, const orc_itv* root_s
     for (int32_t i = 0; i < n_decisions && !done; ++i) {
       if (obj_var >= 0 && decisions[i].objective_ub != PINF) eng_embed(e, obj_var, NINF, decisions[i].objective_ub);
       failed = fixpoint(n_props, props, e->store, e->store_bot, &it, &de);
-      int ent = !failed;
-      for (int32_t q = 0; q < n_props && ent; ++q) ent = orc_ask(&props[q], e->store);
+      const int ent = !failed && solution_node(cfg, n_vars, e->store, n_props, props);
       if (failed || ent || !split(e)) { mismatch = i; done = 1; break; }
       decision_t* dd = &e->dec[e->depth - 1];
       const orc_path_decision* r = &decisions[i];

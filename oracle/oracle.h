@@ -60,6 +60,10 @@ typedef struct {
   uint64_t stop_after_n_nodes;  /* 0 = no limit (config.hpp -cutnodes) */
   uint64_t stop_after_n_solutions; /* satisfaction problems only; 0 = all */
   uint64_t timeout_ms;          /* 0 = none */
+  int32_t leaf_requires_assignment; /* which leaf rule: 0 = barebones' (a node whose propagators are all entailed is a solution, barebones:988-993);
+                                       1 = the `gpu` / `cpu` paths' (... and every variable is assigned: is_extractable<AtomicExtraction>,
+                                       gpu_dive_and_solve.hpp:333-338, cpu_solving.hpp:33-40; otherwise the search keeps branching) */
+  int32_t reserved;
 } orc_config;
 
 typedef struct {

@@ -22,7 +22,7 @@ class OrcConfig(C.Structure):
     _fields_ = [("subproblems_power", C.c_int32), ("has_eps_strategy", C.c_int32),
                 ("use_fixed_bound", C.c_int32), ("fixed_bound", C.c_int32),
                 ("stop_after_n_nodes", C.c_uint64), ("stop_after_n_solutions", C.c_uint64),
-                ("timeout_ms", C.c_uint64)]
+                ("timeout_ms", C.c_uint64), ("leaf_requires_assignment", C.c_int32), ("reserved", C.c_int32)]
 
 
 class OrcStats(C.Structure):
@@ -97,12 +97,14 @@ def propagate(store: np.ndarray, props: np.ndarray):
 
 
 def solve(tcn, subproblems_power: int = 0, cutnodes: int = 0, timeout_ms: int = 0,
-          stop_after_n_solutions: int = 1, fixed_bound=None):
+          stop_after_n_solutions: int = 1, fixed_bound=None, leaf_requires_assignment: int = 0):
     """Full sequential search over a turbo_amd.frontend.TCN-like object.
+    leaf_requires_assignment: 0 = barebones' leaf rule (all propagators entailed), 1 = the gpu / cpu paths' (... and every variable assigned).
     Returns (has_solution, best_store, stats_dict)."""
     cfg = OrcConfig(subproblems_power=subproblems_power, has_eps_strategy=int(bool(getattr(tcn, "has_eps_strategy", False))),
                     use_fixed_bound=int(fixed_bound is not None), fixed_bound=int(fixed_bound or 0),
-                    stop_after_n_nodes=cutnodes, stop_after_n_solutions=stop_after_n_solutions, timeout_ms=timeout_ms)
+                    stop_after_n_nodes=cutnodes, stop_after_n_solutions=stop_after_n_solutions, timeout_ms=timeout_ms,
+                    leaf_requires_assignment=int(leaf_requires_assignment))
     store = np.ascontiguousarray(tcn.store, dtype=ITV)
     props = np.ascontiguousarray(tcn.props, dtype=PROP)
     vo = np.ascontiguousarray(tcn.strat_var_order, dtype=np.int32)
@@ -120,8 +122,8 @@ def solve(tcn, subproblems_power: int = 0, cutnodes: int = 0, timeout_ms: int = 
     return bool(has.value), best, stats.as_dict()
 
 
-def enumerate_solutions(tcn, capacity: int = 100000):
-    """Every solution leaf (a box: unassigned variables are free) of a satisfaction problem, in DFS order."""
+def enumerate_solutions(tcn, capacity: int = 100000, leaf_requires_assignment: int = 0):
+    """Every solution leaf of a satisfaction problem, in DFS order (barebones' rule: a box whose unassigned variables are free; the gpu / cpu rule: full assignments)."""
     L = lib()
     L.orc_set_solution_sink.argtypes = [C.c_void_p, C.c_int64]
     L.orc_solution_sink_count.restype = C.c_int64
@@ -129,7 +131,7 @@ def enumerate_solutions(tcn, capacity: int = 100000):
     buf = np.zeros((capacity, max(n, 1)), dtype=ITV)
     L.orc_set_solution_sink(buf.ctypes.data, capacity)
     try:
-        _, _, st = solve(tcn, stop_after_n_solutions=0)
+        _, _, st = solve(tcn, stop_after_n_solutions=0, leaf_requires_assignment=leaf_requires_assignment)
         k = int(L.orc_solution_sink_count())
     finally:
         L.orc_set_solution_sink(None, 0)
@@ -138,10 +140,11 @@ def enumerate_solutions(tcn, capacity: int = 100000):
     return buf[:k, :n], st
 
 
-def replay_path(tcn, subproblems_power: int, header: dict, decisions: np.ndarray):
+def replay_path(tcn, subproblems_power: int, header: dict, decisions: np.ndarray, leaf_requires_assignment: int = 0):
     """Replay a path reported by the HIP engine (capi.Session.debug_path): returns (store under the last node, failed, mismatch) with
     mismatch == -1 when every recorded decision is the one this oracle takes."""
-    cfg = OrcConfig(subproblems_power=subproblems_power, has_eps_strategy=int(bool(getattr(tcn, "has_eps_strategy", False))))
+    cfg = OrcConfig(subproblems_power=subproblems_power, has_eps_strategy=int(bool(getattr(tcn, "has_eps_strategy", False))),
+                    leaf_requires_assignment=int(leaf_requires_assignment))
     store = np.ascontiguousarray(tcn.store, dtype=ITV)
     props = np.ascontiguousarray(tcn.props, dtype=PROP)
     vo = np.ascontiguousarray(tcn.strat_var_order, dtype=np.int32)
@@ -173,7 +176,7 @@ class OrcPathHeader(C.Structure):
     _fields_ = [("subproblem", C.c_uint64), ("dive_levels_left", C.c_int32), ("depth", C.c_int32), ("decisions", C.c_int32), ("last_objective_ub", C.c_int32)]
 
 
-def solve_with_path(tcn, cutnodes: int, subproblems_power: int = 0, capacity: int = 4096):
+def solve_with_path(tcn, cutnodes: int, subproblems_power: int = 0, capacity: int = 4096, leaf_requires_assignment: int = 0):
     """solve() with a node budget, plus the path the search stood on when it returned (header dict, decisions) and the store under it:
     (has, best, stats, header, decisions, last_store, last_failed)."""
     L = lib()
@@ -189,7 +192,7 @@ def solve_with_path(tcn, cutnodes: int, subproblems_power: int = 0, capacity: in
     L.orc_set_last_store_sink(last.ctypes.data)
     L.orc_set_node_trace(trace.ctypes.data, trace.shape[0])
     try:
-        has, best, st = solve(tcn, subproblems_power=subproblems_power, cutnodes=cutnodes)
+        has, best, st = solve(tcn, subproblems_power=subproblems_power, cutnodes=cutnodes, leaf_requires_assignment=leaf_requires_assignment)
     finally:
         L.orc_set_path_sink(None, None, 0)
         L.orc_set_last_store_sink(None)
@@ -198,7 +201,7 @@ def solve_with_path(tcn, cutnodes: int, subproblems_power: int = 0, capacity: in
     return has, best, st, header, dec[:hdr.decisions].copy(), last[:n], bool(trace[st["nodes"] - 1]) if st["nodes"] else False
 
 
-def solve_traced(tcn, cutnodes: int, subproblems_power: int = 0):
+def solve_traced(tcn, cutnodes: int, subproblems_power: int = 0, leaf_requires_assignment: int = 0):
     """solve() with a node budget, plus the failed flag of every node and the store the search stopped on."""
     L = lib()
     L.orc_set_node_trace.argtypes = [C.c_void_p, C.c_int64]
@@ -209,7 +212,7 @@ def solve_traced(tcn, cutnodes: int, subproblems_power: int = 0):
     L.orc_set_node_trace(trace.ctypes.data, trace.shape[0])
     L.orc_set_last_store_sink(last.ctypes.data)
     try:
-        has, best, st = solve(tcn, subproblems_power=subproblems_power, cutnodes=cutnodes)
+        has, best, st = solve(tcn, subproblems_power=subproblems_power, cutnodes=cutnodes, leaf_requires_assignment=leaf_requires_assignment)
     finally:
         L.orc_set_node_trace(None, 0)
         L.orc_set_last_store_sink(None)

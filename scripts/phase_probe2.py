@@ -16,5 +16,6 @@ for bits in (0, 0x10000):
     n, B = st["nodes"], st["num_blocks"]
     secs = st["kernel_ns"] * 1e-9
     per = {T[i]: st["timers_ns"][i] / n / 1e3 for i in range(len(T))}
+    per.update({"prof_" + k.lower(): v / n / 1e3 for k, v in zip(capi.PROF, st["prof_ns"])})  # the engine's own phases (tuning build)
     print(f"{name} fp={fp} bits={bits:#x}: {n/secs:.3e} nodes/s, {B} workgroups, {secs*1e6*B/n:.1f} us per node per workgroup, rounds/node {st['fixpoint_iterations']/n:.1f}")
     print("   us per node: " + ", ".join(f"{k}={v:.1f}" for k, v in per.items() if k not in ("OVERALL", "LATEST_BEST_OBJ_FOUND", "FIRST_BLOCK_IDLE")))

@@ -30,8 +30,10 @@ if not m:
 st = json.loads(m.group(1))
 T = st["timers_ns"]
 n = st["nodes"]
-names = ["overall", "snapshot_push", "search", "fixpoint", "fixpoint_rounds", "transfer_gpu2cpu", "variable_selection", "fixpoint_seeding", "dive"]
+names = ["overall", "preprocessing", "search", "fixpoint", "transfer_cpu2gpu", "transfer_gpu2cpu", "select_fp_functions", "wait_cpu", "dive"]
 per_node = {names[i]: T[i] / n for i in range(len(names))}
+# the engine's own phases (tb_stats.prof_ns: r04 had lent them four of the reference's timer keys)
+per_node.update({k: v / n for k, v in zip(["fixpoint_seeding", "fixpoint_rounds", "snapshot_push", "variable_selection"], st["prof_ns"])})
 prof = [l for l in p.stderr.splitlines() if l.startswith("% event-profile")]
 last = {}
 for l in prof:  # the second (last) search's lines win

@@ -44,8 +44,22 @@ def random_model(seed: int) -> str:
         else:
             lines.append(f"constraint int_abs({rng.choice(xs)},{rng.choice(xs)});")
     g = rng.random()
-    lines.append(f"solve minimize {rng.choice(xs)};" if g < 0.4 else f"solve maximize {rng.choice(xs)};" if g < 0.8 else "solve satisfy;")
+    goal = f"minimize {rng.choice(xs)}" if g < 0.4 else f"maximize {rng.choice(xs)}" if g < 0.8 else "satisfy"
+    # r05: a search annotation over every variable / value order of the reference (barebones_dive_and_solve.hpp:193-221,362-387) on part of the variables,
+    # alone or as a seq_search of two (drawn from a generator of its own: the constraints of a seed are what they were)
+    ann_rng = random.Random(seed * 7919 + 13)
+    ann = ""
+    if ann_rng.random() < 0.6:
+        def one():
+            vs = ann_rng.sample(xs + bs, ann_rng.randint(1, len(xs + bs)))
+            return f"int_search([{','.join(vs)}],{ann_rng.choice(VAR_ORDER_NAMES)},{ann_rng.choice(VAL_ORDER_NAMES)},complete)"
+        ann = f" :: {one()}" if ann_rng.random() < 0.6 else f" :: seq_search([{one()},{one()}])"
+    lines.append(f"solve{ann} {goal};")
     return "\n".join(lines) + "\n"
+
+
+VAR_ORDER_NAMES = ["input_order", "first_fail", "anti_first_fail", "smallest", "largest"]
+VAL_ORDER_NAMES = ["indomain_min", "indomain_max", "indomain_split", "indomain_reverse_split"]
 
 
 NINF, PINF = -2**31, 2**31 - 1
@@ -275,5 +289,15 @@ def element_model(seed: int) -> str:
     lines.append(f"constraint int_lin_eq([{','.join(['1'] * len(obj))},-1],[{','.join(v for v, _, _ in obj)},obj],0);")
     order = rng.choice(["first_fail", "input_order", "smallest"])
     val = rng.choice(["indomain_min", "indomain_split", "indomain_max"])
-    lines.append(f"solve :: int_search([{','.join(idxs)}],{order},{val},complete) {rng.choice(['minimize', 'minimize', 'maximize'])} obj;")
+    goal = rng.choice(['minimize', 'minimize', 'maximize'])
+    # r05: every second model searches with the orders r04 never drew -- anti_first_fail, largest, indomain_reverse_split -- and a seq_search that also
+    # branches on the looked-up values (a generator of its own: the constraints of a seed are what they were)
+    ann_rng = random.Random(seed * 104729 + 7)
+    if ann_rng.random() < 0.5:
+        a = f"int_search([{','.join(idxs)}],{ann_rng.choice(VAR_ORDER_NAMES)},{ann_rng.choice(VAL_ORDER_NAMES)},complete)"
+        b = f"int_search([{','.join(v for v, _, _ in vals)}],{ann_rng.choice(['anti_first_fail', 'largest', 'smallest'])},{ann_rng.choice(VAL_ORDER_NAMES)},complete)"
+        ann = a if ann_rng.random() < 0.5 else f"seq_search([{b},{a}])" if ann_rng.random() < 0.5 else f"seq_search([{a},{b}])"
+        lines.append(f"solve :: {ann} {goal} obj;")
+    else:
+        lines.append(f"solve :: int_search([{','.join(idxs)}],{order},{val},complete) {goal} obj;")
     return "\n".join(lines) + "\n"

@@ -38,9 +38,10 @@ def test_front_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     # sizes computed from include/turbo_hip.h by hand: tb_config = 7*8 + 21*4 = 140 -> 144 (8-byte alignment),
-    # tb_stats = 9*8 + 11*8 + 3*8 + 12*4 + 6*8 = 280
+    # tb_stats = 9*8 + 11*8 + 3*8 + 12*4 + 6*8 + 4*8 = 312.  (r05: leaf_requires_assignment took tb_config's 4 bytes of tail padding, prof_ns[4] were appended to tb_stats)
     assert ctypes.sizeof(capi.TbConfig) == 144
-    assert ctypes.sizeof(capi.TbStats) == 280
+    assert capi.TbConfig.leaf_requires_assignment.offset == 140
+    assert ctypes.sizeof(capi.TbStats) == 312
 
 
 def test_no_device_is_a_loud_error():

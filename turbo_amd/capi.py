@@ -21,6 +21,7 @@ TB_NINF = -(2**31)
 MEM_KINDS = ["global", "store_shared", "tcn_shared"]
 TIMERS = ["OVERALL", "PREPROCESSING", "SEARCH", "FIXPOINT", "TRANSFER_CPU2GPU", "TRANSFER_GPU2CPU",
           "SELECT_FP_FUNCTIONS", "WAIT_CPU", "DIVE", "LATEST_BEST_OBJ_FOUND", "FIRST_BLOCK_IDLE"]
+PROF = ["SEEDING", "ROUNDS", "SNAPSHOT_PUSH", "VARIABLE_SELECTION"]  # tb_stats.prof_ns (tuning build, knob 0x10000)
 
 EXPORTS = ["tb_version", "tb_last_error", "tb_device_count", "tb_get_device_info", "tb_eps_local_count", "tb_eps_global_index",
            "tb_propagate", "tb_solve",
@@ -40,7 +41,7 @@ class TbConfig(C.Structure):
                 ("use_fixed_bound", C.c_int32), ("fixed_bound", C.c_int32), ("deterministic", C.c_int32),
                 ("snapshot_levels", C.c_int32), ("stream_solutions", C.c_int32), ("entailed_prop_removal", C.c_int32),
                 ("eps_chunk_log2", C.c_int32), ("decision_stack_depth", C.c_int32), ("poll_period_us", C.c_int32),
-                ("reserved", C.c_int32 * 3)]
+                ("reserved", C.c_int32 * 3), ("leaf_requires_assignment", C.c_int32)]
 
 
 class TbStats(C.Structure):
@@ -55,7 +56,8 @@ class TbStats(C.Structure):
                 ("subproblems_power", C.c_int32), ("best_bound", C.c_int32), ("best_subproblem", C.c_int32),
                 ("interrupted", C.c_int32), ("reserved", C.c_int32 * 2),
                 ("eps_local_subproblems", C.c_uint64), ("eps_stolen_subproblems", C.c_uint64), ("wait_time_ns", C.c_int64),
-                ("min_block_ns", C.c_int64), ("max_block_ns", C.c_int64), ("active_lane_evaluations", C.c_uint64)]
+                ("min_block_ns", C.c_int64), ("max_block_ns", C.c_int64), ("active_lane_evaluations", C.c_uint64),
+                ("prof_ns", C.c_int64 * 4)]
 
     def as_dict(self) -> dict:
         d = {}

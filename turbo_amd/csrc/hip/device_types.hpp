@@ -125,6 +125,7 @@ struct BlockStats {
   int why, pad_why;                 // debugging: reasons that cleared `exhaustive` (bit mask)
 #ifdef TB_TUNING
   unsigned reg[72];                 // tuning build: how often a wave passed each region marker of the search kernel (kernels.hpp: TB_REGION)
+  long long prof[TB_NUM_PROF];      // tuning build, knob 0x10000: thread 0's wall clock in the engine's own phases (tb_stats.prof_ns)
 #endif
   int dbg[TB_DBG_WORDS];            // tuning build: census of the event fixpoint / first violation found by its self-check (production keeps 4 words: the
                                     // block sits in every workgroup's LDS, where 1280-byte granules decide how many workgroups a CU holds)
@@ -185,6 +186,7 @@ struct DevProblem {
   int root_fixpoint;       // 1: root_store is already the fixpoint of the root node (propagated once at session creation): the first
                            // node of every subproblem then has nothing to propagate instead of re-deriving it from the caller's store
   int steal;               // 1: a device whose queue is empty takes work from its peers (0: tb_config.reserved[0] & 0x1000000, A/B runs and tests)
+  int leaf_assign;         // tb_config.leaf_requires_assignment: an all-entailed node is a solution only when every variable of the slab is assigned (gpu_dive_and_solve.hpp:337)
   unsigned long long cut_nodes;       // 0 = none
   unsigned long long cut_nodes_total; // 0 = none: budget of all workgroups of all GPUs together
   unsigned long long stop_after_n_solutions;

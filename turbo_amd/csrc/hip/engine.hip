@@ -105,7 +105,7 @@ struct Layout {
   std::vector<int> base;  // [n_int] (0 for the wide ones)
   // what the device calls a reference to variable i: the id, and for a narrow integer of COMPACT8 its base in bits 16-30
   int ref(int i) const { return (c8 && i >= n_wide && i < n_int) ? (i | ((base[(size_t)i] + 16384) << 16)) : i; }
-  int dev_n_int() const { return c8 ? (n_int | (n_wide << 16)) : n_int; }  // DevProblem::n_int
+  int dev_n_int() const { return c8 ? (int)((unsigned)n_int | ((unsigned)n_wide << 16)) : n_int; }  // DevProblem::n_int (unsigned: n_wide may reach 2^15 and beyond)
   int n_vars = 0, n_int = 0, n_bool = 0;
   int n_out = 0;               // constants kept out of the slab: internal ids n_int + n_bool .. n_vars - 1
   std::vector<int> out_value;  // [n_out] their values
@@ -271,13 +271,14 @@ inline size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 // LDS is handed out in granules of 320 dwords on gfx950 (160 KiB / 128): a workgroup asking for 12 336 B occupies 12 800 B, and 12 -- not 13 -- of
 // them share a CU, whatever hipOccupancyMaxActiveBlocksPerMultiprocessor answers.  Measured r04 (wordpress7_500, 128-thread event workgroups): 12 336 B
 // and 11 568 B per workgroup run at 4.27e7 and 4.35e7 nodes/s, 11 504 B (nine granules: 14 workgroups per CU) at 4.64e7.
-constexpr size_t LDS_GRANULE = 1280;
-inline size_t lds_footprint(size_t bytes) { return (bytes + LDS_GRANULE - 1) / LDS_GRANULE * LDS_GRANULE; }
+// (1/128 of a CU's LDS on the CDNA parts: 1280 B of gfx950's 160 KiB, 512 B of gfx942's 64 KiB -- taken from the device, not assumed)
+inline size_t lds_granule(const DeviceCaps& caps) { return std::max<size_t>(128, (size_t)caps.lds_per_cu / 128); }
+inline size_t lds_footprint(const DeviceCaps& caps, size_t bytes) { const size_t g = lds_granule(caps); return (bytes + g - 1) / g * g; }
 
 // Which memory holds what (the MemoryKind decision of memory_gpu.hpp:56-83 with CDNA4 numbers:
 // 160 KiB of LDS per CU, wave64, at most 32 waves per CU) and how many workgroups to launch
 // (barebones:530-546: occupancy x CUs, capped by -or).
-int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay, int n_props, LaunchPlan* plan) {
+int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay, int n_props, LaunchPlan* plan, bool search = true) {
   const int n_vars = lay.n_vars;
   LaunchPlan p;
   int T = cfg.threads_per_block;
@@ -292,7 +293,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     // A store that leaves room for a single workgroup per CU: make that workgroup wide enough to fill the CU's 16 wave
     // slots (trains15 simplified, 87 KB store: 4.9e6 -> 7.3e6 nodes/s going from 512 to 1024 threads).
     const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64, event) * 8) + dirty_region_bytes(((n_props + 63) / 64 + 31) / 32) + 4096 + SH_BYTES;
-    while (T < 1024 && slab <= (size_t)caps.lds_per_cu && std::min<size_t>((size_t)caps.lds_per_cu / lds_footprint(slab), (size_t)(2048 / T)) * (size_t)(T / 64) < 16) T *= 2;
+    while (T < 1024 && slab <= (size_t)caps.lds_per_cu && std::min<size_t>((size_t)caps.lds_per_cu / lds_footprint(caps, slab), (size_t)(2048 / T)) * (size_t)(T / 64) < 16) T *= 2;
   }
   bool small_wg = false;
   if (auto_threads && T == 256 && !cfg.only_global_memory && (event || n_props < 2048)) {
@@ -302,7 +303,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     // 12 x 128 3.95e7.  trains15 (6 slabs fit) keeps its four waves.
     // (with the shortest change list the planner may pick, see below)
     const size_t slab = align16((size_t)lay.vext((n_props + 63) / 64, event) * 8) + dirty_region_bytes(((n_props + 63) / 64 + 31) / 32) + align16(32 * 4) + SH_BYTES;
-    if (lds_footprint(slab) * 10 <= (size_t)caps.lds_per_cu) { T = 128; small_wg = true; }
+    if (lds_footprint(caps, slab) * 10 <= (size_t)caps.lds_per_cu) { T = 128; small_wg = true; }
   }
   if (T != 64 && T != 128 && T != 256 && T != 512 && T != 1024) return fail(TB_ERR_INVALID, "threads_per_block must be 64, 128, 256, 512 or 1024");
   p.threads = T;
@@ -332,7 +333,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     // (+8.7 % nodes/s), trains15 6 -> 7 (+4.7 %).
     const size_t base = fixed + align16((size_t)vext * 8) + dirty_region_bytes(dirty_words);
     const int reg_cap = std::max(1, 28 / std::max(1, T / 64));
-    auto per_cu = [&](int cap) { return std::min<int>({bpc_max, reg_cap, (int)((size_t)caps.lds_per_cu / lds_footprint(base + align16((size_t)cap * 4)))}); };
+    auto per_cu = [&](int cap) { return std::min<int>({bpc_max, reg_cap, (int)((size_t)caps.lds_per_cu / lds_footprint(caps, base + align16((size_t)cap * 4)))}); };
     int best_cap = p.chg_cap;
     for (int cap : {192, 128, 96, 64, 48, 32})
       if (cap < best_cap && per_cu(cap) > per_cu(best_cap)) best_cap = cap;
@@ -345,26 +346,26 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   // Hot tier (r04): a plain store in global memory, 1024-thread workgroups (one per CU, whose LDS would otherwise hold a few KB of bitmaps): the first
   // HOT_VARS intervals live in LDS.  (TB_NO_HOT_TIER: A/B runs.)
   auto hot_tier = [&]() {
-    if (lay.compact || T != 1024 || n_vars <= HOT_VARS || cfg.entailed_prop_removal || std::getenv("TB_NO_HOT_TIER") != nullptr) return false;
+    if (!search || lay.compact || T != 1024 || n_vars <= HOT_VARS || cfg.entailed_prop_removal || std::getenv("TB_NO_HOT_TIER") != nullptr) return false;
     return fixed + (size_t)HOT_VARS * 8 + dirty_b <= lds;
   };
   if (cfg.only_global_memory) {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
     if (hot_tier()) { p.hot = true; p.blocks_per_cu = 1; p.shared_bytes = (int)(fixed + (size_t)HOT_VARS * 8 + dirty_b); }
-  } else if (!event && !lay.compact && lds_footprint(fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
+  } else if (!event && !lay.compact && lds_footprint(caps, fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
     // (records in LDS: the plain sweeps on small networks only.  The event kernels and the compact layouts have no such instantiation:
     //  their records come out of L2 fast enough, see below, and a third memory kind for them is a quarter of the library's compile time.)
     p.mem_kind = TB_MEM_TCN_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b + props_b);
   // (event mode, measured on accap_a3: the records in LDS at the price of 3 workgroups per CU instead of 7 -- 1.39e7 against 4.50e7 nodes/s.
   //  The records come out of L2 fast enough; what a CU needs is subproblems in flight.)
-  } else if (lds_footprint(fixed + store_b) * (size_t)bpc_max <= lds) {
+  } else if (lds_footprint(caps, fixed + store_b) * (size_t)bpc_max <= lds) {
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + store_b);
-  } else if (fixed + store_b <= lds && !(event && (int)(lds / lds_footprint(fixed + store_b)) < 4 && !(cfg.reserved[0] & 0x40000))) {
+  } else if (fixed + store_b <= lds && !(event && (int)(lds / lds_footprint(caps, fixed + store_b)) < 4 && !(cfg.reserved[0] & 0x40000))) {
     // (event mode: a store that leaves fewer than 4 workgroups per CU goes to global memory instead: what a CU needs is
     //  subproblems in flight -- trains15, compact slab of 50 KB: 1.77e7 nodes/s with 3 workgroups per CU in LDS, 2.04e7 with 7
     //  working on slabs in global memory (L2 / Infinity Cache resident); wordpress7_500 r02: 1.2-1.5x.  choose_layout first tries
     //  the COMPACT layout, which usually brings the store back into LDS)
-    p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / lds_footprint(fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
+    p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / lds_footprint(caps, fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
   } else {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
     if (hot_tier()) { p.hot = true; p.blocks_per_cu = 1; p.shared_bytes = (int)(fixed + (size_t)HOT_VARS * 8 + dirty_b); }
@@ -667,7 +668,10 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
         int32_t b = a + 1;
         while (b < end && props[b].y == props[a].y) ++b;
         size_t others = 0;
-        for (const Reader& r : adj.lists[(size_t)props[a].y]) others += (r.slice != base / 64 && !chains.in_chain(props[a].y, r.slice)) ? 1 : 0;
+        // (the chain's own slices are left out only when THIS slice wakes them by value range -- slice_info 0x400, chains.slice_ok: a y may have records in a
+        //  non-dense channelling slice next to its eligible chain, and that slice's run wakes nobody by arithmetic)
+        const bool by_range = chains.slice_ok[(size_t)(base / 64)] != 0;
+        for (const Reader& r : adj.lists[(size_t)props[a].y]) others += (r.slice != base / 64 && !(by_range && chains.in_chain(props[a].y, r.slice))) ? 1 : 0;
         if (others > 2 && others <= 2 * (size_t)(b - a))
           for (int32_t i = a; i < b; ++i) dealt[(size_t)i] = i - a;
         a = b;
@@ -684,7 +688,7 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
         unsigned o[2] = {0xffffu, 0xffffu};
         int in[2] = {0, 0}, n = 0, idx = 0;
         for (const Reader& r : adj.lists[(size_t)vs[k]]) {
-          if (r.slice == s || chains.in_chain(vs[k], r.slice)) continue;
+          if (r.slice == s || (chains.slice_ok[(size_t)s] && chains.in_chain(vs[k], r.slice))) continue;
           if (idx / 2 == dealt[(size_t)i]) { o[n] = (unsigned)r.slice; in[n] = r.interest; ++n; }
           ++idx;
         }
@@ -912,9 +916,9 @@ int prepare_kernel(bool solve, int mem, int tmax, bool event, int opt, int bytes
 // Layout + launch plan of a network.  The COMPACT layout is chosen for the event-driven fixpoint when it brings a
 // store that would otherwise sit in global memory into LDS (tb_config.reserved[0]: 0x80000 never, 0x100000 always).
 int choose_layout(const tb_config& cfg, const DeviceCaps& caps, int32_t n_vars, int32_t n_stores, const tb_itv* stores, int32_t n_props,
-                  Layout* lay, LaunchPlan* plan, int32_t pinned = -1) {
+                  Layout* lay, LaunchPlan* plan, int32_t pinned = -1, bool search = true) {
   *lay = make_layout(n_vars, n_stores, stores, false);
-  int rc = plan_launch(cfg, caps, *lay, n_props, plan);
+  int rc = plan_launch(cfg, caps, *lay, n_props, plan, search);  // (search = false, tb_propagate: no hot tier -- the batch kernel works on plain slabs and would only lose workgroups per CU to it)
   // The sweeps take a compact layout only when it is forced (and never together with entailed-slice removal): measured r03, a sweep
   // evaluates every propagator whatever the layout, and the decode costs more than the extra workgroups bring -- wordpress7_500 WAC1
   // 2.10e6 nodes/s plain (256 x 1024) against 1.81e6 compact (1280 x 256); trains15 6.77e6 against 7.44e6.
@@ -1270,7 +1274,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   if ((rc = query_caps(cfg.device, &caps)) != TB_OK) return rc;
   Layout lay;
   LaunchPlan plan;
-  if ((rc = choose_layout(cfg, caps, n_vars, n_stores, stores_inout, n_props, &lay, &plan)) != TB_OK) return rc;
+  if ((rc = choose_layout(cfg, caps, n_vars, n_stores, stores_inout, n_props, &lay, &plan, -1, false)) != TB_OK) return rc;
   const int32_t n_rec = plan_records(cfg, caps, n_vars, n_stores, stores_inout, n_props, props, &lay, &plan);  // records the kernels see
   const size_t VX = (size_t)plan.vext, slab_bytes = VX * 8;
 
@@ -1386,7 +1390,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     int occ = 0;
     if ((rc = prepare_kernel(true, s->plan.mem_kind, s->plan.tmax, s->plan.kernel_event != 0, s->plan.kernel_opt, s->plan.shared_bytes, s->plan.threads, &occ)) != TB_OK) return rc;
     // (the occupancy query does not round the LDS request up to its allocation granule: 13 workgroups of 12 336 B "fit" a CU that holds 12)
-    if (s->plan.shared_bytes > 0) occ = std::min<int>(occ > 0 ? occ : 1 << 20, (int)((size_t)s->caps.lds_per_cu / lds_footprint((size_t)s->plan.shared_bytes)));
+    if (s->plan.shared_bytes > 0) occ = std::min<int>(occ > 0 ? occ : 1 << 20, (int)((size_t)s->caps.lds_per_cu / lds_footprint(s->caps, (size_t)s->plan.shared_bytes)));
     if (occ > 0 && (long long)occ * s->caps.cus < (long long)s->plan.num_blocks) {
       tb_config capped = s->cfg;
       capped.or_nodes = (uint64_t)occ * (uint64_t)s->caps.cus;
@@ -1490,6 +1494,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   P.poll_ticks = (int)std::min<long long>(0x3fffffff, (long long)(s->cfg.poll_period_us > 0 ? s->cfg.poll_period_us : 100) * (long long)s->caps.wall_khz / 1000);
   if (P.poll_ticks < 1) P.poll_ticks = 1;
   P.steal = (s->cfg.reserved[0] & 0x1000000) ? 0 : 1;
+  P.leaf_assign = s->cfg.leaf_requires_assignment ? 1 : 0;
   // the cell other GPUs reach over xGMI: fine-grained device memory (coherent at system scope while kernels run)
   {
     void* c = nullptr;
@@ -1906,6 +1911,9 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
 #endif
     for (int t = 0; t < TB_NUM_TIMERS; ++t)
       if (t != TB_T_FIRST_BLOCK_IDLE && t != TB_T_LATEST_BEST_OBJ_FOUND) st.timers_ns[t] += (int64_t)((double)x.timers[t] * ns_per_tick);
+#ifdef TB_TUNING
+    for (int t = 0; t < TB_NUM_PROF; ++t) st.prof_ns[t] += (int64_t)((double)x.prof[t] * ns_per_tick);
+#endif
     st.cumulative_time_block_ns += (int64_t)((double)x.timers[TB_T_FIRST_BLOCK_IDLE] * ns_per_tick);
     if (first_idle < 0 || x.timers[TB_T_FIRST_BLOCK_IDLE] < first_idle) first_idle = x.timers[TB_T_FIRST_BLOCK_IDLE];
     if (x.solutions > 0) {

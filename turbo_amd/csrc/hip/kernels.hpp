@@ -90,7 +90,7 @@ struct alignas(16) BlockShared {
   int leaf, stop, depth, remaining;
   int cur_strategy, next_unassigned, snap_strategy, snap_next_unassigned;
   int best_bound;  // best objective found by this workgroup (BlockData::best_bound, barebones:116)
-  int found, sol, skip, pad_abort;
+  int found, sol, skip, open_vars;  // open_vars: the all-assigned scan of an all-entailed node found a variable that is not (leaf rule of the `gpu` path)
   int new_depth, ev_all, chg_count[2], ev_busy;  // event mode: "run every slice" request, change-list fill, waves running a slice
   unsigned long long sub_idx;  // global index of the current subproblem
   unsigned long long sub_j;    // its index in the local numbering of rank sub_owner (eps_global_index)
@@ -147,6 +147,12 @@ __device__ __forceinline__ int reps_of(const DevProblem& P, int phase) { return 
 // Regions of the search kernel for the instruction budget (scripts/region_budget.py): a -DTB_REGION_MARKERS build is the production kernel with an
 // assembler comment at each point -- static instruction counts between two markers, in layout order -- and the tuning build counts how often a
 // wave passes each point (BlockStats::reg; wave-uniform points only).
+// In-kernel phase timers of the tuning build (knob 0x10000): the engine's own phases, apart from the reference's timers (BlockStats::prof, tb_stats.prof_ns)
+#ifdef TB_TUNING
+#define TB_PROF_ADD(bs, which, dt) ((bs).prof[which] += (dt))
+#else
+#define TB_PROF_ADD(bs, which, dt) ((void)(dt))
+#endif
 #if defined(TB_REGION_MARKERS)
 #define TB_REGION(id) asm volatile("; TBREGION " #id)
 #elif defined(TB_TUNING)
@@ -1132,7 +1138,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   if (tid == 0) { st(&sh.unent[0], 0); st(&sh.flag[0], 0); st(&sh.flag[1], 0); }
   __syncthreads();
   if (tid == 0) { st(&sh.ev_all, 0); st(&sh.chg_count[0], 0); }
-  if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_WAIT_CPU] += t - tp0; tp0 = t; }  // profiling: seeding
+  if (tid == 0 && prof) { const long long t = wall_clock64(); TB_PROF_ADD(sh.bs, TB_PROF_SEEDING, t - tp0); tp0 = t; }  // profiling: seeding
   // ---- rounds
   // bits of a bitmap word owned by this wave: slices s with s % nw == wave (nw divides 32)
   unsigned own = 0;
@@ -1591,7 +1597,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   TB_REGION(21);
   if (lane == 0) tc.writes += wave_writes;
   if (lane == 0 && wave_iters_total != 0) { add_deductions(sh, 64ull * wave_iters_total); add_active(sh, (unsigned long long)wave_active_total); }
-  if (tid == 0 && prof) { const long long t = wall_clock64(); sh.bs.timers[TB_T_TRANSFER_CPU2GPU] += t - tp0; tp0 = t; }  // profiling: rounds
+  if (tid == 0 && prof) { const long long t = wall_clock64(); TB_PROF_ADD(sh.bs, TB_PROF_ROUNDS, t - tp0); tp0 = t; }  // profiling: rounds
   // leave both bitmaps empty for the next node (they are not after a failure)
   for (int rep = reps_of(P, 7); rep > 0; --rep)
   for (int i = tid; i < 2 * W; i += T) __hip_atomic_store(&es.dirty[i], 0u, TB_RLX, TB_WG);
@@ -2170,6 +2176,18 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
     __syncthreads();
   }
 #endif
+  // The leaf rule of the reference's `gpu` and `cpu` paths (gpu_dive_and_solve.hpp:333-338, cpu_solving.hpp:33-40): "no propagator is active" makes a node a
+  // solution only if the store is extractable as well -- every variable assigned (hybrid_dive_and_solve.hpp:531); otherwise it is an inner node and the
+  // search keeps branching below it.  barebones accepts the box (barebones:988-993).  Only all-entailed nodes pay for the scan: one pass over the slab.
+  if (P.leaf_assign && !failed && all_entailed) {  // uniform
+    bool open = false;
+    for (int v = tid; v < P.n_vars; v += block_threads<TB>()) {  // (P.n_vars: the variables of the slab; constants kept out of it are assigned)
+      const Itv d = load_dom<C>(store, P.n_int, C == 4 ? (v | (C8_BASE_BIAS << 16)) : v);  // (COMPACT8: any base will do for "lb == ub")
+      open |= d.lb != d.ub;
+    }
+    if (wave_any(open) && (tid & 63) == 0) st(&sh.open_vars, 1);
+    __syncthreads();
+  }
   if (tid == 0) {
     TB_REGION(25);
     const long long t1 = wall_clock64();
@@ -2177,6 +2195,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
     sh.t_mark = t1;
     int leaf = failed ? 1 : 0, sol = 0;
     bool stream = false;
+    if (P.leaf_assign && ld(&sh.open_vars) != 0) { all_entailed = false; st(&sh.open_vars, 0); }
     if (!failed && all_entailed) {
       TB_REGION(62);
       leaf = 1;
@@ -2374,9 +2393,10 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_
     for (int i = 0; i < TB_DBG_WORDS; ++i) bs.dbg[i] = 0;
 #ifdef TB_TUNING
     for (int i = 0; i < 72; ++i) bs.reg[i] = 0;
+    for (int i = 0; i < TB_NUM_PROF; ++i) bs.prof[i] = 0;
 #endif
     bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
-    sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0;
+    sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0; sh.open_vars = 0;
     sh.n_dec_seg = 0;
     sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; sh.witness = -1;
     sh.t_start = sh.t_mark = wall_clock64();
@@ -2452,10 +2472,10 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_
           __syncthreads();
         }
         TB_REGION(50);
-        if (prof && tid == 0) { const long long t = wall_clock64(); bs.timers[TB_T_PREPROCESSING] += t - tp; tp = t; }  // profiling: snapshot push
+        if (prof && tid == 0) { const long long t = wall_clock64(); TB_PROF_ADD(bs, TB_PROF_SNAPSHOT_PUSH, t - tp); tp = t; }  // profiling: snapshot push
         split_node<EVENT, C, (MEM >= TB_MEM_STORE_SHARED), TB>(P, sh, dec, store);
         TB_REGION(51);
-        if (prof && tid == 0) bs.timers[TB_T_SELECT_FP_FUNCTIONS] += wall_clock64() - tp;  // profiling: variable selection
+        if (prof && tid == 0) TB_PROF_ADD(bs, TB_PROF_VARIABLE_SELECTION, wall_clock64() - tp);  // profiling: variable selection
         if (sh.stop) break;
         if (tid == 0) {
           TB_REGION(35);

@@ -34,7 +34,7 @@ void usage_and_exit(const std::string& program) {
       << "\t-i: print intermediate solutions (not supported by the GPU architectures, a warning is printed).\n"
       << "\t-f: free search (accepted, search annotations are still followed).\n"
       << "\t-s: print statistics.  -v: verbose (repeatable).\n"
-      << "\t-arch <gpu|barebones>: both run the MI355X dive-and-solve engine; cpu and hybrid are not provided by this build.\n"
+      << "\t-arch <gpu|barebones>: both run the MI355X dive-and-solve engine (gpu: a solution has every variable assigned and -i / -a / -n stream; barebones, the default: a node whose propagators are all entailed is a solution); cpu and hybrid are not provided by this build.\n"
       << "\t-fp <ac1|wac1|event|auto>: fixpoint strategy (default auto: event from 320 propagators on, wac1 below; event: wac1 that only re-evaluates the 64-propagator slices reading a narrowed variable -- same search tree, fastest; wac1, the reference's default: each wave reaches a local fixpoint over its 64 propagators in every sweep; ac1: plain sweeps).\n"
       << "\t-or / -p <n>: number of workgroups (default 0: automatic).\n"
       << "\t-sub <d>: 2^d subproblems (default -1: at least subfactor x workgroups).  -subfactor <f>: default 300.\n"

@@ -115,6 +115,9 @@ tb_config make_config(const Options& o, bool has_eps) {
   c.threads_per_block = o.threads_per_block; c.device = 0; c.rank = 0; c.world_size = 1;
   c.deterministic = o.deterministic;
   c.entailed_prop_removal = o.entailed_removal ? 1 : 0;
+  // the leaf rule follows the architecture, as in the reference: `-arch gpu` calls an all-entailed node a solution only when the store is extractable
+  // (every variable assigned, gpu_dive_and_solve.hpp:333-338), `-arch barebones` accepts the box (barebones_dive_and_solve.hpp:988-993)
+  c.leaf_requires_assignment = o.arch == Arch::GPU ? 1 : 0;
   return c;
 }
 
