@@ -44,6 +44,13 @@ $(LIBDIR)/libturbo_hip_tuning.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DTB_TUNING -shared -o $@ $(HIP_SRC)
 
+# the same engine with a range check in front of every index the kernels form from host-packed fields (kernels.hpp: TB_BOUNDS): a report
+# {site, index, limit, workgroup} instead of a memory fault.  scripts/bounds_soak.py runs the bench workloads and the fuzz families on it.
+bounds: $(LIBDIR)/libturbo_hip_bounds.so
+$(LIBDIR)/libturbo_hip_bounds.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DTB_BOUNDS -shared -o $@ $(HIP_SRC)
+
 # one library per phase of the event kernels, each the production kernels with exactly that phase executed twice (compile-time choice:
 # scripts/phase_budget.py measures the difference in SQ_INSTS_* to the production library)
 PHASES := 1 2 3 4 5 6 7 8 9 10 11 12 13 14
@@ -71,4 +78,4 @@ clean:
 	rm -rf $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all front hip cli oracle sanitize clean tuning phases
+.PHONY: all front hip cli oracle sanitize clean tuning phases bounds

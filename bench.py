@@ -80,8 +80,9 @@ def cpu_baseline(tcn, subproblems_power: int, seconds: float) -> dict:
         pyoracle.use_library(native)
     core = pinned_core()
     try:
-        _, _, st = pyoracle.solve(tcn, subproblems_power=subproblems_power, timeout_ms=int(seconds * 1000))
-        _, _, dfs = pyoracle.solve(tcn, subproblems_power=0, timeout_ms=int(seconds * 300))
+        # (cpu_solving.hpp:36 calls a node a solution only when the store is extractable: the cpu path's leaf rule, whatever rule the GPU rows ran)
+        _, _, st = pyoracle.solve(tcn, subproblems_power=subproblems_power, timeout_ms=int(seconds * 1000), leaf_requires_assignment=1)
+        _, _, dfs = pyoracle.solve(tcn, subproblems_power=0, timeout_ms=int(seconds * 300), leaf_requires_assignment=1)
     finally:
         if before is not None:
             try:
@@ -97,7 +98,7 @@ def cpu_baseline(tcn, subproblems_power: int, seconds: float) -> dict:
     return {"value": st["num_deductions"] / secs, "unit": "propagations/s", "cores": 1, "kind": "port",
             "nodes_per_sec": st["nodes"] / secs,
             "sample": f"first {secs:.1f} s of the sequential walk over the same 2^{subproblems_power} EPS subproblems the GPU step explores "
-                      f"(dive + solve nodes, AC1 Gauss-Seidel): {st['nodes']} nodes, {st['num_deductions']} propagations, "
+                      f"(dive + solve nodes, AC1 Gauss-Seidel, leaf rule of cpu_solving.hpp:36): {st['nodes']} nodes, {st['num_deductions']} propagations, "
                       f"{st['eps_solved_subproblems'] + st['eps_skipped_subproblems']} subproblems done",
             "build": "gcc -O3 -march=native (built on this host)" if native else "gcc -O3 (prebuilt, portable)",
             "pinned_core": core, "host_cpus": os.cpu_count(), "cpu_model": model,
@@ -193,6 +194,98 @@ def attach_counters(roof: dict, workload: str, fixpoint: str, launch_s: float) -
     roof["issue"]["note"] = "binding resource; rocprofv3 --pmc SQ_* passes of this command, not measured in this run"
 
 
+# --mode solve: (fixed bound of the proof run, target of the time-to-target run, 2^d) per workload, calibrated on one MI355X so that a run lasts seconds
+# (scripts/r05_solve_probe.py).  The proof run is a satisfaction search under the CONSTANT constraint objective <= B (tb_config.use_fixed_bound:
+# no incumbent is exchanged, the tree does not depend on timing): with B below the optimum every subproblem is refuted -- a fixed amount of work whatever the number of
+# GPUs, which is what a strong-scaling curve needs.  -1: the reference's 2^d rule.
+SOLVE_DEFAULTS = {
+    "wordpress7_500": (8000, 16000, -1),
+    "accap_a3": (None, None, 12),
+    "trains15": (100, 130, -1),
+    "synthetic": (None, None, -1),
+}
+
+
+def solve_mode(args, tcn, fzn, rank, world, local_rank, dist, tdev, capi, tdist, torch) -> int:
+    """Whole searches instead of node budgets: what `reduce_blocks` (barebones:1033-1067) and `first_block_idle_time` (barebones:887-894) are about.
+    Every rank runs this collectively; rank 0 prints one JSON line."""
+    d_bound, d_target, d_power = SOLVE_DEFAULTS[args.workload]
+    bound = args.fixed_bound if args.fixed_bound is not None else d_bound
+    target = args.target if args.target is not None else d_target
+    power = args.subproblems_power if args.subproblems_power >= 0 else d_power
+    base = dict(fixpoint=FP_CODE[args.fixpoint], or_nodes=args.or_nodes, threads_per_block=args.threads, timeout_ms=int(args.solve_timeout * 1000), device=local_rank,
+                rank=rank, world_size=world, debug=args.debug_bits, subproblems_power=power, leaf_requires_assignment=int(args.leaf_rule == "gpu"))
+
+    def run(cfg_extra: dict, stop_at: int | None):
+        sess = capi.Session(tcn, capi.make_config(**base, **cfg_extra))
+        tdist.agree_on_plan(sess, dist, tdev)
+        linked = world > 1 and args.exchange == "peer" and tdist.link_group(sess, dist, tdev)
+        plan = sess.plan()
+        sess.arm()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sess.start()
+        first_hit = None
+        if world > 1:
+            # collective loop over the gloo side group: agrees on the group's incumbent, relays it when the cells are not linked, ends every rank together
+            gbest, _ = tdist.exchange_until_done(sess, dist, period_s=0.0005, max_seconds=args.solve_timeout, target=stop_at)
+        else:
+            gbest = 2**31 - 1
+            while True:
+                best, done = sess.poll()
+                gbest = min(gbest, best)
+                if stop_at is not None and gbest <= stop_at and first_hit is None:
+                    first_hit = time.perf_counter() - t0
+                    sess.stop()
+                if done:
+                    break
+                time.sleep(0.0005)
+        has, best, st = sess.finish()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+            t = torch.tensor([wall], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        row = {"kernel_ms": st["kernel_ns"] * 1e-6, "nodes": st["nodes"], "eps_solved": st["eps_solved_subproblems"], "eps_skipped": st["eps_skipped_subproblems"],
+               "stolen_subproblems": st["eps_stolen_subproblems"], "wait_share": st["wait_time_ns"] / max(1, st["cumulative_time_block_ns"]),
+               "first_block_idle_ms": st["min_block_ns"] * 1e-6, "last_block_ms": st["max_block_ns"] * 1e-6, "blocks_done": st["num_blocks_done"],
+               "exhaustive": st["exhaustive"], "has_solution": int(has), "best_bound": st["best_bound"] if has else 2**31 - 1, "propagations": st["num_deductions"]}
+        per_rank = tdist.gather_rank_rows(row, dist if world > 1 else None, tdev)
+        sess.close()
+        tot = {k: sum(r[k] for r in per_rank) for k in ("nodes", "eps_solved", "eps_skipped", "stolen_subproblems", "propagations")}
+        rec = {"seconds": wall, "time_to_target_s": first_hit, "linked": bool(linked) if world > 1 else None, "subproblems_power": plan["subproblems_power"],
+               "workgroups_per_gpu": plan["num_blocks"], "threads": plan["threads_per_block"],
+               "exhaustive": int(all(r["exhaustive"] for r in per_rank)), "has_solution": int(any(r["has_solution"] for r in per_rank)),
+               "best_objective_bound": int(min(r["best_bound"] for r in per_rank)), **tot,
+               "every_subproblem_accounted_once": int(tot["eps_solved"] + tot["eps_skipped"]) == (1 << plan["subproblems_power"]),
+               "nodes_per_sec": tot["nodes"] / max(wall, 1e-9), "per_rank": per_rank}
+        return rec
+
+    out = {"mode": "solve", "n_gpus": world, "workload": fzn, "fixpoint": args.fixpoint, "leaf_rule": args.leaf_rule, "scaling": "strong", "data": "reference instance file (no randomness)"}
+    if bound is not None:
+        rec = run(dict(use_fixed_bound=1, fixed_bound=int(bound)), None)
+        rec["fixed_bound"] = int(bound)
+        rec["what"] = ("canonical pass under the constant constraint objective <= B: no incumbent is exchanged, the tree is the same at every N; "
+                       "exhaustive and no solution = B is proved infeasible (every subproblem solved or skipped exactly once)")
+        out["proof"] = rec
+    if target is not None or bound is None:
+        rec = run(dict(), target)
+        rec["target"] = target
+        rec["what"] = ("branch and bound until the group's incumbent is <= target (None: until optimality is proved); the incumbent travels between the GPUs "
+                       "(peer cells over xGMI when linked, else the gloo relay), so the tree depends on when it arrives")
+        out["to_target"] = rec
+    head = out.get("proof") or out["to_target"]
+    out.update({"metric": "seconds of a whole sharded search (proof under a fixed bound; time to a target objective) on " + fzn, "value": head["seconds"], "unit": "s",
+                "higher_is_better": False, "vs_baseline": None, "dtype": "int32"})
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    return 0
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` on its own: run the N ranks as FRESH child processes (one per GPU, torch.distributed.run on
     127.0.0.1) and relay what they print.  This process never imports torch and never touches a GPU; it exits with the
@@ -235,6 +328,16 @@ def main() -> int:
     ap.add_argument("--exchange", default="peer", choices=["peer", "host"],
                     help="peer: the kernels exchange bound and work through their cells over xGMI; host: all_reduce(MIN) relay, static shares")
     ap.add_argument("--no-simplify", action="store_true", help="skip the network simplifier (the reference's -disable_simplify)")
+    ap.add_argument("--leaf-rule", default="barebones", choices=["barebones", "gpu"],
+                    help="barebones (the reference's default -arch of a GPU build): all propagators entailed = solution (barebones:988-993); gpu: ... and every variable "
+                         "assigned (gpu_dive_and_solve.hpp:333-338, cpu_solving.hpp:36)")
+    ap.add_argument("--mode", default="throughput", choices=["throughput", "solve"],
+                    help="throughput (default, the contract of this file): steps with a fixed node budget.  solve: wall time of whole searches that exercise the SHARDED "
+                         "search -- queue, subtree skips, work stealing, incumbent exchange: (i) proof of `objective <= --fixed-bound` (canonical pass: fixed total work, "
+                         "strong scaling) and (ii) branch and bound until the group's incumbent reaches --target")
+    ap.add_argument("--fixed-bound", type=int, default=None, help="--mode solve: the bound B of the proof run (default: per workload, SOLVE_DEFAULTS)")
+    ap.add_argument("--target", type=int, default=None, help="--mode solve: the target objective of the time-to-target run (default: per workload)")
+    ap.add_argument("--solve-timeout", type=float, default=120.0, help="--mode solve: give up after this many seconds per run")
     ap.add_argument("--debug-bits", type=lambda v: int(v, 0), default=0, help="tuning knobs of tb_config.reserved[0] (experiments only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -279,6 +382,7 @@ def main() -> int:
         import torch.distributed as dist
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)  # "nccl" is RCCL over xGMI
         dist.barrier()  # communicator set-up happens here, outside every timed region
+        tdist.relay_group(dist)  # gloo side group (collective): what the ranks exchange while a kernel runs never queues an RCCL kernel behind it
 
     def load_workload(name: str):
         file_name = WORKLOADS[name][0]
@@ -301,7 +405,7 @@ def main() -> int:
         per_rank_budget = budget if (world == 1 or linked) else max(1, budget // world)  # unlinked ranks count on their own
         cfg = capi.make_config(fixpoint=FP_CODE[fixpoint], stop_after_n_nodes_total=per_rank_budget, stop_after_n_nodes=args.cutnodes,
                                or_nodes=args.or_nodes, threads_per_block=args.threads, timeout_ms=600000, device=local_rank, rank=rank, world_size=world, debug=args.debug_bits,
-                               subproblems_power=args.subproblems_power)
+                               subproblems_power=args.subproblems_power, leaf_requires_assignment=int(args.leaf_rule == "gpu"))
         sess = capi.Session(tcn, cfg)  # inputs uploaded to HBM here, outside the timed region
         tdist.agree_on_plan(sess, dist, tdev)
         if linked:
@@ -365,6 +469,13 @@ def main() -> int:
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             g["start_skew_ms_max"] = float((hi - lo).max().item()) * 1000.0
         return elapsed, tot, g, last
+
+    if args.mode == "solve":
+        rc = solve_mode(args, tcn, fzn, rank, world, local_rank, dist, tdev, capi, tdist, torch)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return rc
 
     scale = world if args.scaling == "weak" else 1
     budget = (args.nodes_total or (budget_event if args.fixpoint == "event" else budget_sweep)) * scale
@@ -455,7 +566,8 @@ def main() -> int:
                                    f"{last['num_blocks']} workgroups x {last['threads_per_block']} threads per GPU, "
                                    f"{capi.MEM_KINDS[last['mem_kind']]} ({last['shared_bytes']} B LDS per workgroup), "
                                    f"2^{plan['subproblems_power']} subproblems, one step = {budget} nodes of the search by all GPUs together"
-                                   f"{'' if not args.cutnodes else f', at most {args.cutnodes} per workgroup'}, fixpoint={args.fixpoint}",
+                                   f"{'' if not args.cutnodes else f', at most {args.cutnodes} per workgroup'}, fixpoint={args.fixpoint}, leaf rule of -arch {args.leaf_rule}",
+                       "leaf_rule": args.leaf_rule,
                        "parallelism": f"eps_block_cyclic{world}" + ("" if world == 1 else ("+xgmi_steal" if linked else "+host_relay"))},
             "roofline": roof,
         }

@@ -204,11 +204,24 @@ def finite_class_network(rng, scale=1):
         b = new_var(0, 1, int(t)); bools.append(b)
         return b
     props = []
-    kinds = rng.choice(["add", "add0", "addb", "minmax", "clause", "leq", "eq", "neq", "gt", "leq_r", "eq_r", "leq_rc", "impl"], size=int(rng.integers(2, 6)), replace=False)
+    kinds = rng.choice(["add", "add0", "addb", "minmax", "clause", "leq", "eq", "neq", "gt", "leq_r", "eq_r", "leq_rc", "impl", "mul"], size=int(rng.integers(2, 6)), replace=False)
     for kind in kinds:
         for _ in range(int(rng.integers(66, 150))):
             if kind == "add":
                 y, z = anyv(), anyv(); props.append((0, defined(val[y] + val[z]), y, z))
+            elif kind == "mul":
+                # x = y * z over non-negative operands (r05: the lean product run, kernels.hpp K_MUL_NN): a price times a 0/1 occupancy as in wordpress7_500, two small
+                # factors, a constant factor; now and then a factor that may be negative, which sends the whole slice back to the generic rule
+                r = rng.random()
+                vy = int(rng.integers(0, 30 * min(scale, 8)))
+                y = new_var(max(0, vy - int(rng.integers(0, 9))) if rng.random() < 0.93 else vy - 40, vy + int(rng.integers(0, 9)), vy); ints.append(y)
+                if r < 0.4: z = bv()
+                elif r < 0.8:
+                    vz = int(rng.integers(0, 7)); z = new_var(max(0, vz - int(rng.integers(0, 3))), vz + int(rng.integers(0, 3)), vz); ints.append(z)
+                else: z = const(int(rng.integers(0, 5)))
+                v = val[y] * val[z]
+                x = new_var(max(0, v - int(rng.integers(0, 12))), v + int(rng.integers(0, 12)), v); ints.append(x)
+                props.append((1, x, y, z))
             elif kind == "add0":
                 y = iv(); props.append((0, 0, y, defined(-val[y])))            # 0 = y + z
             elif kind == "addb":

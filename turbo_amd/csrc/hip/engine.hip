@@ -41,6 +41,8 @@ int fail(int code, const std::string& msg) {
     }                                                                                                       \
   } while (0)
 
+thread_local int g_adj_sizes[2] = {1 << 30, 1 << 30};  // entries of var_adj / 2 and of adj_rest of the tables uploaded last by this thread (bounds build)
+
 struct DeviceCaps {
   int cus = 0, lds_per_cu = 0, wall_khz = 100000;
   size_t free_mem = 0, total_mem = 0;
@@ -815,8 +817,18 @@ std::vector<int2> slice_infos(const std::vector<int4>& packed, const std::vector
         if (d.lb < -(1 << 29) || d.ub > (1 << 29)) finite = false;
       }
     }
+    // 0x800 (r05): every record is `x = y * z` over non-negative finite operands whose products stay below 2^30 -- the lean product run (kernels.hpp: K_MUL_NN)
+    bool mul_nn = plain_lean && root != nullptr && n_real > 0 && classes == (1u << K_HEAVY) && !std::getenv("TB_NO_LEAN_MUL");
+    for (int l = 0; l < n_real && mul_nn; ++l) {
+      const int4 r = packed[(size_t)s * 64 + (size_t)l];
+      tb_itv d[3];
+      int k = 0;
+      for (int v : {r.y, r.z, r.w}) d[k++] = field_is_value(v) ? tb_itv{field_value(v), field_value(v)} : root[v];
+      mul_nn = ((r.x >> 12) & 7) == TB_MUL && d[0].lb >= 0 && d[1].lb >= 0 && d[2].lb >= 0 && d[0].ub <= (1 << 30) && d[1].ub <= (1 << 30) && d[2].ub <= (1 << 30) &&
+               (long long)d[1].ub * (long long)d[2].ub <= (1ll << 30);
+    }
     const bool chain_ok = (size_t)s < chains.slice_ok.size() && chains.slice_ok[(size_t)s];
-    info[(size_t)s] = make_int2(w0, n_real | (is_lean ? 0x100 : 0) | (finite ? 0x200 : 0) | (chain_ok ? 0x400 : 0));
+    info[(size_t)s] = make_int2(w0, n_real | (is_lean ? 0x100 : 0) | (finite ? 0x200 : 0) | (chain_ok ? 0x400 : 0) | (mul_nn ? 0x800 : 0));
   }
   return info;
 }
@@ -1073,6 +1085,28 @@ int device_now(hipStream_t stream, long long* d_now, long long* now_out) {
   return TB_OK;
 }
 
+// Software bounds build (kernels.hpp: TB_BOUNDS): the limits of one launch go to the device before it, a report comes back after it.
+#ifdef TB_BOUNDS
+int bounds_arm(const DevProblem& P, const LaunchPlan& plan, int strats, int strat_total, const int adj_sizes[2], Ctrl* ctrl) {
+  BoundsLimits L{};
+  L.store_words = plan.vext * 2; L.slab_vars = P.n_vars; L.n_slices = std::max(1, plan.n_slices); L.records = std::max(1, plan.n_slices) * 64;
+  L.adj_vars = std::max(1, adj_sizes[0]); L.adj_rest = std::max(1, adj_sizes[1]);
+  L.strats = std::max(1, strats); L.strat_total = strat_total; L.snapshot_levels = std::max(1, plan.snapshot_levels);
+  L.mark_words = std::max(1, plan.vext * 2 - plan.unent_off / 4); L.chg_cap = std::max(1, plan.chg_cap); L.ctrl = ctrl;
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_bl), &L, sizeof(L)));
+  return TB_OK;
+}
+int bounds_collect(const char* what) {
+  BoundsReport r{};
+  HIP_TRY(hipMemcpyFromSymbol(&r, HIP_SYMBOL(g_br), sizeof(r)));
+  if (r.hits == 0) return TB_OK;
+  const BoundsReport zero{};
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_br), &zero, sizeof(zero)));
+  return fail(TB_ERR_HIP, std::string("bounds build: ") + what + ": " + std::to_string(r.hits) + " out-of-range indexes; first: site " + std::to_string(r.site) + ", index " +
+                              std::to_string(r.index) + ", limit " + std::to_string(r.limit) + ", workgroup " + std::to_string(r.workgroup) + ", thread " + std::to_string(r.thread));
+}
+#endif
+
 }  // namespace
 
 // ---- session -------------------------------------------------------------------------------------
@@ -1104,6 +1138,7 @@ struct tb_session {
   unsigned long long local_count = 0;  // size of this rank's share of the index space
   int host_best = TB_PINF;
   long long* d_now = nullptr;
+  int adj_sizes[2] = {1 << 30, 1 << 30}, strat_total = 0;  // bounds build: limits of this session's tables
   std::chrono::steady_clock::time_point t_start;
   ~tb_session() {
     if (ev_start) (void)hipEventDestroy(ev_start);
@@ -1205,6 +1240,7 @@ int upload_event_tables(DevBuffers& bufs, DevProblem& P, const tb_config& cfg, c
   P.slice_info = d_info;
   std::vector<int4> heads; std::vector<int> rest;
   pack_var_adj(adj, &heads, &rest);
+  g_adj_sizes[0] = (int)(heads.size() / 2); g_adj_sizes[1] = (int)rest.size();  // (bounds build: limits of var_adj / adj_rest for the launch that follows)
   int4* d_heads = nullptr; int* d_rest = nullptr;
   if ((rc = bufs.alloc(&d_heads, heads.size())) != TB_OK) return rc;
   if ((rc = bufs.alloc(&d_rest, rest.size())) != TB_OK) return rc;
@@ -1333,6 +1369,9 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
     P.deadline_ticks = now + (long long)cfg.timeout_ms * (long long)caps.wall_khz;
   }
   const int grid = std::min(n_stores, plan.num_blocks);
+#ifdef TB_BOUNDS
+  { const int none[2] = {1 << 30, 1 << 30}; if ((rc = bounds_arm(P, plan, 1, 0, event ? g_adj_sizes : none, nullptr)) != TB_OK) return rc; }
+#endif
   HIP_TRY(hipEventRecord(e0, stream));
   DISPATCH_KERNEL_WIDE(propagate_kernel, plan.mem_kind, plan.tmax, event, compact, <<<dim3(grid), dim3(plan.threads), plan.shared_bytes, stream>>>(P, d_stores, d_out, n_stores));
   HIP_TRY(hipGetLastError());
@@ -1342,6 +1381,9 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
   if (kernel_ns_out) *kernel_ns_out = (int64_t)((double)ms * 1e6);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(stream);
+#ifdef TB_BOUNDS
+  if ((rc = bounds_collect("tb_propagate")) != TB_OK) return rc;
+#endif
   std::vector<PropagateOut> outs((size_t)n_stores);
   HIP_TRY(hipMemcpy(outs.data(), d_out, (size_t)n_stores * sizeof(PropagateOut), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(slabs.data(), d_stores, slabs.size(), hipMemcpyDeviceToHost));
@@ -1424,6 +1466,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   total_svars = (int32_t)i_vars.size();
   const int32_t i_obj = obj_var >= 0 ? lay.ref(lay.perm[(size_t)obj_var]) : -1;
 
+  s->strat_total = total_svars;
   int4* d_props = nullptr; int2* d_root = nullptr; int *d_vo = nullptr, *d_vl = nullptr, *d_off = nullptr, *d_sv = nullptr;
   if ((rc = s->bufs.alloc(&d_props, (size_t)plan.n_slices * 64)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_root, VX)) != TB_OK) return rc;
@@ -1442,6 +1485,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     packed.resize((size_t)plan.n_slices * 64, make_int4(K_LEQ_T, 0, 0, 0));
     if (n_rec) { const std::vector<int4> dev = device_records(packed, lay); HIP_TRY(hipMemcpy(d_props, dev.data(), dev.size() * sizeof(int4), hipMemcpyHostToDevice)); }
     if ((rc = upload_event_tables(s->bufs, s->P, s->cfg, s->plan, s->lay, n_rec, net.props, adj, packed, value, net.store.data())) != TB_OK) return rc;
+    s->adj_sizes[0] = g_adj_sizes[0]; s->adj_sizes[1] = g_adj_sizes[1];
   }
   s->P.n_slices = s->plan.n_slices; s->P.dirty_words = s->plan.dirty_words; s->P.vext = s->plan.vext; s->P.chg_cap = s->plan.chg_cap;
   s->P.n_int = s->plan.n_int; s->P.unent_off = s->plan.unent_off;
@@ -1559,9 +1603,15 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
       if ((rc = device_now(s->stream, s->d_now, &now)) != TB_OK) return rc;
       Q.deadline_ticks = now + (long long)s->cfg.timeout_ms * (long long)s->caps.wall_khz;
     }
+#ifdef TB_BOUNDS
+    if ((rc = bounds_arm(Q, plan, std::max(1, n_strats), s->strat_total, s->adj_sizes, nullptr)) != TB_OK) return rc;
+#endif
     DISPATCH_KERNEL_WIDE(propagate_kernel, plan.mem_kind, plan.tmax, event, opt, <<<dim3(1), dim3(plan.threads), plan.shared_bytes, s->stream>>>(Q, d_root, d_out, 1));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
+#ifdef TB_BOUNDS
+    if ((rc = bounds_collect("root fixpoint of tb_session_create")) != TB_OK) return rc;
+#endif
     PropagateOut o;
     HIP_TRY(hipMemcpy(&o, d_out, sizeof(o), hipMemcpyDeviceToHost));
     if (o.failed == 0) P.root_fixpoint = 1;
@@ -1700,8 +1750,11 @@ int tb_session_start(tb_session* s) {
   s->t_start = std::chrono::steady_clock::now();
   if (s->d_P == nullptr) { int rc2 = s->bufs.alloc(&s->d_P, 1); if (rc2 != TB_OK) return rc2; }
   HIP_TRY(hipMemcpyAsync(s->d_P, &s->P, sizeof(DevProblem), hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipEventRecord(s->ev_start, s->stream));
   const LaunchPlan& plan = s->plan;
+#ifdef TB_BOUNDS
+  if ((rc = bounds_arm(s->P, plan, std::max(1, s->P.n_strats), s->strat_total, s->adj_sizes, s->P.ctrl)) != TB_OK) return rc;
+#endif
+  HIP_TRY(hipEventRecord(s->ev_start, s->stream));
   DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, plan.kernel_event != 0, plan.kernel_opt, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->d_P, s->mbox_dev));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev_stop, s->stream));
@@ -1830,6 +1883,9 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
   HIP_TRY(hipSetDevice(s->cfg.device));
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->finished = true;
+#ifdef TB_BOUNDS
+  { const int brc = bounds_collect("search kernel"); if (brc != TB_OK) return brc; }
+#endif
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
   const size_t B = (size_t)s->plan.num_blocks, V = (size_t)s->n_vars;
@@ -1858,7 +1914,7 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
       for (int i = 0; i < s->plan.n_slices; ++i) order[(size_t)i] = i;
       std::sort(order.begin(), order.end(), [&](int a, int b2) { return c[(size_t)a * 2] > c[(size_t)b2 * 2]; });
       const double n = (double)std::max<unsigned long long>(1, nodes);
-      for (int i = 0; i < std::min(40, s->plan.n_slices); ++i) {
+      for (int i = 0; i < std::min(std::getenv("TB_CENSUS_ROWS") ? std::atoi(std::getenv("TB_CENSUS_ROWS")) : 40, s->plan.n_slices); ++i) {
         const int q = order[(size_t)i];
         std::fprintf(stderr, "%% slice-census %3d: slice %4d runs/node %.3f useless %.3f\n", i, q, c[(size_t)q * 2] / n, c[(size_t)q * 2 + 1] / n);
       }

@@ -213,6 +213,52 @@ __device__ __forceinline__ bool deadline_passed(const DevProblem& P);
 __device__ __forceinline__ int ld(const int* p) { return __hip_atomic_load(p, TB_RLX, TB_WG); }
 __device__ __forceinline__ void st(int* p, int v) { __hip_atomic_store(p, v, TB_RLX, TB_WG); }
 
+// ---- software bounds build (-DTB_BOUNDS, `make bounds`; r05) --------------------------------------------------------------------------------
+// GPU AddressSanitizer is not available on the pool, and r04 saw ONE unexplained memory fault in ~40 traced runs.  The kernels form LDS and global addresses
+// from host-packed fields (16-bit word indexes, COMPACT8 bases, 16-bit slice ids, 28-bit queue words): in this build every such index goes through TB_IDX,
+// which compares it with the limit the host computed for THIS launch (BoundsLimits, hipMemcpyToSymbol before the launch), records the first offender
+// {site, index, limit, workgroup, thread}, asks the grid to stop and substitutes index 0 -- a report instead of a fault (or of a silent LDS over-read:
+// out-of-range LDS accesses do not fault at all).  tb_session_finish / tb_propagate turn a report into TB_ERR_HIP.  Production builds compile TB_IDX to
+// the index itself.  Sites: 1 interval of a plain / COMPACT / HOT slab, 2 word of a COMPACT16 slab, 3 word of a COMPACT8 integer, 4-6 load_dom of COMPACT8 /
+// COMPACT16 / COMPACT, 7-8 narrowing of an integer, 9 Boolean word, 10 slice id into a dirty bitmap, 11 variable into var_adj, 12 adj_rest entry, 13 slice
+// of a run (slice_info / records / successor records), 14 word indexes of a lean implication record, 15 decision-stack entry, 16 strategy tables,
+// 17 snapshot level, 18 entailment mark of a slice, 19 propagator index (witness, sweeps), 20 change-list entry, 21 all-assigned scan, 22 Boolean column of a run.
+#ifdef TB_BOUNDS
+struct BoundsLimits {
+  int store_words;      // 32-bit words of a workgroup's slab (vext * 2): domains + entailment marks
+  int slab_vars;        // variables of the slab (DevProblem::n_vars)
+  int n_slices, records;  // slices; records = n_slices * 64 (the arrays are padded to whole slices)
+  int adj_vars;         // entries of var_adj / 2
+  int adj_rest;         // entries of adj_rest
+  int strats, strat_total;
+  int snapshot_levels;
+  int mark_words;       // 32-bit words of entailment marks behind the domains (event: dirty_words; sweeps: bytes / 4 rounded up)
+  int chg_cap;
+  Ctrl* ctrl;           // the search's grid words (nullptr: batch propagation)
+};
+struct BoundsReport { unsigned hits; int site, index, limit, workgroup, thread; };
+__device__ BoundsLimits g_bl;
+__device__ BoundsReport g_br;
+__device__ __noinline__ void bounds_hit(int site, int idx, int limit) {
+  if (atomicAdd(&g_br.hits, 1u) == 0u) { g_br.site = site; g_br.index = idx; g_br.limit = limit; g_br.workgroup = (int)blockIdx.x; g_br.thread = (int)threadIdx.x; }
+  if (g_bl.ctrl != nullptr) (void)__hip_atomic_fetch_or(&g_bl.ctrl->stop, STOP_HOST, TB_RLX, TB_AGENT);
+}
+__device__ __forceinline__ int bounds_idx(int site, int idx, int limit) {
+  if ((unsigned)idx >= (unsigned)limit) { bounds_hit(site, idx, limit); return 0; }
+  return idx;
+}
+#define TB_IDX(site, idx, lim) bounds_idx(site, (int)(idx), g_bl.lim)
+#define TB_IDX_N(site, idx, n) bounds_idx(site, (int)(idx), (int)(n))
+__device__ __forceinline__ int g_bl_total() { return g_bl.strat_total > 0 ? g_bl.strat_total : 1; }
+// an index of 8-byte intervals (int2) into the slab: both of its words must lie inside
+#define TB_CHECK_ITV(site, v) do { (v) = bounds_idx(site, 2 * (int)(v) + 1, g_bl.store_words) >> 1; } while (0)
+#else
+#define TB_CHECK_ITV(site, v) do { } while (0)
+#define TB_IDX(site, idx, lim) (idx)
+#define TB_IDX_N(site, idx, n) (idx)
+__device__ __forceinline__ constexpr int g_bl_total() { return 1; }
+#endif
+
 // Store slab of a workgroup: [ni x int2 {lb,ub}] [Boolean words: 16 variables x 2 bits] [one byte per slice].
 // Variables >= ni are the Boolean ones of the COMPACT layout (root domain within 0..1): bit 2k of their word says
 // "lb raised to 1", bit 2k+1 "ub lowered to 0" -- narrowing is a `ds_or` (monotone like max/min), 3 = empty.
@@ -252,17 +298,20 @@ template <int C>
 __device__ __forceinline__ Itv load_int(const int2* store, int v) {  // an integer (non-Boolean) variable of the layout
   Itv d;
   if (C == 3) {
+    v = TB_IDX(1, v, slab_vars);
     const long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(hot_or_cold(store + v, v)), TB_RLX, TB_WG);
     d.lb = (int)(raw & 0xffffffffll);
     d.ub = (int)(raw >> 32);
     return d;
   }
   if (C == 2) {
+    v = TB_IDX(2, v, store_words);
     const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + v, TB_RLX, TB_WG);
     d.lb = (int)(short)(w & 0xffffu);
     d.ub = (int)w >> 16;
     return d;
   }
+  TB_CHECK_ITV(1, v);
   const long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + v), TB_RLX, TB_WG);
   d.lb = (int)(raw & 0xffffffffll);
   d.ub = (int)(raw >> 32);
@@ -274,7 +323,7 @@ __device__ __forceinline__ Itv load_int8(const int2* store, int nw, int f, unsig
   const int v = f & 0xffff, base = ((f >> 16) & 0x7fff) - C8_BASE_BIAS;
   const bool wide = v < nw;
   const int h = v + nw;
-  const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + (wide ? v : (h >> 1)), TB_RLX, TB_WG);
+  const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + TB_IDX(3, wide ? v : (h >> 1), store_words), TB_RLX, TB_WG);
   if (raw) *raw = w;
   const unsigned pair = w >> ((h & 1) * 16);
   Itv d;
@@ -305,7 +354,7 @@ __device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v, unsign
     const int id = v & 0xffff, nw = ni_wide(ni), n_i = ni & 0xffff, base = ((v >> 16) & 0x7fff) - C8_BASE_BIAS;
     const bool isb = id >= n_i, wide = id < nw;
     const int b = id - n_i, h = id + nw;
-    const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + (isk ? 0 : (isb ? bool_word0<4>(ni) + (b >> 4) : (wide ? id : (h >> 1)))), TB_RLX, TB_WG);
+    const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + TB_IDX(4, isk ? 0 : (isb ? bool_word0<4>(ni) + (b >> 4) : (wide ? id : (h >> 1))), store_words), TB_RLX, TB_WG);
     const unsigned bits = (w >> ((b & 15) * 2)) & 3u, pair = w >> ((h & 1) * 16);
     if (seen) *seen = w;
     Itv d;
@@ -317,7 +366,7 @@ __device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v, unsign
     // one 4-byte load whatever the kind: the integer's packed bounds, or the Boolean word holding the variable's two bits
     const bool isb = v >= ni;
     const int b = v - ni;
-    const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + (isk ? 0 : (isb ? ni + (b >> 4) : v)), TB_RLX, TB_WG);
+    const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned*>(store) + TB_IDX(5, isk ? 0 : (isb ? ni + (b >> 4) : v), store_words), TB_RLX, TB_WG);
     const unsigned bits = (w >> ((b & 15) * 2)) & 3u;
     Itv d;
     d.lb = isk ? kv : (isb ? (int)(bits & 1u) : (int)(short)(w & 0xffffu));
@@ -330,7 +379,8 @@ __device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v, unsign
   Itv d;
   const bool isb = v >= ni;
   const int b = v - ni;
-  const int idx = isk ? 0 : (isb ? ni + (b >> 5) : v);
+  int idx = isk ? 0 : (isb ? ni + (b >> 5) : v);
+  TB_CHECK_ITV(6, idx);
   const long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + idx), TB_RLX, TB_WG);
   const int lo = (int)(raw & 0xffffffffll), hi = (int)(raw >> 32);
   const unsigned word = (unsigned)(((b >> 4) & 1) ? hi : lo);
@@ -377,24 +427,26 @@ __device__ __forceinline__ void cas_lower_ub8(unsigned* w, int sh, int rel) {
 __device__ __forceinline__ void raise_int_lb8(int2* store, int nw, int f, int val) {
   const int v = f & 0xffff, h = v + nw;
   unsigned* const words = reinterpret_cast<unsigned*>(store);
-  if (v < nw) { cas_raise_lb16(words + v, val); return; }
-  cas_raise_lb8(words + (h >> 1), (h & 1) * 16, val - (((f >> 16) & 0x7fff) - C8_BASE_BIAS));
+  if (v < nw) { cas_raise_lb16(words + TB_IDX(8, v, store_words), val); return; }
+  cas_raise_lb8(words + TB_IDX(8, h >> 1, store_words), (h & 1) * 16, val - (((f >> 16) & 0x7fff) - C8_BASE_BIAS));
 }
 __device__ __forceinline__ void lower_int_ub8(int2* store, int nw, int f, int val) {
   const int v = f & 0xffff, h = v + nw;
   unsigned* const words = reinterpret_cast<unsigned*>(store);
-  if (v < nw) { cas_lower_ub16(words + v, val); return; }
-  cas_lower_ub8(words + (h >> 1), (h & 1) * 16 + 8, val - (((f >> 16) & 0x7fff) - C8_BASE_BIAS));
+  if (v < nw) { cas_lower_ub16(words + TB_IDX(8, v, store_words), val); return; }
+  cas_lower_ub8(words + TB_IDX(8, h >> 1, store_words), (h & 1) * 16 + 8, val - (((f >> 16) & 0x7fff) - C8_BASE_BIAS));
 }
 template <int C>
 __device__ __forceinline__ void raise_int_lb(int2* store, int v, int val) {
-  if (C == 2) { cas_raise_lb16(reinterpret_cast<unsigned*>(store) + v, val); return; }
+  if (C == 2) { cas_raise_lb16(reinterpret_cast<unsigned*>(store) + TB_IDX(7, v, store_words), val); return; }
+  if (C == 3) v = TB_IDX(7, v, slab_vars); else TB_CHECK_ITV(7, v);
   if (C == 3) { (void)__hip_atomic_fetch_max(&hot_or_cold(store + v, v)->x, val, TB_RLX, TB_WG); return; }
   (void)__hip_atomic_fetch_max(&store[v].x, val, TB_RLX, TB_WG);
 }
 template <int C>
 __device__ __forceinline__ void lower_int_ub(int2* store, int v, int val) {
-  if (C == 2) { cas_lower_ub16(reinterpret_cast<unsigned*>(store) + v, val); return; }
+  if (C == 2) { cas_lower_ub16(reinterpret_cast<unsigned*>(store) + TB_IDX(7, v, store_words), val); return; }
+  if (C == 3) v = TB_IDX(7, v, slab_vars); else TB_CHECK_ITV(7, v);
   if (C == 3) { (void)__hip_atomic_fetch_min(&hot_or_cold(store + v, v)->y, val, TB_RLX, TB_WG); return; }
   (void)__hip_atomic_fetch_min(&store[v].y, val, TB_RLX, TB_WG);
 }
@@ -420,7 +472,7 @@ __device__ __forceinline__ void raise_lb(int2* store, int ni, int v, int val) {
   if (C && v < 0) return;  // a constant kept out of the slab (load_dom)
   if (C && var_of<C>(v) >= ni_int<C>(ni)) {
     const int b = var_of<C>(v) - ni_int<C>(ni);
-    if (val >= 1) (void)__hip_atomic_fetch_or(bool_words<C>(store, ni) + (b >> 4), 1u << ((b & 15) * 2), TB_RLX, TB_WG);
+    if (val >= 1) (void)__hip_atomic_fetch_or(reinterpret_cast<unsigned*>(store) + TB_IDX(9, bool_word0<C>(ni) + (b >> 4), store_words), 1u << ((b & 15) * 2), TB_RLX, TB_WG);
     return;
   }
   raise_ivar_lb<C>(store, ni, v, val);
@@ -431,7 +483,7 @@ __device__ __forceinline__ void lower_ub(int2* store, int ni, int v, int val) {
   if (C && v < 0) return;
   if (C && var_of<C>(v) >= ni_int<C>(ni)) {
     const int b = var_of<C>(v) - ni_int<C>(ni);
-    if (val <= 0) (void)__hip_atomic_fetch_or(bool_words<C>(store, ni) + (b >> 4), 2u << ((b & 15) * 2), TB_RLX, TB_WG);
+    if (val <= 0) (void)__hip_atomic_fetch_or(reinterpret_cast<unsigned*>(store) + TB_IDX(9, bool_word0<C>(ni) + (b >> 4), store_words), 2u << ((b & 15) * 2), TB_RLX, TB_WG);
     return;
   }
   lower_ivar_ub<C>(store, ni, v, val);
@@ -447,9 +499,10 @@ __device__ __forceinline__ void narrow_var8(int2* store, int ni, int f, int nl, 
   if (v >= n_i) {
     const int b = v - n_i;
     const unsigned bits = ((cl && nl >= 1) ? 1u : 0u) | ((cu && nu <= 0) ? 2u : 0u);
-    if (bits) (void)__hip_atomic_fetch_or(words + bool_word0<4>(ni) + (b >> 4), bits << ((b & 15) * 2), TB_RLX, TB_WG);
+    if (bits) (void)__hip_atomic_fetch_or(words + TB_IDX(9, bool_word0<4>(ni) + (b >> 4), store_words), bits << ((b & 15) * 2), TB_RLX, TB_WG);
     return;
   }
+  (void)TB_IDX(8, v < nw ? v : ((v + nw) >> 1), store_words);
   unsigned old = __hip_atomic_load(words + (v < nw ? v : ((v + nw) >> 1)), TB_RLX, TB_WG);
   if (v < nw) {
     const int tl = nl > 32767 ? 32767 : nl, tu = nu < -32768 ? -32768 : nu;
@@ -718,6 +771,7 @@ __device__ __forceinline__ void note_change(BlockShared& sh, const EventState& e
 }
 
 __device__ __forceinline__ void mark_slice(unsigned* dirty, int t) {
+  t = TB_IDX(10, t, n_slices);
   (void)__hip_atomic_fetch_or(&dirty[t >> 5], 1u << (t & 31), TB_RLX, TB_WG);
 }
 
@@ -740,7 +794,7 @@ __device__ __forceinline__ bool mark_packed(unsigned* dirty, unsigned packed, in
 // whatever the degree up to 11; returns true when the list is longer (mark_tail).
 __device__ __forceinline__ bool mark_var(const DevProblem& P, unsigned* dirty, int v, int self, int ev, int& deg_out, int& off_out, bool& did) {
   int4 a = make_int4(0, 0, 0, 0), b = a;
-  if (ev) { a = glob(P.var_adj)[2 * (size_t)v]; b = glob(P.var_adj)[2 * (size_t)v + 1]; }
+  if (ev) { v = TB_IDX(11, v, adj_vars); a = glob(P.var_adj)[2 * (size_t)v]; b = glob(P.var_adj)[2 * (size_t)v + 1]; }
   const unsigned w[8] = {(unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w, (unsigned)b.x, (unsigned)b.y, (unsigned)b.z, (unsigned)b.w};
   const int deg = (int)(w[0] & 0xffffu);
 #pragma unroll
@@ -763,7 +817,7 @@ __device__ __forceinline__ bool mark_tail(const DevProblem& P, unsigned* dirty, 
     mask &= mask - 1;
     const int d = __builtin_amdgcn_readlane(deg, l), o = __builtin_amdgcn_readlane(off, l), e = __builtin_amdgcn_readlane(ev, l);
     for (int j = lane; j < d - 11; j += 64) {
-      const int t = glob(P.adj_rest)[o + j];
+      const int t = glob(P.adj_rest)[TB_IDX(12, o + j, adj_rest)];
       if ((t & 0x3fffffff) != self && ((t >> 30) & e)) { mark_slice(dirty, t & 0x3fffffff); did = true; }
     }
   }
@@ -878,7 +932,7 @@ template <int C>
 __device__ __forceinline__ BoolRef bool_ref(int2* store, int ni, int v, bool act) {
   const int b = act ? v - ni_int<C>(ni) : 0;  // idle lanes of a padded slice look at the first Boolean and touch nothing (a Boolean's reference is the variable in every layout)
   BoolRef r;
-  r.word = bool_words<C>(store, ni) + (b >> 4);
+  r.word = reinterpret_cast<unsigned*>(store) + TB_IDX(22, bool_word0<C>(ni) + (b >> 4), store_words);
   r.shift = (b & 15) * 2;
   return r;
 }
@@ -917,6 +971,15 @@ __device__ __forceinline__ Itv lean_load(int2* store, int ni, const LeanOperand<
   if (C && kind != 1) return load_dom<C>(store, ni, o.v);
   return load_ivar<C>(store, ni, o.v);
 }
+// Pseudo-class of the lean run (never in a record): a slice of `x = y * z` whose operands are all non-negative and finite with products below 2^30 (engine.hip:
+// slice_infos, bit 0x800 of the info word).  The generic heavy rule (propagators.hpp: evaluate_heavy) pays for every sign case: four 64-bit corner products, sixteen
+// signed divisions with floor / ceil fix-ups and the TDIV / TMOD code beside it -- 1018 VALU per pass, and the 15 `Price_i = price_i * occupied_i` of wordpress7_500 sit
+// on the objective's critical path (1.5 passes per node: 16 % of a node's VALU, r04 region budget).  On non-negative operands products and quotients are monotone:
+// the hull of the corner products is [y.lb * z.lb, y.ub * z.ub], of the quotients [ceil(x.lb / z.ub), floor(x.ub / z.lb)] -- two unsigned multiplications and four
+// unsigned divisions, same bounds as the generic rule on every store that is not already failed.
+constexpr int K_MUL_NN = 10;
+__device__ __forceinline__ unsigned umax1(int a) { return a > 1 ? (unsigned)a : 1u; }  // a divisor that may be garbage on an idle or failed lane
+
 // CLS >= 0: the class is a compile-time constant (the pass loop then holds one class body and no chain of scalar compares); -1: `cls_dyn`.
 template <int C, int CLS>
 __device__ __forceinline__ unsigned lean_class_run_t(const RunEnv& E, const int cls_dyn, const int kinds, const int4 pr, const bool act, int2* store, const int ni, unsigned& run_writes, unsigned& wave_writes, int& nar_all) {
@@ -948,6 +1011,23 @@ __device__ __forceinline__ unsigned lean_class_run_t(const RunEnv& E, const int 
       yl = imax(yl, X.lb - Z.ub); yu = imin(yu, X.ub - Z.lb);
       zl = imax(zl, X.lb - Y.ub); zu = imin(zu, X.ub - Y.lb);
       ent = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub;
+    } else if (cls == K_MUL_NN) {
+      xl = imax(xl, (int)((unsigned)Y.lb * (unsigned)Z.lb)); xu = imin(xu, (int)((unsigned)Y.ub * (unsigned)Z.ub));
+      const bool xnz = X.lb > 0;  // a non-zero product has non-zero factors
+      yl = sel(xnz && Y.lb == 0, 1, yl); yu = sel(xnz && Y.ub == 0, -1, yu);
+      zl = sel(xnz && Z.lb == 0, 1, zl); zu = sel(xnz && Z.ub == 0, -1, zu);
+      const unsigned uxl = (unsigned)imax(X.lb, 0), uxu = (unsigned)imax(X.ub, 0);
+      if (wave_any(act && Z.lb > 0)) {  // y within x / z (0 not in z)
+        const unsigned dzu = umax1(Z.ub), dzl = umax1(Z.lb);
+        const int lo = (int)((uxl + dzu - 1u) / dzu), hi = (int)(uxu / dzl);
+        yl = sel(Z.lb > 0, imax(yl, lo), yl); yu = sel(Z.lb > 0, imin(yu, hi), yu);
+      }
+      if (wave_any(act && Y.lb > 0)) {  // z within x / y
+        const unsigned dyu = umax1(Y.ub), dyl = umax1(Y.lb);
+        const int lo = (int)((uxl + dyu - 1u) / dyu), hi = (int)(uxu / dyl);
+        zl = sel(Y.lb > 0, imax(zl, lo), zl); zu = sel(Y.lb > 0, imin(zu, hi), zu);
+      }
+      ent = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub && X.lb == (int)((unsigned)Y.lb * (unsigned)Z.lb);
     } else if (cls == K_LEQ_T) {
       yu = imin(yu, Z.ub); zl = imax(zl, Y.lb);
       ent = Y.ub <= Z.lb;
@@ -1125,7 +1205,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     for (int e0 = wave * 64; e0 < cnt; e0 += T) {  // one lane per entry; long lists are finished cooperatively
       TB_REGION(3);
       const int e = e0 + lane;
-      const int entry = e < cnt ? es.list[e] : 0;
+      const int entry = e < cnt ? es.list[TB_IDX(20, e, chg_cap)] : 0;
       const int ev = e < cnt ? ((entry >> 30) & 3) : 0;
       int deg = 0, off = 0;
       bool did = false;
@@ -1215,6 +1295,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       while (s >= 0) {
         TB_REGION(5);
         const int s_next = next_slice();
+        s = TB_IDX(13, s, n_slices);
 #if TB_SC_PREFETCH
         const int4 sc = sc_cur;
         if (s_next >= 0) sc_cur = (es.succ + (size_t)s_next * 64)[lane];
@@ -1242,8 +1323,8 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             // ---- lean implication run: `y <= z` on two 2-bit Booleans (bit 0: lb raised to 1, bit 1: ub lowered to 0) from the successor
             // record alone (engine.hip: pack_succ): z.ub = 0 forces y.ub = 0, y.lb = 1 forces z.lb = 1; entailed once y.ub = 0 or z.lb = 1.
             unsigned* const words = reinterpret_cast<unsigned*>(store);  // (word indexes from the start of the slab, whatever the layout)
-            unsigned* const wy = words + ((unsigned)sc.x & 0xffffu);
-            unsigned* const wz = words + ((unsigned)sc.x >> 16);
+            unsigned* const wy = words + TB_IDX(14, (unsigned)sc.x & 0xffffu, store_words);
+            unsigned* const wz = words + TB_IDX(14, (unsigned)sc.x >> 16, store_words);
             const int ys = (sc.w >> 19) & 30, zs = (sc.w >> 23) & 30;
             const unsigned am = act ? ~0u : 0u;  // idle lanes of a padded slice see nothing to do
             unsigned acc = 0u;  // what this lane narrowed during the run: bit 1 its y (upper bound lowered), bit 0 its z (lower bound raised)
@@ -1537,6 +1618,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               }
               un_i = act & !ent;
             });
+          } else if (info.y & 0x800) {
+            TB_REGION(66);
+            wave_iters = lean_class_run_t<C, K_MUL_NN>(E, K_MUL_NN, (int)(key >> 10), pr, act, store, P.n_int, run_writes, wave_writes, nar_all);
           } else if (info.y & 0x200) {
             TB_REGION(43);
             wave_iters = lean_class_run<C>(E, __builtin_ctz(key & CLASS_SET_MASK), (int)(key >> 10), pr, act, store, P.n_int, run_writes, wave_writes, nar_all);
@@ -1613,7 +1697,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
     auto unentailed_lanes = [&](int first_prop, bool whole_slice) -> unsigned long long {  // wave-uniform result
       const int i = whole_slice ? first_prop + lane : first_prop;
       const bool act = i < n;
-      const int4 pr = props[act ? i : 0];
+      const int4 pr = props[TB_IDX(19, act ? i : 0, records)];
       const Itv X = load_dom<C>(store, P.n_int, pr.y), Y = load_dom<C>(store, P.n_int, pr.z), Z = load_dom<C>(store, P.n_int, pr.w);
       const Cand c = evaluate_single(pr.x, X, Y, Z);
       return wave_ballot(act && !c.ent);
@@ -1768,6 +1852,7 @@ __device__ __forceinline__ unsigned order_key(int var_order, const Itv d) {
 // search went deeper (the reference reallocates its vector, barebones:401-403; here a segment is 16 384 decisions by default).
 __device__ __forceinline__ Decision& dec_at(const DevProblem& P, BlockShared& sh, Decision* dec, int i) {
   const int k = i >> P.max_depth_log2;
+  (void)TB_IDX_N(15, i, (1 + sh.n_dec_seg) << P.max_depth_log2);
   return k == 0 ? dec[i] : sh.dec_seg[k - 1][i & (P.max_depth - 1)];
 }
 
@@ -1813,8 +1898,9 @@ __device__ __forceinline__ void split(const DevProblem& P, BlockShared& sh, Deci
     TB_REGION(33);
     const int s = sh.cur_strategy;  // uniform: read after a barrier
     if (s >= P.n_strats) { if (tid == 0) sh.found = 0; __syncthreads(); return; }
-    const int off = glob(P.strat_off)[s];
+    const int off = glob(P.strat_off)[TB_IDX(16, s, strats)];
     int n = glob(P.strat_off)[s + 1] - off;
+    if (n > 0) (void)TB_IDX_N(16, off + n - 1, g_bl_total());
     const bool in_store = (n == 0);
     if (in_store) n = P.n_vars;
     const int vo = glob(P.strat_var_order)[s];
@@ -2182,6 +2268,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
   if (P.leaf_assign && !failed && all_entailed) {  // uniform
     bool open = false;
     for (int v = tid; v < P.n_vars; v += block_threads<TB>()) {  // (P.n_vars: the variables of the slab; constants kept out of it are assigned)
+      (void)TB_IDX(21, v, slab_vars);
       const Itv d = load_dom<C>(store, P.n_int, C == 4 ? (v | (C8_BASE_BIAS << 16)) : v);  // (COMPACT8: any base will do for "lb == ub")
       open |= d.lb != d.ub;
     }
@@ -2466,7 +2553,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_
         if (prof && tid == 0) tp = wall_clock64();
         if (!diving) {
           TB_REGION(32);
-          if (d0 < P.snapshot_levels) store_out<C, TB>(snap + (size_t)d0 * VX, store, VX);  // d0 == 0: barebones:785-791
+          if (d0 < P.snapshot_levels) store_out<C, TB>(snap + (size_t)TB_IDX(17, d0, snapshot_levels) * VX, store, VX);  // d0 == 0: barebones:785-791
           if ((pk(P) & 0x4) && d0 < P.snapshot_levels) store_out<C, TB>(snap + (size_t)d0 * VX, store, VX);  // tuning: cost of the snapshot
           if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
           __syncthreads();
@@ -2509,6 +2596,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_
         const int depth = sh.new_depth;
         if (depth == -1) { exhausted = true; break; }
         const int lvl = (depth - 1) < (P.snapshot_levels - 1) ? (depth - 1) : (P.snapshot_levels - 1);
+        (void)TB_IDX(17, lvl, snapshot_levels);
         for (int rep = reps_of(P, 6); rep > 0; --rep) store_in<C, TB>(store, snap + (size_t)lvl * VX, VX);
         if (tid == 0) { sh.bot = 0; sh.depth = depth; }
         __syncthreads();

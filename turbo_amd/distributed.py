@@ -99,27 +99,47 @@ def run_linked(session, dist=None, period_s: float = 0.0002, max_seconds: float 
     return out
 
 
-def exchange_until_done(session, dist=None, tensor_device="cpu", period_s: float = 0.0005, max_seconds: float | None = None):
+_relay_group = None
+
+
+def relay_group(dist):
+    """A gloo group over all ranks for everything the processes exchange WHILE a search kernel runs (collective, created once).
+    The persistent kernel fills every CU: a collective of the default RCCL group would queue its own kernel
+    behind it and deliver the bound when the search is over.  gloo moves a few bytes over CPU tensors and touches no GPU."""
+    global _relay_group
+    if dist is None or dist.get_world_size() == 1:
+        return None
+    if _relay_group is None:
+        _relay_group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    return _relay_group
+
+
+def exchange_until_done(session, dist=None, tensor_device="cpu", period_s: float = 0.0005, max_seconds: float | None = None, target: int | None = None):
     """Host relay (fallback when the cells are not linked): drive one started session to completion.
 
     `session` needs poll() -> (local_best, done), push_bound(b) and stop().  With a process group,
     every rank calls this collectively: each round all-reduces (min) the pair (best bound, done flag),
     so all ranks leave the loop in the same round, and every rank imports the global incumbent.
+    The all-reduce runs on CPU tensors over the gloo side group (relay_group), never on the GPU the search kernel occupies;
+    `tensor_device` is kept for callers of earlier rounds and ignored.
+    `target`: stop every rank as soon as the group's incumbent is <= target (bench.py --mode solve: time to a target objective).
     Returns (global_best, rounds).
     """
     world = dist.get_world_size() if dist is not None else 1
-    buf = None
+    buf, group = None, None
     if world > 1:
         import torch
-        buf = torch.empty(2, dtype=torch.int32, device=tensor_device)
+        group = relay_group(dist)
+        buf = torch.empty(2, dtype=torch.int32, device="cpu")
     gbest, rounds, t0 = PINF, 0, time.perf_counter()
+    stopped = False
     while True:
         best, done = session.poll()
         rounds += 1
         if world > 1:
             buf[0] = int(best)
             buf[1] = 1 if done else 0
-            dist.all_reduce(buf, op=dist.ReduceOp.MIN)
+            dist.all_reduce(buf, op=dist.ReduceOp.MIN, group=group)
             rbest, all_done = int(buf[0].item()), int(buf[1].item())
         else:
             rbest, all_done = int(best), int(bool(done))
@@ -128,8 +148,9 @@ def exchange_until_done(session, dist=None, tensor_device="cpu", period_s: float
             session.push_bound(gbest)
         if all_done:
             return gbest, rounds
-        if max_seconds is not None and time.perf_counter() - t0 > max_seconds:
+        if not stopped and ((max_seconds is not None and time.perf_counter() - t0 > max_seconds) or (target is not None and gbest <= target)):
             session.stop()
+            stopped = True
         time.sleep(period_s)
 
 
