@@ -1,0 +1,110 @@
+"""Workgroup teams (store layout 5, kernels.hpp: solve_kernel_team; opt-in: TB_TEAM=1): the workgroups of one XCD search ONE subproblem together on ONE store in global
+memory -- partitioned sweeps, replicated control, the leader talks to the queue / grid words / host.  Same fixpoints, same trees:
+  * TB_TEAM_ALL=1 makes the whole grid one team (whatever the XCDs: the protocol only uses agent-scope accesses), and one team walking 2^d subproblems in order must
+    walk the ORACLE's tree, node for node, however many members share the sweeps (1, 3, 16, 40 workgroups);
+  * full grids (eight teams racing, formed from the XCDs the workgroups really run on) prove the reference-held optima, enumerate exactly the solutions of satisfaction
+    problems, and agree with the one-workgroup-per-subproblem kernels on the synthetic network.
+The environment switches are read at session creation.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import BENCH, SLOW_FOR_ORACLE, known_answers
+from oracle import pyoracle
+from turbo_amd import capi, frontend
+
+pytestmark = pytest.mark.gpu
+ROWS = known_answers()
+FAST = [r for r in ROWS if r[0] not in SLOW_FOR_ORACLE]
+TEAM = dict(only_global_memory=1, threads_per_block=1024)  # what the team plan needs: the store in global memory, 1024-thread workgroups
+
+
+@pytest.fixture
+def team_env(monkeypatch):
+    monkeypatch.setenv("TB_TEAM", "1")
+    return monkeypatch
+
+
+def plan_of(tcn, **cfg):
+    s = capi.Session(tcn, capi.make_config(**cfg))
+    p = s.plan()
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("members", [1, 3, 16, 40])
+@pytest.mark.parametrize("fixpoint", [1, 0], ids=["wac1", "ac1"])
+@pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pat7.fzn", "test_data/pennies5.fzn", "accap_a3.fzn"])
+def test_one_team_walks_the_oracles_tree(team_env, rel, fixpoint, members):
+    team_env.setenv("TB_TEAM_ALL", "1")
+    tcn = frontend.load_fzn(os.path.join(BENCH, rel))
+    power, cut = 4, 3000
+    has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power, cutnodes=cut)
+    cfg = dict(or_nodes=members, subproblems_power=power, stop_after_n_nodes=cut, timeout_ms=120000, fixpoint=fixpoint, **TEAM)
+    assert plan_of(tcn, **cfg)["kernel_opt"] == 10, "the team kernel was not planned"
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(**cfg))
+    assert has_g == has_o
+    for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
+        assert st_g[k] == st_o[k], k
+    if has_o:
+        np.testing.assert_array_equal(best_g, best_o)
+
+
+@pytest.mark.parametrize("rule", [0, 1], ids=["barebones_rule", "gpu_rule"])
+def test_one_team_under_both_leaf_rules(team_env, rule):
+    team_env.setenv("TB_TEAM_ALL", "1")
+    from leaf_rule_models import as_tcn, loose_network
+    for seed in range(8):
+        rng = np.random.default_rng(4200 + seed)
+        store, props = loose_network(rng)
+        tcn = as_tcn(store, props, var_order=int(rng.integers(0, 5)), val_order=int(rng.integers(0, 4)))
+        for power in (0, 3):
+            has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power, stop_after_n_solutions=0, leaf_requires_assignment=rule)
+            has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=5, subproblems_power=power, timeout_ms=60000, fixpoint=1, stop_after_n_solutions=0,
+                                                                   leaf_requires_assignment=rule, **TEAM))
+            assert has_g == has_o and st_g["exhaustive"] == st_o["exhaustive"], (seed, power)
+            for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
+                assert st_g[k] == st_o[k], (seed, power, k)
+
+
+@pytest.mark.parametrize("fixpoint", [1, 0], ids=["wac1", "ac1"])
+@pytest.mark.parametrize("rel,expected", FAST)
+def test_teams_of_the_real_xcds_prove_the_known_optima(team_env, rel, expected, fixpoint):
+    """The whole grid, teams formed from HW_REG_XCC_ID, racing through the queue with the incumbent exchanged through the grid words."""
+    tcn = frontend.load_fzn(os.path.join(BENCH, rel))
+    has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=120000, fixpoint=fixpoint, **TEAM))
+    assert st["threads_per_block"] == 1024 and st["mem_kind"] == 0
+    assert has and st["exhaustive"] == 1
+    assert tcn.objective_of(best) == expected
+    _, failed, ent, _, _ = pyoracle.propagate(best, tcn.props)
+    assert not failed and ent
+    assert st["eps_solved_subproblems"] + st["eps_skipped_subproblems"] == 1 << st["subproblems_power"], "every subproblem exactly once"
+
+
+def test_teams_enumerate_every_solution_once(team_env):
+    from test_gpu_streaming import MANY, run_streaming
+    tcn = frontend.Model.from_string(MANY).tcn()
+    _, _, ost = pyoracle.solve(tcn, stop_after_n_solutions=0)
+    got, has, best, st = run_streaming(tcn, fixpoint=1, stop_after_n_solutions=0, **TEAM)
+    assert has and st["exhaustive"] and st["solutions"] == ost["solutions"] == len(got)
+    assert len({s.tobytes() for s, _ in got}) == len(got)
+
+
+def test_synthetic_network_teams_agree_with_single_workgroups(team_env):
+    """BASELINE.json configs[4] in small (20k x 100k): the same node budget per searcher gives the same tree statistics whether a searcher is a workgroup or a team."""
+    from turbo_amd.synth import make_synthetic
+    tcn = make_synthetic(20000, 100000, seed=42)
+    cfg = dict(subproblems_power=6, stop_after_n_nodes=40, timeout_ms=240000, fixpoint=1, **TEAM)
+    team_env.setenv("TB_TEAM_ALL", "1")
+    has_t, best_t, st_t = capi.solve(tcn, capi.make_config(or_nodes=32, **cfg))
+    team_env.setenv("TB_TEAM", "0")
+    has_w, best_w, st_w = capi.solve(tcn, capi.make_config(or_nodes=1, **cfg))
+    for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
+        assert st_t[k] == st_w[k], k
+    assert has_t == has_w
+    if has_t:
+        np.testing.assert_array_equal(best_t, best_w)
+        _, failed, ent, _, _ = pyoracle.propagate(best_t, tcn.props)
+        assert not failed and ent

@@ -101,6 +101,24 @@ __host__ __device__ inline unsigned long long eps_local_count(int d, int k, int 
   return eps_local_lower_bound(1ull << d, k, g, G);
 }
 
+// Workgroup teams (store layout 5, r05): the workgroups resident on ONE XCD search one subproblem together on ONE store in global memory, which then lives in that
+// XCD's 4 MB of L2 instead of 32 stores of 800 KB thrashing it (synthetic 100k x 500k: three of four gathers missed L2).  One TeamCtl per XCD, plain device memory
+// touched with agent-scope atomics only.
+struct alignas(64) TeamCtl {
+  unsigned members;     // workgroups registered (team formation at kernel start)
+  unsigned arrive;      // barrier: arrivals of the current generation
+  unsigned flags;       // barrier: OR of the members' contributions
+  unsigned gen;         // barrier generation
+  unsigned result[2];   // merged flags of generation g in result[g & 1]
+  unsigned pad[2];
+  unsigned long long bcast[4];  // leader -> members (subproblem, bound), read between two barriers
+};
+struct alignas(64) TeamGrid {
+  unsigned registered;  // workgroups of the grid that have joined a team
+  unsigned pad[15];
+  TeamCtl team[8];      // indexed by HW_REG_XCC_ID
+};
+
 // Solution ring in pinned host memory (streaming, gpu_dive_and_solve.hpp:100-132 re-done without a print lock):
 // a producer takes a ticket, waits until `ticket - consumed < slots`, copies its store into slot ticket % slots and
 // publishes seq[slot] = ticket + 1; the host consumes in ticket order.
@@ -202,6 +220,8 @@ struct DevProblem {
   Decision* dec_pool;  // [dec_pool_segments][max_depth] further segments, taken by the workgroups whose search goes deeper
   BlockStats* g_stats;
   Ctrl* ctrl;
+  TeamGrid* teams;           // store layout 5: the per-XCD team control blocks (nullptr otherwise)
+  int team_all, pad_team;    // store layout 5, test aid (TB_TEAM_ALL=1): the whole grid is ONE team whatever the XCDs (agent-scope accesses are coherent device-wide: slower, same results)
   PeerCell* cell;            // this device's cell
   PeerCell* const* peers;    // [world] cells of every rank (peers[rank] == cell; nullptr = not reachable), device array
   SolutionRing ring;

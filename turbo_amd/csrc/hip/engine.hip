@@ -70,6 +70,7 @@ int query_caps(int device, DeviceCaps* caps) {
 
 // ---- launch planning -----------------------------------------------------------------------------
 
+constexpr int TEAM_SWEEP_OPT = 10;  // kernel_opt of a plan that searches in workgroup teams (sweeps, layout 5 << 1)
 constexpr int HOT_EVENT_OPT = 3, HOT_SWEEP_OPT = 6;  // kernel_opt of a plan with the hot tier (event: the layout; sweeps: layout << 1)
 struct LaunchPlan {
   int threads = 256, tmax = 256;
@@ -83,7 +84,8 @@ struct LaunchPlan {
   int kernel_event = 0, kernel_opt = 0;  // template flags of the kernels this plan launches (solve and root propagation alike)
   int compact = 0, n_int = 0, unent_off = 0;  // store layout (Layout below)
   bool hot = false;  // store in global memory with its first HOT_VARS intervals in LDS (kernels.hpp: layout 3); the search kernel only
-  int prop_opt() const { return hot ? 0 : kernel_opt; }  // template flag of the batch-propagation kernel on the same slabs (the plain layout)
+  bool team = false; // one store per XCD shared by the workgroups resident on it (kernels.hpp: layout 5, solve_kernel_team); the search kernel only
+  int prop_opt() const { return (hot || team) ? 0 : kernel_opt; }  // template flag of the batch-propagation kernel on the same slabs (the plain layout)
 };
 
 // Store layout of a session.  COMPACT: the variables whose root domain lies within 0..1 are renumbered behind the
@@ -351,9 +353,17 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     if (!search || lay.compact || T != 1024 || n_vars <= HOT_VARS || cfg.entailed_prop_removal || std::getenv("TB_NO_HOT_TIER") != nullptr) return false;
     return fixed + (size_t)HOT_VARS * 8 + dirty_b <= lds;
   };
+  // Workgroup teams (r05; kernels.hpp layout 5): the sweeps of a network whose store lives in global memory, 1024-thread workgroups, one per CU -- the workgroups of an
+  // XCD share ONE store, which then sits in that XCD's L2.  (TB_TEAM=0 switches it off for A/B runs, TB_TEAM=1 takes it wherever it is possible.)
+  auto team_mode = [&]() {
+    const char* e = std::getenv("TB_TEAM");
+    if (!search || event || lay.compact || T != 1024 || cfg.entailed_prop_removal || (e != nullptr && e[0] == '0')) return false;
+    return e != nullptr && e[0] == '1';  // (opt-in until it is measured against the hot tier)
+  };
   if (cfg.only_global_memory) {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
-    if (hot_tier()) { p.hot = true; p.blocks_per_cu = 1; p.shared_bytes = (int)(fixed + (size_t)HOT_VARS * 8 + dirty_b); }
+    if (team_mode()) { p.team = true; p.blocks_per_cu = 1; }
+    else if (hot_tier()) { p.hot = true; p.blocks_per_cu = 1; p.shared_bytes = (int)(fixed + (size_t)HOT_VARS * 8 + dirty_b); }
   } else if (!event && !lay.compact && lds_footprint(caps, fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
     // (records in LDS: the plain sweeps on small networks only.  The event kernels and the compact layouts have no such instantiation:
     //  their records come out of L2 fast enough, see below, and a third memory kind for them is a quarter of the library's compile time.)
@@ -370,7 +380,8 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / lds_footprint(caps, fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
   } else {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
-    if (hot_tier()) { p.hot = true; p.blocks_per_cu = 1; p.shared_bytes = (int)(fixed + (size_t)HOT_VARS * 8 + dirty_b); }
+    if (team_mode()) { p.team = true; p.blocks_per_cu = 1; }
+    else if (hot_tier()) { p.hot = true; p.blocks_per_cu = 1; p.shared_bytes = (int)(fixed + (size_t)HOT_VARS * 8 + dirty_b); }
   }
   long long blocks = (long long)p.blocks_per_cu * caps.cus;
   if (cfg.or_nodes != 0) blocks = std::min<long long>(blocks, (long long)cfg.or_nodes);
@@ -406,7 +417,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   p.snapshot_levels = std::max(1, std::min(L, p.max_depth));
   p.kernel_event = event ? 1 : 0;
   // sweeps: entailed-slice removal (bit 0) or a compact layout (2: COMPACT, 4: COMPACT16) -- not both, to keep the number of kernels down
-  p.kernel_opt = p.hot ? (event ? HOT_EVENT_OPT : HOT_SWEEP_OPT) : (event ? p.compact : (cfg.entailed_prop_removal != 0 ? 1 : p.compact * 2));
+  p.kernel_opt = p.team ? TEAM_SWEEP_OPT : (p.hot ? (event ? HOT_EVENT_OPT : HOT_SWEEP_OPT) : (event ? p.compact : (cfg.entailed_prop_removal != 0 ? 1 : p.compact * 2)));
   *plan = p;
   return TB_OK;
 }
@@ -920,6 +931,14 @@ int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
 // (register / LDS limited).  A persistent kernel gains nothing from queued workgroups, so the grid is capped.
 int prepare_kernel(bool solve, int mem, int tmax, bool event, int opt, int bytes, int threads, int* max_blocks_per_cu) {
   int rc = TB_OK;
+  if (solve && opt == TEAM_SWEEP_OPT && !event) {  // the team kernel is not an instantiation of solve_kernel
+    const void* k = reinterpret_cast<const void*>(&solve_kernel_team);
+    HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, threads, (size_t)bytes));
+    *max_blocks_per_cu = std::min(nb, 1);  // one workgroup per CU: every workgroup of the grid must be resident (the teams form by waiting for the whole grid)
+    return TB_OK;
+  }
   if (solve) DISPATCH_KERNEL(rc = prepare_solve, mem, tmax, event, opt, (bytes, threads, max_blocks_per_cu));
   else DISPATCH_KERNEL_WIDE(rc = prepare_prop, mem, tmax, event, opt, (bytes, threads, max_blocks_per_cu));  // (batch propagation: no 128-thread instantiation)
   return rc;
@@ -1539,6 +1558,9 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   if (P.poll_ticks < 1) P.poll_ticks = 1;
   P.steal = (s->cfg.reserved[0] & 0x1000000) ? 0 : 1;
   P.leaf_assign = s->cfg.leaf_requires_assignment ? 1 : 0;
+  P.teams = nullptr;
+  P.team_all = (std::getenv("TB_TEAM_ALL") != nullptr && std::getenv("TB_TEAM_ALL")[0] == '1') ? 1 : 0;
+  if (plan.team && (rc = s->bufs.alloc(&P.teams, 1)) != TB_OK) return rc;
   // the cell other GPUs reach over xGMI: fine-grained device memory (coherent at system scope while kernels run)
   {
     void* c = nullptr;
@@ -1755,6 +1777,10 @@ int tb_session_start(tb_session* s) {
   if ((rc = bounds_arm(s->P, plan, std::max(1, s->P.n_strats), s->strat_total, s->adj_sizes, s->P.ctrl)) != TB_OK) return rc;
 #endif
   HIP_TRY(hipEventRecord(s->ev_start, s->stream));
+  if (plan.team) {
+    HIP_TRY(hipMemsetAsync(s->P.teams, 0, sizeof(TeamGrid), s->stream));
+    solve_kernel_team<<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->mbox_dev);
+  } else
   DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, plan.kernel_event != 0, plan.kernel_opt, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->d_P, s->mbox_dev));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev_stop, s->stream));

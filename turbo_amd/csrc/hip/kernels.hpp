@@ -91,17 +91,17 @@ struct alignas(16) BlockShared {
   int cur_strategy, next_unassigned, snap_strategy, snap_next_unassigned;
   int best_bound;  // best objective found by this workgroup (BlockData::best_bound, barebones:116)
   int found, sol, skip, open_vars;  // open_vars: the all-assigned scan of an all-entailed node found a variable that is not (leaf rule of the `gpu` path)
-  int new_depth, ev_all, chg_count[2], ev_busy;  // event mode: "run every slice" request, change-list fill, waves running a slice
+  int new_depth, ev_all, chg_count[2], team_res;  // event mode: "run every slice" request, change-list fill; team_res: merged flags of the last team barrier (layout 5)
   unsigned long long sub_idx;  // global index of the current subproblem
   unsigned long long sub_j;    // its index in the local numbering of rank sub_owner (eps_global_index)
   int sub_owner, sub_gen;      // rank whose share it belongs to; generation of the queue range it was fetched from
   int has_work, witness;       // witness: index of a propagator found un-entailed (fixpoint_event), -1 = none
   long long ticket;  // streaming: sequence number of the solution being handed to the host, -1 if none
   Decision* dec_seg[MAX_DEC_SEGS];  // segments 1.. of this workgroup's decision stack (segment 0 is its slab in g_dec)
-  int n_dec_seg, pad_seg;
+  int n_dec_seg, team;        // team (layout 5): member index | team size << 12 | XCD << 24
   long long t_start, t_mark;  // thread 0's clocks (kernel start, last phase boundary): LDS, not registers that live through every loop
   long long t_dive;           // start of the current dive (0: not diving)
-  int last_obj_ub, pad_ub;    // upper bound last imposed on the objective in this subproblem (PINF: none): test aid, tb_session_debug_path
+  int last_obj_ub, team_gen;  // upper bound last imposed on the objective in this subproblem (PINF: none): test aid, tb_session_debug_path; team_gen: barriers passed (layout 5)
   unsigned long long red_key[MAX_WAVES];
   int red_first[MAX_WAVES];
   BlockStats bs;  // written by thread 0 only
@@ -259,6 +259,75 @@ __device__ __forceinline__ int g_bl_total() { return g_bl.strat_total > 0 ? g_bl
 __device__ __forceinline__ constexpr int g_bl_total() { return 1; }
 #endif
 
+// ---- workgroup teams (store layout 5, r05) -----------------------------------------------------------------------------------------------
+// The workgroups resident on one XCD search ONE subproblem together, on ONE store in global memory (device_types.hpp: TeamCtl):
+//   * the store is read with agent-scope relaxed loads (`global_load ... sc1`: served by the XCD's L2, never by a CU's L1) and narrowed with agent-scope
+//     atomic max / min -- coherent for every CU whatever its placement, and L2 hits for the members of a team because they share that L2;
+//   * a sweep is PARTITIONED: member m of M evaluates the slices m, m + M, ... of every wave's share; the has-changed / not-entailed / failed / aborted
+//     flags of the members are merged by one team barrier per sweep (team_sync);
+//   * everything else is REPLICATED: every member runs the same control code on the same store -- same variable selection, same decision stack (a copy
+//     each), same backtracking -- so no decision has to be communicated; what is not a function of the store (the subproblem fetched from the queue, the
+//     incumbent read from the grid words, a stop request) is read by the team's leader (member 0) and broadcast through TeamCtl::bcast before a barrier;
+//   * block copies of the store (root restore, snapshot push / restore) are striped over the members; statistics are kept by the leader.
+// Teams are formed at kernel start from where the workgroups actually are (HW_REG_XCC_ID), not from an assumed dispatch order.
+constexpr unsigned TEAM_CHANGED = 1u, TEAM_UNENT = 2u, TEAM_BOT = 4u, TEAM_ABORT = 8u, TEAM_STOP = 16u, TEAM_WORK = 32u;
+__device__ __forceinline__ int team_member(const BlockShared& sh) { return sh.team & 0xfff; }
+__device__ __forceinline__ int team_size(const BlockShared& sh) { return (sh.team >> 12) & 0xfff; }
+__device__ __forceinline__ int team_xcd(const BlockShared& sh) { return (sh.team >> 24) & 0xf; }
+__device__ __forceinline__ TeamCtl* team_ctl(const DevProblem& P, const BlockShared& sh) { return &glob(P.teams)->team[team_xcd(sh)]; }
+
+// Team barrier (uniform call, every thread of every member): returns the OR of the members' `contrib` (thread 0's value counts).
+// Before it, every wave waits for its own outstanding memory operations (the narrowings are non-returning atomics: `vmcnt` counts them), the arrival is
+// an agent-scope acq_rel atomic; after it, agent-scope loads see everything the members wrote before they arrived.  Sense reversal by generation: the last
+// arriver collects the flags, clears the counter and publishes generation + 1; result[g & 1] cannot be overwritten before every member has read it
+// (generation g + 2 needs every member's arrival at g + 2).
+__device__ __forceinline__ unsigned team_sync(const DevProblem& P, BlockShared& sh, unsigned contrib) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    TeamCtl* t = team_ctl(P, sh);
+    const unsigned g = (unsigned)sh.team_gen, M = (unsigned)team_size(sh);
+    unsigned res = contrib;
+    if (M > 1) {
+      if (contrib) (void)__hip_atomic_fetch_or(&t->flags, contrib, TB_RLX, TB_AGENT);
+      const unsigned old = __hip_atomic_fetch_add(&t->arrive, 1u, __ATOMIC_ACQ_REL, TB_AGENT);
+      if (old == M - 1) {
+        res = __hip_atomic_exchange(&t->flags, 0u, TB_RLX, TB_AGENT);
+        __hip_atomic_store(&t->result[g & 1], res, TB_RLX, TB_AGENT);
+        __hip_atomic_store(&t->arrive, 0u, TB_RLX, TB_AGENT);
+        __hip_atomic_store(&t->gen, g + 1, __ATOMIC_RELEASE, TB_AGENT);
+      } else {
+        while (__hip_atomic_load(&t->gen, TB_RLX, TB_AGENT) == g) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        res = __hip_atomic_load(&t->result[g & 1], TB_RLX, TB_AGENT);
+      }
+    }
+    sh.team_gen = (int)(g + 1);
+    sh.team_res = (int)res;
+  }
+  __syncthreads();
+  return (unsigned)sh.team_res;
+}
+// Leader -> members: four 64-bit words, written by the leader's thread 0 BEFORE a team_sync and read by anybody after it.
+__device__ __forceinline__ void team_post(const DevProblem& P, const BlockShared& sh, int slot, unsigned long long v) {
+  __hip_atomic_store(&team_ctl(P, sh)->bcast[slot], v, TB_RLX, TB_AGENT);
+}
+__device__ __forceinline__ unsigned long long team_read(const DevProblem& P, const BlockShared& sh, int slot) {
+  return __hip_atomic_load(&team_ctl(P, sh)->bcast[slot], TB_RLX, TB_AGENT);
+}
+// Join the team of the XCD this workgroup runs on (thread 0; kernel start).  Every workgroup of the grid is resident (the plan launches at most one per CU), so
+// waiting for the whole grid to register cannot deadlock; after it the member counts are final.
+__device__ __forceinline__ void team_join(const DevProblem& P, BlockShared& sh) {
+  TeamGrid* G = glob(P.teams);
+  const unsigned xcc = P.team_all ? 0u : ((unsigned)__builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7u);
+  const unsigned m = __hip_atomic_fetch_add(&G->team[xcc].members, 1u, TB_RLX, TB_AGENT);
+  (void)__hip_atomic_fetch_add(&G->registered, 1u, __ATOMIC_RELEASE, TB_AGENT);
+  while (__hip_atomic_load(&G->registered, __ATOMIC_ACQUIRE, TB_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(8);
+  const unsigned M = __hip_atomic_load(&G->team[xcc].members, TB_RLX, TB_AGENT);
+  sh.team = (int)(m | (M << 12) | (xcc << 24));
+  sh.team_gen = 0; sh.team_res = 0;
+}
+
 // Store slab of a workgroup: [ni x int2 {lb,ub}] [Boolean words: 16 variables x 2 bits] [one byte per slice].
 // Variables >= ni are the Boolean ones of the COMPACT layout (root domain within 0..1): bit 2k of their word says
 // "lb raised to 1", bit 2k+1 "ub lowered to 0" -- narrowing is a `ds_or` (monotone like max/min), 3 = empty.
@@ -283,6 +352,7 @@ __device__ __forceinline__ constexpr int g_bl_total() { return 1; }
 //                 few VALU, and a rule computes on absolute values as everywhere else.  trains15: 4939 of its 5011 integers are narrow, the slab goes from
 //                 20.7 KB to 11.6 KB and two-wave workgroups fit eleven to a CU instead of four-wave ones seven.  `ni` of this layout is
 //                 n_int | n_wide << 16 (the wide integers are numbered first, then the narrow ones, then the Booleans).
+//   5  TEAM       the PLAIN layout of a store in global memory shared by the workgroups of an XCD (r05, see "workgroup teams" above): agent-scope loads and atomics.
 constexpr int C8_BASE_BIAS = 16384;
 template <int C> __device__ __forceinline__ int ni_int(int ni) { return C == 4 ? (ni & 0xffff) : ni; }   // integer variables of the slab
 __device__ __forceinline__ int ni_wide(int ni) { return (int)((unsigned)ni >> 16); }                      // COMPACT8: the wide ones
@@ -300,6 +370,13 @@ __device__ __forceinline__ Itv load_int(const int2* store, int v) {  // an integ
   if (C == 3) {
     v = TB_IDX(1, v, slab_vars);
     const long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(hot_or_cold(store + v, v)), TB_RLX, TB_WG);
+    d.lb = (int)(raw & 0xffffffffll);
+    d.ub = (int)(raw >> 32);
+    return d;
+  }
+  if (C == 5) {
+    TB_CHECK_ITV(1, v);
+    const long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + v), TB_RLX, TB_AGENT);  // global_load_dwordx2 sc1: the XCD's L2
     d.lb = (int)(raw & 0xffffffffll);
     d.ub = (int)(raw >> 32);
     return d;
@@ -347,6 +424,7 @@ template <int C>
 __device__ __forceinline__ Itv load_dom(const int2* store, int ni, int v, unsigned* seen = nullptr) {  // (`seen`, COMPACT8: the word that was read)
   if (C == 0) return load_int<0>(store, v);
   if (C == 3) return load_int<3>(store, v);
+  if (C == 5) return load_int<5>(store, v);
   const bool isk = v < 0;
   const int kv = field_value(v);
   if (C == 4) {
@@ -440,6 +518,7 @@ template <int C>
 __device__ __forceinline__ void raise_int_lb(int2* store, int v, int val) {
   if (C == 2) { cas_raise_lb16(reinterpret_cast<unsigned*>(store) + TB_IDX(7, v, store_words), val); return; }
   if (C == 3) v = TB_IDX(7, v, slab_vars); else TB_CHECK_ITV(7, v);
+  if (C == 5) { (void)__hip_atomic_fetch_max(&store[v].x, val, TB_RLX, TB_AGENT); return; }
   if (C == 3) { (void)__hip_atomic_fetch_max(&hot_or_cold(store + v, v)->x, val, TB_RLX, TB_WG); return; }
   (void)__hip_atomic_fetch_max(&store[v].x, val, TB_RLX, TB_WG);
 }
@@ -447,6 +526,7 @@ template <int C>
 __device__ __forceinline__ void lower_int_ub(int2* store, int v, int val) {
   if (C == 2) { cas_lower_ub16(reinterpret_cast<unsigned*>(store) + TB_IDX(7, v, store_words), val); return; }
   if (C == 3) v = TB_IDX(7, v, slab_vars); else TB_CHECK_ITV(7, v);
+  if (C == 5) { (void)__hip_atomic_fetch_min(&store[v].y, val, TB_RLX, TB_AGENT); return; }
   if (C == 3) { (void)__hip_atomic_fetch_min(&hot_or_cold(store + v, v)->y, val, TB_RLX, TB_WG); return; }
   (void)__hip_atomic_fetch_min(&store[v].y, val, TB_RLX, TB_WG);
 }
@@ -469,6 +549,7 @@ __device__ __forceinline__ void lower_ivar_ub(int2* store, int ni, int f, int va
 template <int C>
 __device__ __forceinline__ void raise_lb(int2* store, int ni, int v, int val) {
   if (C == 3) { raise_int_lb<3>(store, v, val); return; }
+  if (C == 5) { raise_int_lb<5>(store, v, val); return; }
   if (C && v < 0) return;  // a constant kept out of the slab (load_dom)
   if (C && var_of<C>(v) >= ni_int<C>(ni)) {
     const int b = var_of<C>(v) - ni_int<C>(ni);
@@ -480,6 +561,7 @@ __device__ __forceinline__ void raise_lb(int2* store, int ni, int v, int val) {
 template <int C>
 __device__ __forceinline__ void lower_ub(int2* store, int ni, int v, int val) {
   if (C == 3) { lower_int_ub<3>(store, v, val); return; }
+  if (C == 5) { lower_int_ub<5>(store, v, val); return; }
   if (C && v < 0) return;
   if (C && var_of<C>(v) >= ni_int<C>(ni)) {
     const int b = var_of<C>(v) - ni_int<C>(ni);
@@ -659,7 +741,9 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     // (the record array is padded to whole slices with idle records, and the prefetch index is clamped to the last
     //  slice instead of being predicated: an unconditional load lets the wait sink to the first use)
     const int last_base = ((n - 1) >> 6) << 6;
-    const int wave_base = __builtin_amdgcn_readfirstlane(tid - lane);  // wave-uniform: slice addressing stays in SGPRs
+    // (layout 5, workgroup teams: member m of M takes the slices m, m + M, ... of every wave's share -- TS is the stride of the whole team)
+    const int TS = C == 5 ? T * team_size(sh) : T;
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid - lane) + (C == 5 ? T * team_member(sh) : 0);  // wave-uniform: slice addressing stays in SGPRs
     // one slice of a plain (AC1) sweep
     auto ac1_step = [&](const int4 pr, const int base) {
       const int i = base + lane;
@@ -706,24 +790,24 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     if (!wac1) {
       int4 pr_next = idle_record();
       if (n > 0) pr_next = props[imin(wave_base, last_base) + lane];
-      for (int base = wave_base; base < n; base += T) {
+      for (int base = wave_base; base < n; base += TS) {
         const int4 pr = pr_next;
-        pr_next = props[imin(base + T, last_base) + lane];
+        pr_next = props[imin(base + TS, last_base) + lane];
         ac1_step(pr, base);
       }
     } else if (!DEEP) {
       int4 pr_next = props[imin(wave_base, last_base) + lane];
-      for (int base = wave_base; base < n; base += T) {
+      for (int base = wave_base; base < n; base += TS) {
         const int4 pr = pr_next;
-        pr_next = props[imin(base + T, last_base) + lane];
+        pr_next = props[imin(base + TS, last_base) + lane];
         wac1_step(pr, base);
       }
     } else {
-      int4 q0 = props[imin(wave_base, last_base) + lane], q1 = props[imin(wave_base + T, last_base) + lane], q2 = props[imin(wave_base + 2 * T, last_base) + lane];  // (n > 0: WAC1 runs above its threshold)
-      for (int base = wave_base; base < n; base += 3 * T) {
-        { const int4 pr = q0; q0 = props[imin(base + 3 * T, last_base) + lane]; wac1_step(pr, base); }
-        if (base + T < n) { const int4 pr = q1; q1 = props[imin(base + 4 * T, last_base) + lane]; wac1_step(pr, base + T); }
-        if (base + 2 * T < n) { const int4 pr = q2; q2 = props[imin(base + 5 * T, last_base) + lane]; wac1_step(pr, base + 2 * T); }
+      int4 q0 = props[imin(wave_base, last_base) + lane], q1 = props[imin(wave_base + TS, last_base) + lane], q2 = props[imin(wave_base + 2 * TS, last_base) + lane];  // (n > 0: WAC1 runs above its threshold)
+      for (int base = wave_base; base < n; base += 3 * TS) {
+        { const int4 pr = q0; q0 = props[imin(base + 3 * TS, last_base) + lane]; wac1_step(pr, base); }
+        if (base + TS < n) { const int4 pr = q1; q1 = props[imin(base + 4 * TS, last_base) + lane]; wac1_step(pr, base + TS); }
+        if (base + 2 * TS < n) { const int4 pr = q2; q2 = props[imin(base + 5 * TS, last_base) + lane]; wac1_step(pr, base + 2 * TS); }
       }
     }
     const bool any_changed = wave_any(changed), any_un = wave_any(un);
@@ -738,11 +822,22 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
       if ((it & 255) == 255 && deadline_passed(P)) st(&sh.abort, 1);
     }
     __syncthreads();
+    if constexpr (C == 5) {
+      // one team barrier per sweep: did ANY member change something / see an un-entailed propagator / fail / run out of time?
+      const unsigned mine = (ld(&sh.flag[k]) ? TEAM_CHANGED : 0u) | (ld(&sh.unent[k]) ? TEAM_UNENT : 0u) | (ld(&sh.bot) ? TEAM_BOT : 0u) | (ld(&sh.abort) ? TEAM_ABORT : 0u);
+      const unsigned all = team_sync(P, sh, mine);
+      if (tid == 0) {
+        st(&sh.flag[k], (all & TEAM_CHANGED) ? 1 : 0); st(&sh.unent[k], (all & TEAM_UNENT) ? 1 : 0);
+        if (all & TEAM_BOT) st(&sh.bot, 1);
+        if (all & TEAM_ABORT) st(&sh.abort, 1);
+      }
+      __syncthreads();
+    }
     ++it;
     if (force_sweeps) { if (it >= force_sweeps) break; else continue; }
     if (!ld(&sh.flag[k]) || dead_node(sh)) break;
   }
-  if (!wac1 && !rm && tid == 0) { add_deductions(sh, (unsigned long long)it * (unsigned long long)n); add_active(sh, (unsigned long long)it * (unsigned long long)n); }  // barebones:934
+  if (!wac1 && !rm && tid == 0 && (C != 5 || team_member(sh) == 0)) { add_deductions(sh, (unsigned long long)it * (unsigned long long)n); add_active(sh, (unsigned long long)it * (unsigned long long)n); }  // barebones:934 (a team: its leader counts)
   if (lane == 0 && wave_evals != 0) { add_deductions(sh, 64ull * wave_evals); add_active(sh, wave_active); }
   all_entailed = !ld(&sh.unent[k]);
   return it;
@@ -1776,14 +1871,30 @@ __device__ __forceinline__ void copy_store_hot(int2* dst, const int2* src, int n
 }
 template <int TB>
 __device__ __forceinline__ void copy_store(int2* dst, const int2* src, int n);
+// Layout 5 (workgroup teams): copies between the team's store and a private slab, rows [lo, hi).  The team store is READ with agent-scope loads (another CU narrowed it: this CU's
+// L1 may hold stale lines) and WRITTEN with agent-scope stores (they land in the XCD's L2, where the members' agent-scope loads find them).
+__device__ __forceinline__ void team_copy_out(int2* dst, const int2* store, int lo, int hi) {
+  for (int i = lo + (int)threadIdx.x; i < hi; i += (int)blockDim.x) {
+    const long long raw = __hip_atomic_load(reinterpret_cast<const long long*>(store + i), TB_RLX, TB_AGENT);
+    dst[i] = make_int2((int)(raw & 0xffffffffll), (int)(raw >> 32));
+  }
+}
+__device__ __forceinline__ void team_copy_in(int2* store, const int2* src, int lo, int hi) {
+  for (int i = lo + (int)threadIdx.x; i < hi; i += (int)blockDim.x) {
+    const int2 d = src[i];
+    __hip_atomic_store(reinterpret_cast<long long*>(store + i), (long long)(((unsigned long long)(unsigned)d.y << 32) | (unsigned long long)(unsigned)d.x), TB_RLX, TB_AGENT);
+  }
+}
 // the working store of layout C written to / filled from a slab in global memory
 template <int C, int TB>
 __device__ __forceinline__ void store_out(int2* dst, const int2* store, int n) {
-  if constexpr (C == 3) copy_store_hot<TB, true, false>(dst, store, n); else copy_store<TB>(dst, store, n);
+  if constexpr (C == 5) team_copy_out(dst, store, 0, n);
+  else if constexpr (C == 3) copy_store_hot<TB, true, false>(dst, store, n); else copy_store<TB>(dst, store, n);
 }
 template <int C, int TB>
 __device__ __forceinline__ void store_in(int2* store, const int2* src, int n) {
-  if constexpr (C == 3) copy_store_hot<TB, false, true>(store, src, n); else copy_store<TB>(store, src, n);
+  if constexpr (C == 5) team_copy_in(store, src, 0, n);
+  else if constexpr (C == 3) copy_store_hot<TB, false, true>(store, src, n); else copy_store<TB>(store, src, n);
 }
 template <int TB = 0>
 __device__ __forceinline__ void copy_store(int2* dst, const int2* src, int n) {
@@ -2211,6 +2322,9 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
                                                     int2* best_store, Mailbox* mbox, ThreadCounters& tc) {
   const int tid = threadIdx.x;
   BlockStats& bs = sh.bs;
+  // layout 5 (workgroup teams): every member runs this function on the same store and reaches the same leaf / solution verdict; what touches the grid words, the host or
+  // the statistics is the LEADER's business, and the leader's stop decision is what every member follows (merged by one team barrier below)
+  const bool lead = C != 5 || team_member(sh) == 0;
   TB_REGION(1);
   // (thread 0's clock at the phase boundary lives in LDS, sh.t_mark: a register pair held through the fixpoint ended up in scratch)
   if (tid == 0) { const long long t0 = wall_clock64(); bs.timers[TB_T_SEARCH] += t0 - sh.t_mark; sh.t_mark = t0; }
@@ -2291,7 +2405,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
         if (sh.best_bound > obj && (!P.use_fixed_bound || obj <= P.fixed_bound)) {  // barebones:994
           sh.best_bound = obj;
           sol = 1;
-          if (!P.use_fixed_bound) {
+          if (!P.use_fixed_bound && lead) {
             const int old = __hip_atomic_fetch_min(&glob(P.ctrl)->best_bound, obj, TB_RLX, TB_AGENT);  // appx_best_bound.meet
             if (obj < old) {
               publish_bound(P, mbox, obj);
@@ -2304,7 +2418,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
         // only the leftmost one reports the solution, so that `-a` / `-n k` enumerate each solution leaf once.
         sol = (sh.remaining > 0 && (sh.sub_idx & ((1ull << sh.remaining) - 1ull)) != 0ull) ? 0 : 1;
       }
-      if (sol) {
+      if (sol && lead) {
         bs.solutions++;
         bs.best_sub = (long long)sh.sub_idx;
         bs.best_time = t1 - sh.t_start;
@@ -2326,6 +2440,7 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
     sh.ticket = stream ? (long long)__hip_atomic_fetch_add(&glob(P.ctrl)->sol_ticket, 1ull, TB_RLX, TB_AGENT) : -1ll;
     sh.leaf = leaf;
     sh.sol = sol;
+    if (lead) {
     bs.fixpoint_iterations += (unsigned long long)iters;
     bs.nodes++;
     bs.fails += failed ? 1 : 0;
@@ -2347,17 +2462,26 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
     if (P.use_fixed_bound && __hip_atomic_load(&glob(P.ctrl)->first_sol_idx, TB_RLX, TB_AGENT) < sh.sub_idx) { sh.stop = 1; }
     if (aborted) { must_stop = true; (void)__hip_atomic_fetch_or(&glob(P.ctrl)->stop, STOP_HOST, TB_RLX, TB_AGENT); }
     if (must_stop) { bs.exhaustive = 0; sh.stop = 1; bs.why |= 4 | (aborted ? 8 : 0) | ((P.cut_nodes != 0 && bs.nodes >= P.cut_nodes) ? 16 : 0); }
+    }  // lead
+  }
+  if constexpr (C == 5) {
+    // the leader's verdict on stopping is everybody's (a member that ran out of time counts too); also the point after which nobody reads this node's store any more
+    const unsigned all = team_sync(P, sh, ((lead && sh.stop) || ld(&sh.abort)) ? TEAM_STOP : 0u);
+    if (tid == 0 && (all & TEAM_STOP)) sh.stop = 1;
   }
   __syncthreads();
   TB_REGION(26);
-  if (sh.sol) {  // uniform
+  if (sh.sol) {  // uniform (and the same on every member of a team)
     TB_REGION(27);
+    if (lead) {
     // (the workgroup's slab of g_best is located here, where a solution is kept: not a pointer that lives through every round of every node)
     if (best_store == nullptr) best_store = glob(P.g_best) + (size_t)here_s(blockIdx.x) * P.vext;
     for (int rep = reps_of(P, 8); rep > 1; --rep) store_out<C, TB>(best_store, store, P.vext);
     store_out<C, TB>(best_store, store, P.vext);
     __syncthreads();
     if (sh.ticket >= 0) produce_solution<TB, C>(P, sh, store, mbox);
+    }
+    if constexpr (C == 5) (void)team_sync(P, sh, 0u);  // the store stays as it is until the leader has copied it
   }
   TB_REGION(48);
 }
@@ -2485,7 +2609,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_
     bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
     sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0; sh.open_vars = 0;
     sh.n_dec_seg = 0;
-    sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; sh.witness = -1;
+    sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.team_res = 0; sh.witness = -1;
     sh.t_start = sh.t_mark = wall_clock64();
     sh.has_work = next_subproblem(P, sh, mbox) ? 1 : 0;
   }
@@ -2665,6 +2789,191 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_
   }
 }
 
+// ---- the persistent search kernel of workgroup teams (store layout 5, r05) ---------------------------------------------------------------------
+// One subproblem per TEAM (the workgroups of one XCD) at a time, on one store in global memory -- see "workgroup teams" above.  Same dive-and-solve loop as
+// solve_kernel (barebones:656-886): the sweeps are partitioned over the members, the control is replicated, the leader talks to the queue, the grid words
+// and the host.  Sweeping fixpoints only (AC1 / WAC1), 1024 threads, the PLAIN layout.
+// Between "the last read of this node's store" and "the first write for the next node" stands a team barrier: a member that is still selecting a variable must
+// not see the decision a faster member has already applied.
+__global__ void __launch_bounds__(1024, 1) solve_kernel_team(DevProblem P, Mailbox* mbox) {
+  __builtin_amdgcn_s_dcache_inv();
+  constexpr int C = 5;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  BlockShared& sh = *reinterpret_cast<BlockShared*>(smem);
+  const int tid = threadIdx.x, b = blockIdx.x, VX = P.vext;
+  EventState es{};  // (unused by the sweeps)
+  BlockStats& bs = sh.bs;
+  ThreadCounters tc;
+  if (tid == 0) {
+    for (int i = 0; i < TB_NUM_TIMERS; ++i) bs.timers[i] = 0;
+    bs.nodes = bs.fails = bs.solutions = bs.fixpoint_iterations = bs.num_deductions = 0;
+    bs.eps_solved = bs.eps_skipped = bs.store_writes = bs.stolen = bs.active_evals = 0;
+    bs.wait_ticks = 0;
+    bs.why = 0; bs.pad_why = 0;
+    for (int i = 0; i < TB_DBG_WORDS; ++i) bs.dbg[i] = 0;
+#ifdef TB_TUNING
+    for (int i = 0; i < 72; ++i) bs.reg[i] = 0;
+    for (int i = 0; i < TB_NUM_PROF; ++i) bs.prof[i] = 0;
+#endif
+    bs.depth_max = 0; bs.exhaustive = 1; bs.num_blocks_done = 0; bs.best_bound = PINF; bs.best_sub = -1; bs.best_time = 0;
+    sh.stop = 0; sh.bot = 0; sh.leaf = 0; sh.depth = 0; sh.best_bound = PINF; sh.sol = 0; sh.found = 0; sh.skip = 0; sh.open_vars = 0;
+    sh.n_dec_seg = 0; sh.has_work = 0; sh.remaining = 0; sh.sub_idx = 0;
+    sh.abort = 0; sh.new_depth = 0; sh.ev_all = 0; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.witness = -1;
+    sh.t_start = sh.t_mark = wall_clock64(); sh.t_dive = 0; sh.last_obj_ub = PINF;
+    team_join(P, sh);
+  }
+  __syncthreads();
+  const int M = team_size(sh), m = team_member(sh), xcd = team_xcd(sh);
+  const bool lead = m == 0;
+  // the team's store and snapshot stack: the slabs of "workgroup" xcd (every workgroup has slabs; a team uses one set); the leader's best store is its own slab
+  int2* const store = glob(P.g_store) + (size_t)xcd * VX;
+  int2* const snap = glob(P.g_snap) + (size_t)xcd * P.snapshot_levels * VX;
+  Decision* const dec = glob(P.g_dec) + (size_t)b * P.max_depth;  // (a copy of the decision stack per member: the control is replicated)
+  const int4* const props = P.props;
+  // rows of a block copy that are this member's (even boundaries: 16-byte granules stay whole)
+  const int chunk = (((VX + M - 1) / M) + 1) & ~1;
+  const int row_lo = m * chunk < VX ? m * chunk : VX, row_hi = (m + 1) * chunk < VX ? (m + 1) * chunk : VX;
+
+  // leader: fetch a subproblem; everybody: learn which (uniform call)
+  auto fetch = [&]() {
+    if (tid == 0 && lead) {
+      const bool got = !sh.stop && next_subproblem(P, sh, mbox);
+      team_post(P, sh, 0, sh.sub_idx);
+      team_post(P, sh, 1, got ? 1ull : 0ull);
+    }
+    (void)team_sync(P, sh, 0u);
+    if (tid == 0) { sh.sub_idx = team_read(P, sh, 0); sh.has_work = (int)team_read(P, sh, 1); }
+    (void)team_sync(P, sh, 0u);  // (the slots may be written again after this)
+  };
+  fetch();
+
+  while (sh.has_work && !sh.stop) {
+    // C. restore the root, striped over the members
+    team_copy_in(store, glob(P.root_store), row_lo, row_hi);
+    if (tid == 0) {
+      sh.cur_strategy = 0; sh.next_unassigned = 0; sh.depth = 0; sh.bot = 0;
+      sh.remaining = P.subproblems_power; sh.leaf = 0;
+      sh.last_obj_ub = PINF;
+      sh.t_dive = wall_clock64();
+      if (P.subproblems_power == 0) end_of_dive(P, sh);
+    }
+    (void)team_sync(P, sh, 0u);
+    bool exhausted = false;
+    while (!sh.stop) {
+      const bool diving = sh.remaining > 0;
+      if (!diving && P.obj_var >= 0) {
+        // I. the objective bound: read from the grid words by the leader, imposed by everybody (barebones:756-771)
+        if (tid == 0 && lead) {
+          int g = PINF;
+          if (P.use_fixed_bound) g = P.fixed_bound == PINF ? PINF : P.fixed_bound + 1;  // (the members subtract one)
+          else {
+            const unsigned long long bf = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&glob(P.ctrl)->best_bound), TB_RLX, TB_AGENT);
+            g = (int)(bf & 0xffffffffull);
+            const int f = (int)(bf >> 32);
+            g = f < g ? f : g;
+            g = sh.best_bound < g ? sh.best_bound : g;
+            if (g == NINF) raise_gpu_stop(P);  // unbounded objective
+          }
+          team_post(P, sh, 2, (unsigned long long)(unsigned)g);
+        }
+        (void)team_sync(P, sh, 0u);
+        if (tid == 0) {
+          const int g = (int)(unsigned)team_read(P, sh, 2);
+          if (g == NINF) sh.stop = 1;
+          else if (g != PINF) { sh.last_obj_ub = g - 1; (void)embed0<C>(store, P.n_int, &sh.bot, P.obj_var, NINF, g - 1); }
+        }
+        (void)team_sync(P, sh, 0u);
+        if (sh.stop) break;
+      }
+      // II. propagate (the sweeps are partitioned, the verdict is everybody's; ends with the team's agreement on stopping)
+      propagate_node_impl<false, C, false, TB_MEM_GLOBAL, 0, true>(P, sh, store, props, es, nullptr, mbox, tc);
+      if (sh.stop) break;
+      // III. branch
+      if (!sh.leaf) {
+        const int d0 = sh.depth;
+        if (!diving) {
+          if (d0 < P.snapshot_levels) team_copy_out(snap + (size_t)d0 * VX, store, row_lo, row_hi);
+          if (tid == 0 && d0 == 0) { sh.snap_strategy = sh.cur_strategy; sh.snap_next_unassigned = sh.next_unassigned; }
+        }
+        split<C>(P, sh, dec, store);
+        {  // nobody reads this node's store after this barrier; a member whose decision stack could not grow stops everybody
+          const unsigned all = team_sync(P, sh, sh.stop ? TEAM_STOP : 0u);
+          if (tid == 0 && (all & TEAM_STOP)) sh.stop = 1;
+          __syncthreads();
+        }
+        if (sh.stop) break;
+        if (tid == 0) {
+          if (!sh.found) { sh.leaf = 1; if (lead) { bs.exhaustive = 0; bs.why |= diving ? 1 : 2; } }
+          else if (diving) {
+            --sh.remaining;
+            --sh.depth;
+            const int bit = (int)((sh.sub_idx >> sh.remaining) & 1ull);
+            (void)embed0<C>(store, P.n_int, &sh.bot, dec[0].var, dec[0].child[bit].x, dec[0].child[bit].y);
+            if (sh.remaining == 0) end_of_dive(P, sh);
+          } else {
+            Decision& dd = dec_at(P, sh, dec, sh.depth - 1);
+            const int c = ++dd.cur;
+            (void)embed0<C>(store, P.n_int, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      if (sh.leaf) {
+        if (diving) { if (tid == 0 && lead) skip_subtree(P, sh); break; }
+        // IV. backtrack (barebones:812-863): rope jump, restore the deepest snapshot (striped), replay, right child
+        const int dcur = sh.depth;
+        if (dcur == 0) { exhausted = true; break; }
+        if (tid == 0) { const Decision& dl = dec_at(P, sh, dec, dcur - 1); sh.new_depth = dl.rope[dl.cur]; }
+        __syncthreads();
+        const int depth = sh.new_depth;
+        if (depth == -1) { exhausted = true; break; }
+        const int lvl = (depth - 1) < (P.snapshot_levels - 1) ? (depth - 1) : (P.snapshot_levels - 1);
+        team_copy_in(store, snap + (size_t)lvl * VX, row_lo, row_hi);
+        if (tid == 0) { sh.bot = 0; sh.depth = depth; }
+        (void)team_sync(P, sh, 0u);  // the whole store is the snapshot before anybody narrows it again
+        for (int i = lvl + tid; i < depth - 1; i += (int)blockDim.x) {
+          const Decision& di = dec_at(P, sh, dec, i);
+          const int2 ch = di.child[di.cur];
+          raise_lb<C>(store, P.n_int, di.var, ch.x);
+          lower_ub<C>(store, P.n_int, di.var, ch.y);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          Decision& dd = dec_at(P, sh, dec, depth - 1);
+          const int c = ++dd.cur;
+          (void)embed0<C>(store, P.n_int, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+          sh.cur_strategy = sh.snap_strategy;
+          sh.next_unassigned = sh.snap_next_unassigned;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+    if (tid == 0) {
+      if (sh.t_dive != 0) end_of_dive_timer(sh);
+      if (exhausted && !sh.stop && lead) bs.eps_solved += 1;
+    }
+    fetch();
+  }
+  __syncthreads();
+  if (P.g_last != nullptr && lead) store_out<C, 0>(glob(P.g_last) + (size_t)b * VX, store, VX);  // test aid: the store the team stopped on (the leader's slot)
+  (void)team_sync(P, sh, 0u);
+  flush_writes(sh, tc, true);
+  __syncthreads();
+  if (tid == 0) {
+    bs.best_bound = lead ? sh.best_bound : PINF;
+    const int stopped = __hip_atomic_load(&glob(P.ctrl)->stop, TB_RLX, TB_AGENT) & STOP_HOST;
+    if (!(P.cut_nodes != 0 && bs.nodes >= P.cut_nodes) && !stopped) bs.num_blocks_done = 1;
+    const long long t_end = wall_clock64();
+    bs.timers[TB_T_FIRST_BLOCK_IDLE] = t_end - sh.t_start;
+    bs.timers[TB_T_OVERALL] = t_end - sh.t_start;
+    bs.timers[TB_T_LATEST_BEST_OBJ_FOUND] = bs.best_time;
+    glob(P.g_stats)[b] = bs;
+    __hip_atomic_fetch_add(&glob(P.ctrl)->blocks_done, 1, TB_RLX, TB_AGENT);
+  }
+}
+
 __global__ void clock_kernel(long long* out) { *out = wall_clock64(); }
 
 // ---- batch propagation kernel: one store per workgroup (tb_propagate) ----------------------------
@@ -2718,7 +3027,7 @@ __global__ void __launch_bounds__(TMAX, 4) propagate_kernel(DevProblem P, int2* 
     __syncthreads();
     bool all_entailed = false;
     int iters = 0;
-    if (EVENT) { if (tid == 0) { sh.ev_all = 1; sh.chg_count[0] = 0; sh.chg_count[1] = 0; sh.ev_busy = 0; } __syncthreads(); }
+    if (EVENT) { if (tid == 0) { sh.ev_all = 1; sh.chg_count[0] = 0; sh.chg_count[1] = 0; } __syncthreads(); }
     if (!ld(&sh.bot)) {
       if constexpr (EVENT) iters = fixpoint_event<C>(P, sh, store, props, es, tc, all_entailed);
       else iters = fixpoint<RM, C, (TMAX == 1024)>(P, sh, store, props, es.unent, tc, all_entailed);
