@@ -198,10 +198,13 @@ def attach_counters(roof: dict, workload: str, fixpoint: str, launch_s: float) -
 # (scripts/r05_solve_probe.py).  The proof run is a satisfaction search under the CONSTANT constraint objective <= B (tb_config.use_fixed_bound:
 # no incumbent is exchanged, the tree does not depend on timing): with B below the optimum every subproblem is refuted -- a fixed amount of work whatever the number of
 # GPUs, which is what a strong-scaling curve needs.  -1: the reference's 2^d rule.
+# Calibration (gpurun_out/r05_solve_ladder.log, one MI355X): wordpress7_500 -- `objective <= 500` is refuted in 0.86 s (4.7e7 nodes, 2^21 subproblems: 2 060 486 solved +
+# 36 666 skipped), <= 1000 is not within 17 s; branch and bound reaches 14 000 after 9 s (4.9e8 nodes).  trains15 -- <= 0 is refuted in 0.54 s (every one of the 2^20 subproblems dies
+# in its dive: queue and dive throughput), <= 10 leaves a dozen hard subproblems after 17 s; 75 is reached after 0.9 s.  accap_a3 at 2^16 -- <= 55 is refuted in 1.2 s, 135 reached in 0.06 s.
 SOLVE_DEFAULTS = {
-    "wordpress7_500": (8000, 16000, -1),
-    "accap_a3": (None, None, 12),
-    "trains15": (100, 130, -1),
+    "wordpress7_500": (500, 14000, -1),
+    "accap_a3": (55, 135, 16),
+    "trains15": (0, 75, -1),
     "synthetic": (None, None, -1),
 }
 

@@ -5,19 +5,23 @@ root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp && cd $root
 out=gpurun_out/team_ab; rm -rf $out; mkdir -p $out
 args="--workload synthetic --steps 2 --warmup 1 --side-steps 0 --other-steps 0 --reference-seconds 0 --no-cpu-baseline"
-for fp in wac1 ac1; do
-  for mode in 0 1 0 1; do
-    TB_TEAM=$mode timeout 300 python3 bench.py $args --fixpoint $fp > $out/rate_${fp}_$mode.log 2>$out/rate_${fp}_$mode.err
+# configurations: TB_TEAM TB_TEAM_SPLIT TB_TEAM_RELAXED (default of this script: the hot tier, then teams of an XCD, relaxed barrier, two and four teams per XCD)
+for fp in ${TEAM_FPS:-wac1}; do
+  for cfg in ${TEAM_CFGS:-"0:1:0 1:1:0 1:1:1 1:2:1 1:4:1 0:1:0 1:1:1 1:2:1 1:4:1"}; do
+    IFS=: read t sp rl <<< "$cfg"
+    TB_TEAM=$t TB_TEAM_SPLIT=$sp TB_TEAM_RELAXED=$rl timeout 300 python3 bench.py $args --fixpoint $fp > $out/rate_${fp}_$cfg.log 2>$out/rate_${fp}_$cfg.err
     python3 - <<PY
 import json
 try:
-    d=[json.loads(l) for l in open("$out/rate_${fp}_$mode.log") if l.startswith("{")][-1]
-    print("TB_TEAM=$mode $fp: %.3e propagations/s  %.3e nodes/s  %s" % (d["value"], d["nodes_per_sec"], d["config"]["workload"][-120:]))
+    d=[json.loads(l) for l in open("$out/rate_${fp}_$cfg.log") if l.startswith("{")][-1]
+    print("team=$t split=$sp relaxed=$rl $fp: %.3e propagations/s  %.3e nodes/s" % (d["value"], d["nodes_per_sec"]))
 except Exception as e:
-    print("TB_TEAM=$mode $fp: failed", e, open("$out/rate_${fp}_$mode.err").read()[-400:])
+    print("team=$t split=$sp relaxed=$rl $fp: failed", e, open("$out/rate_${fp}_$cfg.err").read()[-400:])
 PY
   done
 done
+[ -n "$TEAM_NO_PMC" ] && exit 0
+export TB_TEAM_SPLIT=${TEAM_PMC_SPLIT:-1} TB_TEAM_RELAXED=${TEAM_PMC_RELAXED:-0}
 pass() { d=$1; shift; c=""; while [ "$1" != "--" ]; do c="$c $1"; shift; done; shift
   TB_TEAM=1 timeout 420 rocprofv3 --pmc $c -d $out/$d -o p -- python3 bench.py "$@" > $out/$d.log 2>&1 || echo "pass $d: rc=$?"; }
 pass tcc TCC_HIT_sum TCC_MISS_sum -- $args --fixpoint wac1

@@ -362,6 +362,31 @@ def test_bench_two_ranks_complete_subproblems_and_steal_inside_a_step():
     assert all(r["nodes"] > 0 and r["eps_solved"] > 0 for r in m["per_rank"])
 
 
+def test_bench_solve_mode_two_ranks_prove_a_fixed_bound_and_reach_a_target():
+    """`bench.py --mode solve` (r05): whole searches instead of node budgets, two ranks on cuda:0 over gloo.  The proof run (`objective <= B`, a constant constraint: no incumbent
+    travels) must refute B with every subproblem solved or skipped exactly once across the ranks; the time-to-target run must stop both ranks once the GROUP's incumbent is at or
+    under the target -- agreed over the gloo side group, which never queues a GPU kernel behind the persistent search kernel."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--dist-backend", "gloo", "--mode", "solve", "--workload", "accap_a3",
+           "--or-nodes", "256", "--subproblems-power", "12", "--fixed-bound", "40", "--target", "140", "--solve-timeout", "60"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["mode"] == "solve" and rec["n_gpus"] == 2 and rec["higher_is_better"] is False
+    proof, tt = rec["proof"], rec["to_target"]
+    assert proof["exhaustive"] == 1 and proof["has_solution"] == 0 and proof["every_subproblem_accounted_once"], proof
+    assert proof["eps_solved"] + proof["eps_skipped"] == 4096 and len(proof["per_rank"]) == 2 and all(r["nodes"] > 0 for r in proof["per_rank"])
+    assert tt["has_solution"] == 1 and tt["best_objective_bound"] <= 140 and tt["seconds"] < 60, tt
+    # the same on one rank
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "solve", "--workload", "accap_a3", "--or-nodes", "256", "--subproblems-power", "12",
+                         "--fixed-bound", "40", "--target", "140", "--solve-timeout", "60"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    r1 = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][-1])
+    assert r1["proof"]["exhaustive"] == 1 and r1["proof"]["every_subproblem_accounted_once"] and r1["to_target"]["time_to_target_s"] is not None
+    # (the tree under a constant bound does not depend on who walks it -- up to the dives into subtrees another workgroup is skipping at that moment)
+    assert abs(r1["proof"]["nodes"] - proof["nodes"]) <= 0.1 * proof["nodes"]
+
+
 def test_bench_refuses_to_report_fewer_gpus_than_asked():
     """Two ranks on a one-GPU box without --share-device: rank 1 has no device, the run fails -- it never prints n_gpus != --gpus."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}

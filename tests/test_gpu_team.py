@@ -83,6 +83,24 @@ def test_teams_of_the_real_xcds_prove_the_known_optima(team_env, rel, expected, 
     assert st["eps_solved_subproblems"] + st["eps_skipped_subproblems"] == 1 << st["subproblems_power"], "every subproblem exactly once"
 
 
+@pytest.mark.parametrize("split,relaxed", [(1, 1), (2, 0), (2, 1), (4, 1)], ids=["relaxed", "two_per_xcd", "two_per_xcd_relaxed", "four_per_xcd_relaxed"])
+@pytest.mark.parametrize("rel,expected", [r for r in FAST if r[0].split("/")[-1] in ("pat2.fzn", "pat7.fzn", "pennies5.fzn", "sudoku_opt4.fzn", "bug4.fzn", "pat11.fzn")])
+def test_teams_per_xcd_and_barrier_flavours(team_env, rel, expected, split, relaxed):
+    """TB_TEAM_SPLIT: two / four teams per XCD (the workgroups of an XCD dealt to them in turn); TB_TEAM_RELAXED: the barrier with relaxed agent-scope atomics and an explicit
+    wait for the wave's own memory operations instead of acq_rel fences.  Same optima, every subproblem exactly once; and one of each walks the oracle's tree as ONE team."""
+    team_env.setenv("TB_TEAM_SPLIT", str(split))
+    team_env.setenv("TB_TEAM_RELAXED", str(relaxed))
+    tcn = frontend.load_fzn(os.path.join(BENCH, rel))
+    has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=120000, fixpoint=1, **TEAM))
+    assert has and st["exhaustive"] == 1 and tcn.objective_of(best) == expected
+    assert st["eps_solved_subproblems"] + st["eps_skipped_subproblems"] == 1 << st["subproblems_power"]
+    team_env.setenv("TB_TEAM_ALL", "1")
+    has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=3, cutnodes=2000)
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=24, subproblems_power=3, stop_after_n_nodes=2000, timeout_ms=120000, fixpoint=1, **TEAM))
+    for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
+        assert st_g[k] == st_o[k], k
+
+
 def test_teams_enumerate_every_solution_once(team_env):
     from test_gpu_streaming import MANY, run_streaming
     tcn = frontend.Model.from_string(MANY).tcn()

@@ -114,9 +114,10 @@ struct alignas(64) TeamCtl {
   unsigned long long bcast[4];  // leader -> members (subproblem, bound), read between two barriers
 };
 struct alignas(64) TeamGrid {
-  unsigned registered;  // workgroups of the grid that have joined a team
-  unsigned pad[15];
-  TeamCtl team[8];      // indexed by HW_REG_XCC_ID
+  unsigned registered;      // workgroups of the grid that have joined a team
+  unsigned xcd_members[8];  // workgroups registered per XCD (HW_REG_XCC_ID)
+  unsigned pad[7];
+  TeamCtl team[32];         // XCD x * split + k: up to four teams per XCD (DevProblem::team_split)
 };
 
 // Solution ring in pinned host memory (streaming, gpu_dive_and_solve.hpp:100-132 re-done without a print lock):
@@ -221,7 +222,9 @@ struct DevProblem {
   BlockStats* g_stats;
   Ctrl* ctrl;
   TeamGrid* teams;           // store layout 5: the per-XCD team control blocks (nullptr otherwise)
-  int team_all, pad_team;    // store layout 5, test aid (TB_TEAM_ALL=1): the whole grid is ONE team whatever the XCDs (agent-scope accesses are coherent device-wide: slower, same results)
+  int team_all, team_split;  // store layout 5.  team_all, test aid (TB_TEAM_ALL=1): the whole grid is ONE team whatever the XCDs (agent-scope accesses are coherent device-wide: slower,
+                             // same results); team_split (TB_TEAM_SPLIT, 1 / 2 / 4): teams per XCD -- more independent searches, fewer members per barrier, k stores in the XCD's L2
+  int team_relaxed, pad_team; // team barrier with relaxed agent-scope atomics and an explicit wait for the wave's own memory operations instead of acq_rel fences (TB_TEAM_RELAXED=1)
   PeerCell* cell;            // this device's cell
   PeerCell* const* peers;    // [world] cells of every rank (peers[rank] == cell; nullptr = not reachable), device array
   SolutionRing ring;

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <iterator>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -838,8 +839,19 @@ std::vector<int2> slice_infos(const std::vector<int4>& packed, const std::vector
       mul_nn = ((r.x >> 12) & 7) == TB_MUL && d[0].lb >= 0 && d[1].lb >= 0 && d[2].lb >= 0 && d[0].ub <= (1 << 30) && d[1].ub <= (1 << 30) && d[2].ub <= (1 << 30) &&
                (long long)d[1].ub * (long long)d[2].ub <= (1ll << 30);
     }
+    // 0x1000 (r05): a lean implication slice in which no variable is the y of one record and the z of another: a narrowing pass enables no other lane, the run needs no
+    // confirmation pass (kernels.hpp: lean implication run)
+    bool single = is_lean && n_real > 0 && !std::getenv("TB_NO_SINGLE_IMPL");
+    if (single) {
+      std::vector<int> ys, zs;
+      for (int l = 0; l < n_real; ++l) { ys.push_back(packed[(size_t)s * 64 + (size_t)l].z); zs.push_back(packed[(size_t)s * 64 + (size_t)l].w); }
+      std::sort(ys.begin(), ys.end()); std::sort(zs.begin(), zs.end());
+      std::vector<int> both;
+      std::set_intersection(ys.begin(), ys.end(), zs.begin(), zs.end(), std::back_inserter(both));
+      single = both.empty();
+    }
     const bool chain_ok = (size_t)s < chains.slice_ok.size() && chains.slice_ok[(size_t)s];
-    info[(size_t)s] = make_int2(w0, n_real | (is_lean ? 0x100 : 0) | (finite ? 0x200 : 0) | (chain_ok ? 0x400 : 0) | (mul_nn ? 0x800 : 0));
+    info[(size_t)s] = make_int2(w0, n_real | (is_lean ? 0x100 : 0) | (finite ? 0x200 : 0) | (chain_ok ? 0x400 : 0) | (mul_nn ? 0x800 : 0) | (single ? 0x1000 : 0));
   }
   return info;
 }
@@ -1560,6 +1572,8 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   P.leaf_assign = s->cfg.leaf_requires_assignment ? 1 : 0;
   P.teams = nullptr;
   P.team_all = (std::getenv("TB_TEAM_ALL") != nullptr && std::getenv("TB_TEAM_ALL")[0] == '1') ? 1 : 0;
+  { const char* e = std::getenv("TB_TEAM_SPLIT"); const int k = e ? std::atoi(e) : 1; P.team_split = (k == 2 || k == 4) ? k : 1; }
+  P.team_relaxed = (std::getenv("TB_TEAM_RELAXED") != nullptr && std::getenv("TB_TEAM_RELAXED")[0] == '1') ? 1 : 0;
   if (plan.team && (rc = s->bufs.alloc(&P.teams, 1)) != TB_OK) return rc;
   // the cell other GPUs reach over xGMI: fine-grained device memory (coherent at system scope while kernels run)
   {

@@ -273,7 +273,7 @@ __device__ __forceinline__ constexpr int g_bl_total() { return 1; }
 constexpr unsigned TEAM_CHANGED = 1u, TEAM_UNENT = 2u, TEAM_BOT = 4u, TEAM_ABORT = 8u, TEAM_STOP = 16u, TEAM_WORK = 32u;
 __device__ __forceinline__ int team_member(const BlockShared& sh) { return sh.team & 0xfff; }
 __device__ __forceinline__ int team_size(const BlockShared& sh) { return (sh.team >> 12) & 0xfff; }
-__device__ __forceinline__ int team_xcd(const BlockShared& sh) { return (sh.team >> 24) & 0xf; }
+__device__ __forceinline__ int team_xcd(const BlockShared& sh) { return (sh.team >> 24) & 0x3f; }  // the team's slot: XCD x split + k
 __device__ __forceinline__ TeamCtl* team_ctl(const DevProblem& P, const BlockShared& sh) { return &glob(P.teams)->team[team_xcd(sh)]; }
 
 // Team barrier (uniform call, every thread of every member): returns the OR of the members' `contrib` (thread 0's value counts).
@@ -290,16 +290,24 @@ __device__ __forceinline__ unsigned team_sync(const DevProblem& P, BlockShared& 
     unsigned res = contrib;
     if (M > 1) {
       if (contrib) (void)__hip_atomic_fetch_or(&t->flags, contrib, TB_RLX, TB_AGENT);
-      const unsigned old = __hip_atomic_fetch_add(&t->arrive, 1u, __ATOMIC_ACQ_REL, TB_AGENT);
+      // (relaxed form: the store is only ever touched with agent-scope atomics and loads, which no cache holds dirty or stale -- every wave has waited for its own above)
+      const unsigned old = P.team_relaxed ? __hip_atomic_fetch_add(&t->arrive, 1u, TB_RLX, TB_AGENT) : __hip_atomic_fetch_add(&t->arrive, 1u, __ATOMIC_ACQ_REL, TB_AGENT);
       if (old == M - 1) {
         res = __hip_atomic_exchange(&t->flags, 0u, TB_RLX, TB_AGENT);
         __hip_atomic_store(&t->result[g & 1], res, TB_RLX, TB_AGENT);
         __hip_atomic_store(&t->arrive, 0u, TB_RLX, TB_AGENT);
-        __hip_atomic_store(&t->gen, g + 1, __ATOMIC_RELEASE, TB_AGENT);
+        if (P.team_relaxed) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __hip_atomic_store(&t->gen, g + 1, TB_RLX, TB_AGENT); }
+        else __hip_atomic_store(&t->gen, g + 1, __ATOMIC_RELEASE, TB_AGENT);
       } else {
-        while (__hip_atomic_load(&t->gen, TB_RLX, TB_AGENT) == g) __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        res = __hip_atomic_load(&t->result[g & 1], TB_RLX, TB_AGENT);
+        bool lost = false;
+        for (unsigned spins = 1; __hip_atomic_load(&t->gen, TB_RLX, TB_AGENT) == g; ++spins) {
+          __builtin_amdgcn_s_sleep(2);
+          // (a team that has fallen apart -- a member that never arrives -- must not outlive the search's deadline: everybody left gives up, as after a watchdog abort)
+          if ((spins & 4095u) == 0u && deadline_passed(P)) { lost = true; break; }
+        }
+        if (!P.team_relaxed) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        res = lost ? (contrib | TEAM_STOP | TEAM_ABORT) : __hip_atomic_load(&t->result[g & 1], TB_RLX, TB_AGENT);
+        if (lost) { sh.abort = 1; sh.stop = 1; }
       }
     }
     sh.team_gen = (int)(g + 1);
@@ -320,11 +328,16 @@ __device__ __forceinline__ unsigned long long team_read(const DevProblem& P, con
 __device__ __forceinline__ void team_join(const DevProblem& P, BlockShared& sh) {
   TeamGrid* G = glob(P.teams);
   const unsigned xcc = P.team_all ? 0u : ((unsigned)__builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7u);
-  const unsigned m = __hip_atomic_fetch_add(&G->team[xcc].members, 1u, TB_RLX, TB_AGENT);
+  const unsigned split = P.team_all ? 1u : (unsigned)(P.team_split > 1 ? P.team_split : 1);
+  const unsigned mx = __hip_atomic_fetch_add(&G->xcd_members[xcc], 1u, TB_RLX, TB_AGENT);  // my arrival on this XCD: dealt to its teams in turn
   (void)__hip_atomic_fetch_add(&G->registered, 1u, __ATOMIC_RELEASE, TB_AGENT);
-  while (__hip_atomic_load(&G->registered, __ATOMIC_ACQUIRE, TB_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(8);
-  const unsigned M = __hip_atomic_load(&G->team[xcc].members, TB_RLX, TB_AGENT);
-  sh.team = (int)(m | (M << 12) | (xcc << 24));
+  for (unsigned spins = 1; __hip_atomic_load(&G->registered, __ATOMIC_ACQUIRE, TB_AGENT) < gridDim.x; ++spins) {
+    __builtin_amdgcn_s_sleep(8);
+    if ((spins & 4095u) == 0u && deadline_passed(P)) { sh.abort = 1; sh.stop = 1; break; }  // (a grid that is not fully resident: give up at the deadline instead of hanging)
+  }
+  const unsigned Mx = __hip_atomic_load(&G->xcd_members[xcc], TB_RLX, TB_AGENT);
+  const unsigned k = mx % split, m = mx / split, M = Mx / split + (k < Mx % split ? 1u : 0u);
+  sh.team = (int)(m | (M << 12) | ((xcc * split + k) << 24));
   sh.team_gen = 0; sh.team_res = 0;
 }
 
@@ -946,7 +959,7 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
     nar_all |= nar;  // (a cooperative body reaches the slice's fixpoint in one pass: it narrows, reports nar and no change)
     if (!wave_any(ch)) {
       // The byte only ever goes 1 -> 0 below a node (entailment is monotone).
-      if (!wave_any(un_i) && lane == 0) (void)__hip_atomic_fetch_and(&E.unent[s >> 5], ~(1u << (s & 31)), TB_RLX, TB_WG);
+      if (!wave_any(un_i) && lane == 0) { const int sq = here_s(s); (void)__hip_atomic_fetch_and(&E.unent[sq >> 5], ~(1u << (sq & 31)), TB_RLX, TB_WG); }  // (mask and word formed here: hoisted, they were spilled around every run)
       break;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1171,7 +1184,7 @@ __device__ __forceinline__ unsigned lean_class_run_t(const RunEnv& E, const int 
     const bool moved = act && (cxl | cxu | cyl | cyu | czl | czu);
     if (!wave_any(moved)) {
       // quiet pass: the local fixpoint is reached; the slice's "not entailed" bit only ever goes 1 -> 0 below a node
-      if (!wave_any(act && !ent) && lane == 0) (void)__hip_atomic_fetch_and(&E.unent[s >> 5], ~(1u << (s & 31)), TB_RLX, TB_WG);
+      if (!wave_any(act && !ent) && lane == 0) { const int sq = here_s(s); (void)__hip_atomic_fetch_and(&E.unent[sq >> 5], ~(1u << (sq & 31)), TB_RLX, TB_WG); }
       break;
     }
     if (moved) {
@@ -1437,7 +1450,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               if (mask_nz(ny | nz | bad) == 0ull) {
                 // quiet pass: the local fixpoint is reached; the slice's "not entailed" bit only ever goes 1 -> 0 below a node
                 if (mask_nz(~(yb >> 1) & ~zb & 1u & am) == 0ull && lane == 0)
-                  (void)__hip_atomic_fetch_and(&ubits[s >> 5], ~(1u << (s & 31)), TB_RLX, TB_WG);
+                  { const int sq = here_s(s); (void)__hip_atomic_fetch_and(&ubits[sq >> 5], ~(1u << (sq & 31)), TB_RLX, TB_WG); }
                 break;
               }
               if (m_bad != 0ull) { if (lane == 0) st(&sh.bot, 1); break; }  // the node fails: what this pass would still write is moot
@@ -1445,6 +1458,14 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               if (nz) (void)__hip_atomic_fetch_or(wz, 1u << zs, TB_RLX, TB_WG);
               run_writes_lean += (ny >> 1) + nz;
               acc |= ny | nz;
+              if (info.y & 0x1000) {
+                // (r05) No variable of this slice is the y of one record and the z of another (engine.hip: slice_infos): what this pass wrote enables no other lane of the
+                // slice, so there is nothing for a confirmation pass to find -- whoever else narrows one of these variables marks the slice for the next round.  Entailed
+                // now = y false or z true, counting what was just written.  (wordpress7_500: 16 of a node's 29 implication runs narrow something; each saved a pass.)
+                if (mask_nz(~((yb | ny) >> 1) & ~(zb | nz) & 1u & am) == 0ull && lane == 0)
+                  { const int sq = here_s(s); (void)__hip_atomic_fetch_and(&ubits[sq >> 5], ~(1u << (sq & 31)), TB_RLX, TB_WG); }
+                break;
+              }
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
               if (ld(&sh.bot)) break;
             }
@@ -1453,7 +1474,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               const int want = (knobs(P) >> 28) & 15;
               if (rep == reps_of(P, 3) && (want == 0 || want - 1 == K_LEQ_T) && (!(knobs(P) & 0x40) || mask_nz(acc) == 0ull)) {
                 wave_iters_total += (pk(P) & 0x400000) ? 1u : iters;
-                wave_active_total += iters * (unsigned)(info.y & 0xff);
+                wave_active_total += iters * (unsigned)__builtin_popcountll(wave_ballot(act));  // (the lanes that hold a record: the vote is live anyway, the count from the info word was a spilled SGPR)
               }
             }
             tc.writes += run_writes_lean;
@@ -1754,7 +1775,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
 #endif
             if (rep == reps_of(P, 3) && (want == 0 || want - 1 == cls_of_slice) && (!(knobs(P) & 0x40) || useless)) {  // 0x40: only the runs that narrowed nothing
               wave_iters_total += (pk(P) & 0x400000) ? 1u : wave_iters;
-              wave_active_total += wave_iters * (unsigned)(info.y & 0xff);
+              wave_active_total += wave_iters * (unsigned)__builtin_popcountll(wave_ballot(act));
             }
           }
         }
