@@ -2,7 +2,7 @@
 # same-box instruction counters of engine builds: scripts/pmc_ab.sh lib1.so lib2.so ... (production-style builds, knob 0)
 cd /tmp; export TMPDIR=/tmp
 for lib in "$@"; do
-  out=$GRAFT_REPO_ROOT/gpurun_out/pmcab_${lib%.so}; rm -rf $out
+  out=$GRAFT_REPO_ROOT/gpurun_out/pmcab_$(basename ${lib%.so}); rm -rf $out
   export TURBO_HIP_LIB=$GRAFT_REPO_ROOT/turbo_amd/lib/$lib
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA -d $out -o p -- python3 $GRAFT_REPO_ROOT/scripts/valu_by_phase.py 0x0 ${PMC_WORKLOAD:-wordpress7_500} ${PMC_NODES:-12000000} > $out.log 2>&1
   python3 - <<PY

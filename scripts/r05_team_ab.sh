@@ -7,7 +7,8 @@ out=gpurun_out/team_ab; rm -rf $out; mkdir -p $out
 args="--workload synthetic --steps 2 --warmup 1 --side-steps 0 --other-steps 0 --reference-seconds 0 --no-cpu-baseline"
 # configurations: TB_TEAM TB_TEAM_SPLIT TB_TEAM_RELAXED (default of this script: the hot tier, then teams of an XCD, relaxed barrier, two and four teams per XCD)
 for fp in ${TEAM_FPS:-wac1}; do
-  for cfg in ${TEAM_CFGS:-"0:1:0 1:1:0 1:1:1 1:2:1 1:4:1 0:1:0 1:1:1 1:2:1 1:4:1"}; do
+  cfgs=${TEAM_CFGS:-0:1:0 1:1:0 1:1:1 1:2:1 1:4:1 0:1:0 1:1:1 1:2:1 1:4:1}
+  for cfg in $cfgs; do
     IFS=: read t sp rl <<< "$cfg"
     TB_TEAM=$t TB_TEAM_SPLIT=$sp TB_TEAM_RELAXED=$rl timeout 300 python3 bench.py $args --fixpoint $fp > $out/rate_${fp}_$cfg.log 2>$out/rate_${fp}_$cfg.err
     python3 - <<PY

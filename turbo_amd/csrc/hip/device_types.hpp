@@ -178,6 +178,8 @@ struct DevProblem {
   const int2* slice_info;  // [n_slices] event kernels, read with scalar loads: {word0 of the slice's records (class set, operand kinds, flags),
                            //  lanes holding a propagator | 0x100: lean implication records (engine.hip: pack_succ)}
   const int* slice_real;  // [n_slices] event kernels: lanes of the slice that hold a propagator (the engine pads every class to whole slices)
+  const int2* cond2;      // [padded n_props] event kernels, COMPACT layouts (r05, engine.hip: pack_cond2): for a channelling record c = (val = v) whose truth variable is only read, as far as
+                          // "c became false" goes, by the implications b_i <= c of ONE index variable: {reference of that index, lowest | highest << 16 position i}; x < 0: none
 #ifdef TB_TUNING
   unsigned* slice_census;  // tuning build, knob 0x400000 + verbose: [2 * n_slices] runs of every slice, and those that narrowed nothing (whole grid)
 #endif

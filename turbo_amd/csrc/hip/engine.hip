@@ -809,6 +809,51 @@ std::vector<int4> pack_succ(int32_t n_props, const tb_prop* props, const Adjacen
   return out;
 }
 
+// (r05) Conditional wake-up of an element constraint's implications by "c became false" (DevProblem::cond2; kernels.hpp: the block before mark_successors).
+// An element constraint val = table[idx] is lowered to channelling records b_i = (idx = i), c_v = (val = v) and implications b_i <= c_table[i].  When a channelling lane makes
+// c_v false, the implication slices holding b_i <= c_v run to make those b_i false -- and find them false already whenever the positions of v lie outside idx's bounds
+// (idx's own chain has seen to it, or will before the fixpoint ends), or idx is assigned (the one b that is not false is true, and ITS becoming true wakes the implications).
+// Eligible: c is the truth variable of exactly this channelling record; every reader slice of c interested in "upper bound lowered" is a lean implication slice; every
+// implication with z = c has for y the truth variable of exactly one channelling record of ONE index variable, an integer of the slab; positions within 0..65535.
+std::vector<int2> pack_cond2(int32_t n_props, const tb_prop* props, const Adjacency& adj, const std::vector<int4>& records, const std::vector<int>& value, const Layout& lay,
+                             std::vector<char>* slice_has) {
+  const size_t padded = ((size_t)n_props + 63) / 64 * 64;
+  std::vector<int2> out(std::max<size_t>(padded, 64), make_int2(-1, 0));
+  slice_has->assign(std::max<size_t>(1, padded / 64), 0);
+  const size_t V = adj.lists.size();
+  auto key_of_slice = [&](int sl) { return (size_t)sl * 64 < records.size() ? (unsigned)records[(size_t)sl * 64].x >> 16 : 0u; };
+  std::vector<int> chan_rec(V, -1);
+  std::vector<std::vector<int>> impl_of_z(V);
+  for (int32_t i = 0; i < n_props; ++i) {
+    if (props[i].op < 0) continue;
+    const unsigned key = key_of_slice(i / 64);
+    if (key == KEY_EQR_BIC) { int& r = chan_rec[(size_t)props[i].x]; r = r == -1 ? i : -2; }
+    else if (key == KEY_LEQT_BB) impl_of_z[(size_t)props[i].z].push_back(i);
+  }
+  for (int32_t i = 0; i < n_props; ++i) {
+    if (props[i].op < 0 || key_of_slice(i / 64) != KEY_EQR_BIC) continue;
+    const int c = props[i].x;
+    // (a table-like fan-in only: where c has a single implication -- trains15's b1 <= b2 between two truth variables -- the test costs what the run it spares does: measured -1 %)
+    if (chan_rec[(size_t)c] != i || impl_of_z[(size_t)c].size() < 4) continue;
+    bool ok = true;
+    for (const Reader& r : adj.lists[(size_t)c])
+      if (r.slice != i / 64 && (r.interest & 2) && key_of_slice(r.slice) != KEY_LEQT_BB) { ok = false; break; }
+    int idx = -1, pmin = 0x7fffffff, pmax = -0x7fffffff;
+    for (size_t q = 0; q < impl_of_z[(size_t)c].size() && ok; ++q) {
+      const int b = props[impl_of_z[(size_t)c][q]].y;
+      const int rb = chan_rec[(size_t)b];
+      if (rb < 0) { ok = false; break; }
+      const int I = props[rb].y, pos = value[(size_t)props[rb].z];
+      if (idx == -1) idx = I; else if (idx != I) ok = false;
+      pmin = std::min(pmin, pos); pmax = std::max(pmax, pos);
+    }
+    if (!ok || idx < 0 || idx >= lay.n_int || pmin < 0 || pmax > 0xffff) continue;
+    out[(size_t)i] = make_int2(lay.ref(idx), pmin | (pmax << 16));
+    (*slice_has)[(size_t)(i / 64)] = 1;
+  }
+  return out;
+}
+
 // Per slice, for the event kernels (read with scalar loads): x = word0 of the slice's first record (its slice-uniform part: class set,
 // operand kinds, flags), y = lanes that hold a propagator | 0x100 when the slice's successor records carry the lean implication encoding.
 // 0x200: the slice has one class (not the heavy one) and every operand of every record has a finite root domain within +-2^29 -- the plain
@@ -1257,7 +1302,20 @@ int upload_event_tables(DevBuffers& bufs, DevProblem& P, const tb_config& cfg, c
   if ((rc = bufs.alloc(&d_succ, succ.size())) != TB_OK) return rc;
   if (!succ.empty()) HIP_TRY(hipMemcpy(d_succ, succ.data(), succ.size() * sizeof(int4), hipMemcpyHostToDevice));
   P.succ = d_succ;
-  const std::vector<int2> info = slice_infos(packed, real, plan.n_slices, lean, root, std::getenv("TB_NO_LEAN") == nullptr, chains);
+  std::vector<int2> info = slice_infos(packed, real, plan.n_slices, lean, root, std::getenv("TB_NO_LEAN") == nullptr, chains);
+  {  // conditional wake-up of element implications by "c became false" (TB_NO_COND2: A/B runs)
+    std::vector<char> has;
+    std::vector<int2> cond2(std::max<size_t>(64, (size_t)plan.n_slices * 64), make_int2(-1, 0));
+    if (lean && joint && std::getenv("TB_NO_COND2") == nullptr) {
+      cond2 = pack_cond2(n_rec, net_props.data(), adj, packed, value, lay, &has);
+      cond2.resize(std::max<size_t>(64, (size_t)plan.n_slices * 64), make_int2(-1, 0));
+      for (int q = 0; q < plan.n_slices && (size_t)q < has.size(); ++q) if (has[(size_t)q]) info[(size_t)q].y |= 0x2000;
+    }
+    int2* d_cond2 = nullptr;
+    if ((rc = bufs.alloc(&d_cond2, cond2.size())) != TB_OK) return rc;
+    HIP_TRY(hipMemcpy(d_cond2, cond2.data(), cond2.size() * sizeof(int2), hipMemcpyHostToDevice));
+    P.cond2 = d_cond2;
+  }
   if (std::getenv("TB_DUMP_SLICES") != nullptr)  // debugging aid
     for (int q = 0; q < plan.n_slices; ++q) {
       int prefix = 0, classed = 0;

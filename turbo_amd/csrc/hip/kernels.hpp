@@ -959,7 +959,7 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
     nar_all |= nar;  // (a cooperative body reaches the slice's fixpoint in one pass: it narrows, reports nar and no change)
     if (!wave_any(ch)) {
       // The byte only ever goes 1 -> 0 below a node (entailment is monotone).
-      if (!wave_any(un_i) && lane == 0) { const int sq = here_s(s); (void)__hip_atomic_fetch_and(&E.unent[sq >> 5], ~(1u << (sq & 31)), TB_RLX, TB_WG); }  // (mask and word formed here: hoisted, they were spilled around every run)
+      if (!wave_any(un_i) && lane == 0) { const int sq = here_s(__builtin_amdgcn_readfirstlane(s)); (void)__hip_atomic_fetch_and(&E.unent[sq >> 5], ~(1u << (sq & 31)), TB_RLX, TB_WG); }  // (mask and word formed here: hoisted, they were spilled around every run)
       break;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1184,7 +1184,7 @@ __device__ __forceinline__ unsigned lean_class_run_t(const RunEnv& E, const int 
     const bool moved = act && (cxl | cxu | cyl | cyu | czl | czu);
     if (!wave_any(moved)) {
       // quiet pass: the local fixpoint is reached; the slice's "not entailed" bit only ever goes 1 -> 0 below a node
-      if (!wave_any(act && !ent) && lane == 0) { const int sq = here_s(s); (void)__hip_atomic_fetch_and(&E.unent[sq >> 5], ~(1u << (sq & 31)), TB_RLX, TB_WG); }
+      if (!wave_any(act && !ent) && lane == 0) { const int sq = here_s(__builtin_amdgcn_readfirstlane(s)); (void)__hip_atomic_fetch_and(&E.unent[sq >> 5], ~(1u << (sq & 31)), TB_RLX, TB_WG); }
       break;
     }
     if (moved) {
@@ -1450,7 +1450,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
               if (mask_nz(ny | nz | bad) == 0ull) {
                 // quiet pass: the local fixpoint is reached; the slice's "not entailed" bit only ever goes 1 -> 0 below a node
                 if (mask_nz(~(yb >> 1) & ~zb & 1u & am) == 0ull && lane == 0)
-                  { const int sq = here_s(s); (void)__hip_atomic_fetch_and(&ubits[sq >> 5], ~(1u << (sq & 31)), TB_RLX, TB_WG); }
+                  { const int sq = here_s(__builtin_amdgcn_readfirstlane(s)); (void)__hip_atomic_fetch_and(&ubits[sq >> 5], ~(1u << (sq & 31)), TB_RLX, TB_WG); }
                 break;
               }
               if (m_bad != 0ull) { if (lane == 0) st(&sh.bot, 1); break; }  // the node fails: what this pass would still write is moot
@@ -1463,7 +1463,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                 // slice, so there is nothing for a confirmation pass to find -- whoever else narrows one of these variables marks the slice for the next round.  Entailed
                 // now = y false or z true, counting what was just written.  (wordpress7_500: 16 of a node's 29 implication runs narrow something; each saved a pass.)
                 if (mask_nz(~((yb | ny) >> 1) & ~(zb | nz) & 1u & am) == 0ull && lane == 0)
-                  { const int sq = here_s(s); (void)__hip_atomic_fetch_and(&ubits[sq >> 5], ~(1u << (sq & 31)), TB_RLX, TB_WG); }
+                  { const int sq = here_s(__builtin_amdgcn_readfirstlane(s)); (void)__hip_atomic_fetch_and(&ubits[sq >> 5], ~(1u << (sq & 31)), TB_RLX, TB_WG); }
                 break;
               }
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1754,6 +1754,19 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             tprof = t_;
           }
 #endif
+          if (C != 0 && (info.y & 0x2000) && wave_any((nar_all & 2) != 0)) {
+            // (r05) A channelling lane has just made c = (val = v) FALSE, and c's only readers that care are the implications b_i <= c of an element constraint
+            // (engine.hip: pack_cond2).  Their rule can only make b_i false for the positions i whose table entry is v -- which the index's own channelling does as
+            // soon as i leaves the index's domain.  So when no such position lies inside the index's bounds, or the index is assigned (the one b that is not false
+            // is then TRUE, and its becoming true wakes these implications by itself), the wake-up would be a run that narrows nothing: one 8-byte record and one
+            // domain read here instead.  wordpress7_500: 12 of a node's 25 implication runs were of that kind (r04 census).
+            TB_REGION(67);
+            const int2 cw = glob(P.cond2)[s * 64 + lane];
+            if ((nar_all & 2) != 0 && cw.x >= 0) {
+              const Itv I = load_ivar<C>(store, P.n_int, cw.x);
+              if (I.lb == I.ub || I.ub < (cw.y & 0xffff) || I.lb > (int)((unsigned)cw.y >> 16)) nar_all &= ~2;
+            }
+          }
           TB_REGION(18);
 #ifdef TB_TUNING
           note_marked(mark_successors<C>(P, sh, nxt, s, pr, sc, nar_all, (prof && wave == 0) ? sh.bs.dbg : nullptr));
