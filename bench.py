@@ -146,7 +146,7 @@ def reference_invocation(seconds: float) -> dict:
 def profile_figures(workload: str, fixpoint: str) -> dict | None:
     """Counter-derived figures of the same command, collected by scripts/profile_round.sh in separate rocprofv3 --pmc
     passes and committed under profiles/ (they are NOT measured in this run: the source file is named)."""
-    for name in ("r04_counters.json", "r03_counters.json", "r02_counters.json"):
+    for name in ("r05_counters.json", "r04_counters.json", "r03_counters.json", "r02_counters.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -201,11 +201,13 @@ def attach_counters(roof: dict, workload: str, fixpoint: str, launch_s: float) -
 # Calibration (gpurun_out/r05_solve_ladder.log, one MI355X): wordpress7_500 -- `objective <= 500` is refuted in 0.86 s (4.7e7 nodes, 2^21 subproblems: 2 060 486 solved +
 # 36 666 skipped), <= 1000 is not within 17 s; branch and bound reaches 14 000 after 9 s (4.9e8 nodes).  trains15 -- <= 0 is refuted in 0.54 s (every one of the 2^20 subproblems dies
 # in its dive: queue and dive throughput), <= 10 leaves a dozen hard subproblems after 17 s; 75 is reached after 0.9 s.  accap_a3 at 2^16 -- <= 55 is refuted in 1.2 s, 135 reached in 0.06 s.
+# 2^d is FIXED per workload (what the reference's rule gives one MI355X): the rule 2^d >= 300 x workgroups x GPUs would double the subproblems -- and the dive nodes of a proof --
+# with every doubling of the GPUs, and a strong-scaling curve needs the same work at every N.
 SOLVE_DEFAULTS = {
-    "wordpress7_500": (500, 14000, -1),
+    "wordpress7_500": (500, 14000, 21),
     "accap_a3": (55, 135, 16),
-    "trains15": (0, 75, -1),
-    "synthetic": (None, None, -1),
+    "trains15": (0, 75, 20),
+    "synthetic": (None, None, 17),
 }
 
 

@@ -1090,12 +1090,21 @@ InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, c
   // order carries locality (the 100k x 500k synthetic network is emitted in topological order: sorted, a node needs
   // 20 % more sweeps and the event worklist twice the evaluations; trains15 on compact slabs in global memory: 2.03e7 nodes/s in the
   // caller's order, 1.96e7 sorted).
-  if (keep_order) return n;
   auto key = [&](const tb_prop& q) {
     const tb_itv d = n.store[(size_t)q.x];
     const bool xc = d.lb == d.ub && d.lb != TB_NINF && d.lb != TB_PINF;
     return class_of(q.op, xc, xc ? d.lb : 0) * 16 + q.op;
   };
+  if (keep_order) {
+    // (r05, experiment: TB_GLOBAL_SORT_WINDOW=W) the caller's order kept at the scale of W records, the class sort applied inside each window: slices become class-pure
+    // (two gathers and one comparison for `y <= z` instead of every class body behind selects) while the topological order of the stream survives at window granularity.
+    const char* e = std::getenv("TB_GLOBAL_SORT_WINDOW");
+    const long W = e != nullptr ? std::atol(e) : 0;
+    if (W >= 128)
+      for (size_t a = 0; a < n.props.size(); a += (size_t)W)
+        std::stable_sort(n.props.begin() + (long)a, n.props.begin() + (long)std::min(n.props.size(), a + (size_t)W), [&](const tb_prop& x, const tb_prop& y) { return key(x) < key(y); });
+    return n;
+  }
   // Event-driven fixpoint: inside the reified comparisons against a constant (`b = (y = k)`, `b = (y <= k)`: the channelling of
   // element constraints) the records of one variable y are made contiguous, so that a slice holds few distinct y and the
   // kernel can evaluate the lanes sharing a variable jointly (kernels.hpp: KEY_EQR_BIC).

@@ -691,7 +691,7 @@ __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store
   Itv X{0, 1}, Y{0, 1}, Z{0, 1};
   if (!(dbg & 2)) { X = load_dom<C>(store, ni, pr.y); Y = load_dom<C>(store, ni, pr.z); Z = load_dom<C>(store, ni, pr.w); }
   Cand c;
-  if (!(dbg & 1)) c = evaluate_packed(w0, X, Y, Z); else c.ent = (pr.y != 0x7fffffff);
+  if (!(dbg & 1)) c = evaluate_packed<((C == 3 || C == 5) ? 1 : ((!EVENT && C == 0) ? 2 : 0))>(w0, X, Y, Z); else c.ent = (pr.y != 0x7fffffff);
   if (dbg & 4) { un |= act & !c.ent; return; }
   const bool empty_in = (X.lb > X.ub) | (Y.lb > Y.ub) | (Z.lb > Z.ub);
   const bool cx = (c.xl > X.lb) | (c.xu < X.ub), cy = (c.yl > Y.lb) | (c.yu < Y.ub), cz = (c.zl > Z.lb) | (c.zu < Z.ub);
@@ -1402,7 +1402,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
 #endif
       while (s >= 0) {
         TB_REGION(5);
+#if TB_SC_PREFETCH
         const int s_next = next_slice();
+#endif
         s = TB_IDX(13, s, n_slices);
 #if TB_SC_PREFETCH
         const int4 sc = sc_cur;
@@ -1792,7 +1794,11 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
             }
           }
         }
+#if TB_SC_PREFETCH
         s = s_next;
+#else
+        s = next_slice();  // (found after the run: nothing of the next slice lives through this one)
+#endif
       }
     }
     for (int rep = reps_of(P, 10); rep > 0; --rep) {  // (tuning: the end of a round twice -- flag, reset, barrier)
@@ -1828,7 +1834,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       const bool act = i < n;
       const int4 pr = props[TB_IDX(19, act ? i : 0, records)];
       const Itv X = load_dom<C>(store, P.n_int, pr.y), Y = load_dom<C>(store, P.n_int, pr.z), Z = load_dom<C>(store, P.n_int, pr.w);
-      const Cand c = evaluate_single(pr.x, X, Y, Z);
+      const Cand c = evaluate_single<((C == 3 || C == 5) ? 1 : 0)>(pr.x, X, Y, Z);
       return wave_ballot(act && !c.ent);
     };
     int wit = __builtin_amdgcn_readfirstlane(ld(&sh.witness));

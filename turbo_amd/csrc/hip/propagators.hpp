@@ -133,6 +133,41 @@ __device__ __forceinline__ Cand evaluate_heavy(int op, const Itv X, const Itv Y,
   return c;
 }
 
+// `x = y * z` on NON-NEGATIVE operands (r05): products and quotients are monotone, so the hull of the corner products is [y.lb * z.lb, y.ub * z.ub] and the hull of the corner
+// quotients [ceil(x.lb / z.ub), floor(x.ub / z.lb)] -- two multiplications and four unsigned divisions where evaluate_heavy walks every sign case (four 64-bit corner products,
+// sixteen signed divisions with floor / ceil fix-ups).  Same candidate bounds as evaluate_heavy on every box with x.lb, y.lb, z.lb >= 0 that is not already empty: an infinite
+// upper bound (INT32_MAX) saturates like mul_ext (0 * inf = 0), the quotient rules apply under the same conditions (x finite, divisor finite and > 0).
+__device__ __forceinline__ int mul_sat_nn(int a, int b) {  // a, b >= 0
+  const unsigned long long p = (unsigned long long)(unsigned)a * (unsigned long long)(unsigned)b;
+  return p >= (unsigned long long)PINF ? PINF : (int)p;
+}
+__device__ __forceinline__ unsigned udiv1(int a) { return a > 1 ? (unsigned)a : 1u; }  // a divisor that is only used when it is positive
+__device__ __forceinline__ Cand evaluate_mul_nn(const Itv X, const Itv Y, const Itv Z) {
+  Cand c;
+  c.xl = mul_sat_nn(Y.lb, Z.lb); c.xu = mul_sat_nn(Y.ub, Z.ub);
+  if (X.lb > 0) {  // a non-zero product has non-zero factors
+    if (Y.lb == 0) c.yl = 1;
+    if (Y.ub == 0) c.yu = -1;
+    if (Z.lb == 0) c.zl = 1;
+    if (Z.ub == 0) c.zu = -1;
+  }
+  const bool x_fin = X.ub != PINF;
+  const unsigned uxl = (unsigned)X.lb, uxu = (unsigned)imax(X.ub, 0);
+  const bool dy = x_fin && Z.lb > 0 && Z.ub != PINF, dz = x_fin && Y.lb > 0 && Y.ub != PINF;
+  if (__builtin_amdgcn_ballot_w64(dy) != 0ull) {
+    const unsigned du = udiv1(Z.ub), dl = udiv1(Z.lb);
+    const int lo = (int)((uxl + du - 1u) / du), hi = (int)(uxu / dl);
+    if (dy) { c.yl = imax(c.yl, lo); c.yu = imin(c.yu, hi); }
+  }
+  if (__builtin_amdgcn_ballot_w64(dz) != 0ull) {
+    const unsigned du = udiv1(Y.ub), dl = udiv1(Y.lb);
+    const int lo = (int)((uxl + du - 1u) / du), hi = (int)(uxu / dl);
+    if (dz) { c.zl = imax(c.zl, lo); c.zu = imin(c.zu, hi); }
+  }
+  c.ent = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub && x_fin && Y.ub != PINF && Z.ub != PINF && (long long)X.lb == (long long)Y.lb * (long long)Z.lb;
+  return c;
+}
+
 // ---- packed records -----------------------------------------------------------------------------------
 // word0 = class | original op << 12 | (set of classes present in the 64-record slice) << 16 ; words 1-3 = x,y,z.
 // A comparison whose truth variable is a constant of the root store (TCN has no constants, only singleton
@@ -159,13 +194,28 @@ __host__ __device__ inline int class_of(int op, bool x_const, int x_value) {
   }
 }
 
+// A class-pure slice of heavy records as a function of its own (NNF = 2, the sweeps of LDS-resident plain stores): the products of non-negative operands take evaluate_mul_nn, the
+// rest evaluate_heavy -- out of line, so that the sweep loop around it keeps its registers and its size (inlined there, the fast path cost wordpress7_500's WAC1 sweeps 15 %).
+__device__ __noinline__ Cand evaluate_heavy_slice(int w0, const Itv X, const Itv Y, const Itv Z) {
+  const int op = (w0 >> 12) & 0x7;
+  const bool nn = op == OP_MUL && X.lb >= 0 && Y.lb >= 0 && Z.lb >= 0 && X.lb <= X.ub && Y.lb <= Y.ub && Z.lb <= Z.ub;
+  if (__builtin_amdgcn_ballot_w64(!nn) == 0ull) return evaluate_mul_nn(X, Y, Z);
+  return evaluate_heavy(op, X, Y, Z);
+}
+
+// NNF: compile the fast path for products of non-negative operands (evaluate_mul_nn) into the heavy branch.  Only the kernels of networks in GLOBAL memory with the caller's record order
+// (store layouts 3 and 5: the synthetic 100k x 500k network, where one product sits in almost every slice) take it: measured r05, same box -- synthetic wac1 +17 %, event +25 %, ac1 +16 %;
+// but wordpress7_500 wac1 -15 %, ac1 -8 %, event -2 % when it is compiled into the LDS-resident kernels too (their five product slices gain, everything else pays for the registers).
+template <int NNF = 0>
 __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y, const Itv Z);
 // The rules for lanes holding ARBITRARY records (not the 64 records of one slice): the slice-level class set of word0 is
 // replaced by "every class may be present", which sends evaluate_packed down its per-lane path.
+template <int NNF = 0>
 __device__ __forceinline__ Cand evaluate_single(int w0, const Itv X, const Itv Y, const Itv Z) {
-  return evaluate_packed((w0 & 0xffff) | (CLASS_SET_MASK << 16), X, Y, Z);
+  return evaluate_packed<NNF>((w0 & 0xffff) | (CLASS_SET_MASK << 16), X, Y, Z);
 }
 
+template <int NNF>
 __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y, const Itv Z) {
   Cand c;
   int cls = w0 & 0xff;
@@ -290,7 +340,17 @@ __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y
     }
   }
   if (present & (1 << K_HEAVY)) {
-    if (cls == K_HEAVY) {
+    // (r05) The heavy lanes of most networks are products of non-negative operands -- coefficient x Boolean terms of linear constraints, price x quantity; the synthetic
+    // 100k x 500k network's 8 147 products sit one to a 64-record slice, so that EVERY slice of a sweep walked evaluate_heavy for a single lane.  When every heavy lane of
+    // the wave is such a product (one vote) they take evaluate_mul_nn; a TDIV / TMOD or a factor that may be negative sends the wave's heavy lanes down the general rule.
+    const bool heavy = cls == K_HEAVY;
+    const bool nn = heavy && ((w0 >> 12) & 0x7) == OP_MUL && X.lb >= 0 && Y.lb >= 0 && Z.lb >= 0 && X.lb <= X.ub && Y.lb <= Y.ub && Z.lb <= Z.ub;
+    if (NNF == 2 && present == (1 << K_HEAVY)) {  // (idle lanes of a padded slice evaluate a harmless record of their own class: the result of a lane without a propagator is never used)
+      c = evaluate_heavy_slice(w0, X, Y, Z);
+      ent = c.ent;
+    } else if (NNF == 1 && __builtin_amdgcn_ballot_w64(heavy && !nn) == 0ull) {
+      if (heavy) { c = evaluate_mul_nn(X, Y, Z); ent = c.ent; }
+    } else if (heavy) {
       c = evaluate_heavy((w0 >> 12) & 0x7, X, Y, Z);
       ent = c.ent;
     }
