@@ -48,7 +48,7 @@ CASES = [  # (network, label, config, nodes per launch)
     ("trains15.fzn", "event, COMPACT8 slab in global memory", dict(fixpoint=2, only_global_memory=1, debug=C8), 10_000_000),
     ("trains15.fzn", "wac1", dict(fixpoint=1), 5_000_000),
     ("synthetic", "event (hot tier)", dict(fixpoint=2), 30_000),
-    ("synthetic", "wac1 (hot tier)", dict(fixpoint=1), 15_000),
+    ("synthetic", "wac1 (workgroup teams, the default plan)", dict(fixpoint=1), 15_000),
 ]
 
 rows, failed = [], None

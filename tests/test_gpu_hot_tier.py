@@ -19,6 +19,12 @@ pytestmark = pytest.mark.gpu
 KEEP = 0x800000
 
 
+@pytest.fixture(autouse=True)
+def no_teams(monkeypatch):
+    # r05: the sweeps of a network this size are planned in workgroup teams (tests/test_gpu_team.py); TB_TEAM=0 gives the hot tier this file is about
+    monkeypatch.setenv("TB_TEAM", "0")
+
+
 @pytest.fixture(scope="module")
 def net():
     return make_synthetic(30_000, 120_000, seed=7)

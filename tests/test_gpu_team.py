@@ -110,6 +110,23 @@ def test_teams_enumerate_every_solution_once(team_env):
     assert len({s.tobytes() for s, _ in got}) == len(got)
 
 
+def test_teams_are_the_default_plan_where_the_hot_tier_was(monkeypatch):
+    """A store in global memory with more variables than the hot tier holds, sweeping fixpoints: the engine plans teams by itself (kernel_opt 10), the hot tier with TB_TEAM=0
+    (kernel_opt 6), and the event fixpoint keeps its hot-tier kernel."""
+    from turbo_amd.synth import make_synthetic
+    monkeypatch.delenv("TB_TEAM", raising=False)
+    tcn = make_synthetic(30000, 120000, seed=7)
+    assert plan_of(tcn, fixpoint=1, timeout_ms=60000)["kernel_opt"] == 10
+    assert plan_of(tcn, fixpoint=0, timeout_ms=60000)["kernel_opt"] == 10
+    assert plan_of(tcn, fixpoint=2, threads_per_block=1024, timeout_ms=60000)["kernel_opt"] == 3
+    monkeypatch.setenv("TB_TEAM", "0")
+    assert plan_of(tcn, fixpoint=1, timeout_ms=60000)["kernel_opt"] == 6
+    monkeypatch.delenv("TB_TEAM")
+    # and the default plan searches: same optimum as the single-workgroup kernels on a budget-free small instance
+    small = frontend.load_fzn(os.path.join(BENCH, "test_data", "pat7.fzn"))
+    assert plan_of(small, fixpoint=1, timeout_ms=60000)["kernel_opt"] != 10, "small networks keep their LDS-resident kernels"
+
+
 def test_synthetic_network_teams_agree_with_single_workgroups(team_env):
     """BASELINE.json configs[4] in small (20k x 100k): the same node budget per searcher gives the same tree statistics whether a searcher is a workgroup or a team."""
     from turbo_amd.synth import make_synthetic

@@ -117,7 +117,7 @@ struct alignas(64) TeamGrid {
   unsigned registered;      // workgroups of the grid that have joined a team
   unsigned xcd_members[8];  // workgroups registered per XCD (HW_REG_XCC_ID)
   unsigned pad[7];
-  TeamCtl team[32];         // XCD x * split + k: up to four teams per XCD (DevProblem::team_split)
+  TeamCtl team[64];         // XCD x * split + k: up to eight teams per XCD (DevProblem::team_split)
 };
 
 // Solution ring in pinned host memory (streaming, gpu_dive_and_solve.hpp:100-132 re-done without a print lock):

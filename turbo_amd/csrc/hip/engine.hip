@@ -355,15 +355,17 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     return fixed + (size_t)HOT_VARS * 8 + dirty_b <= lds;
   };
   // Workgroup teams (r05; kernels.hpp layout 5): the sweeps of a network whose store lives in global memory, 1024-thread workgroups, one per CU -- the workgroups of an
-  // XCD share ONE store, which then sits in that XCD's L2.  (TB_TEAM=0 switches it off for A/B runs, TB_TEAM=1 takes it wherever it is possible.)
+  // XCD share a store, which then sits in that XCD's L2.  (TB_TEAM=0 switches it off -- the hot tier then --, TB_TEAM=1 takes it wherever it is possible.)
   auto team_mode = [&]() {
     const char* e = std::getenv("TB_TEAM");
     if (!search || event || lay.compact || T != 1024 || cfg.entailed_prop_removal || (e != nullptr && e[0] == '0')) return false;
-    return e != nullptr && e[0] == '1';  // (opt-in until it is measured against the hot tier)
+    // r05, same box, synthetic 100k x 500k with the product fast path in: hot tier 9.8e10 propagations/s (wac1) / 8.9e10 (ac1); four teams per XCD 1.09e11 / 1.11e11,
+    // eight 1.10e11 / 1.07e11, two 1.02e11 / 1.05e11 -- so teams are the plan wherever the hot tier was (profiles/r05_team_ab.txt)
+    return (e != nullptr && e[0] == '1') || n_vars > HOT_VARS;
   };
   if (cfg.only_global_memory) {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
-    if (team_mode()) { p.team = true; p.blocks_per_cu = 1; }
+    if (team_mode()) { p.team = true; p.blocks_per_cu = TB_TEAM_WG_PER_CU; }
     else if (hot_tier()) { p.hot = true; p.blocks_per_cu = 1; p.shared_bytes = (int)(fixed + (size_t)HOT_VARS * 8 + dirty_b); }
   } else if (!event && !lay.compact && lds_footprint(caps, fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
     // (records in LDS: the plain sweeps on small networks only.  The event kernels and the compact layouts have no such instantiation:
@@ -381,7 +383,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / lds_footprint(caps, fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
   } else {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
-    if (team_mode()) { p.team = true; p.blocks_per_cu = 1; }
+    if (team_mode()) { p.team = true; p.blocks_per_cu = TB_TEAM_WG_PER_CU; }
     else if (hot_tier()) { p.hot = true; p.blocks_per_cu = 1; p.shared_bytes = (int)(fixed + (size_t)HOT_VARS * 8 + dirty_b); }
   }
   long long blocks = (long long)p.blocks_per_cu * caps.cus;
@@ -993,7 +995,7 @@ int prepare_kernel(bool solve, int mem, int tmax, bool event, int opt, int bytes
     HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     int nb = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, threads, (size_t)bytes));
-    *max_blocks_per_cu = std::min(nb, 1);  // one workgroup per CU: every workgroup of the grid must be resident (the teams form by waiting for the whole grid)
+    *max_blocks_per_cu = std::min(nb, TB_TEAM_WG_PER_CU);  // one workgroup per CU (TB_TEAM_WG_PER_CU): every workgroup of the grid must be resident (the teams form by waiting for the whole grid)
     return TB_OK;
   }
   if (solve) DISPATCH_KERNEL(rc = prepare_solve, mem, tmax, event, opt, (bytes, threads, max_blocks_per_cu));
@@ -1639,8 +1641,8 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   P.leaf_assign = s->cfg.leaf_requires_assignment ? 1 : 0;
   P.teams = nullptr;
   P.team_all = (std::getenv("TB_TEAM_ALL") != nullptr && std::getenv("TB_TEAM_ALL")[0] == '1') ? 1 : 0;
-  { const char* e = std::getenv("TB_TEAM_SPLIT"); const int k = e ? std::atoi(e) : 1; P.team_split = (k == 2 || k == 4) ? k : 1; }
-  P.team_relaxed = (std::getenv("TB_TEAM_RELAXED") != nullptr && std::getenv("TB_TEAM_RELAXED")[0] == '1') ? 1 : 0;
+  { const char* e = std::getenv("TB_TEAM_SPLIT"); const int k = e ? std::atoi(e) : 4; P.team_split = (k == 1 || k == 2 || k == 4 || k == 8) ? k : 4; }  // four teams per XCD by default
+  P.team_relaxed = (std::getenv("TB_TEAM_RELAXED") != nullptr && std::getenv("TB_TEAM_RELAXED")[0] == '0') ? 0 : 1;  // (TB_TEAM_RELAXED=0: acq_rel fences around the barrier, -3 .. -4 %)
   if (plan.team && (rc = s->bufs.alloc(&P.teams, 1)) != TB_OK) return rc;
   // the cell other GPUs reach over xGMI: fine-grained device memory (coherent at system scope while kernels run)
   {

@@ -36,6 +36,15 @@
 // Event kernels: fetch the next slice's successor record (4 registers) while the current slice runs.  Measured on wordpress7_500, same
 // box: 3.51e7 nodes/s without, 2.59e7 with -- loads return in order, so every `s_waitcnt vmcnt(0)` the compiler places inside a run
 // (it cannot count across the branches of the bodies) also waits for the prefetch that was just issued.  Off.
+#ifndef TB_PREGATHER
+#define TB_PREGATHER 1  // the sweeps over stores in global memory gather a slice's operands one slice ahead (kernels.hpp: fixpoint, PREG)
+#endif
+#ifndef TB_TEAM_LOCAL_FENCE
+#define TB_TEAM_LOCAL_FENCE 1  // (0: the WAC1 pass of a team does not wait for its narrowings before the next local pass -- A/B)
+#endif
+#ifndef TB_TEAM_WG_PER_CU
+#define TB_TEAM_WG_PER_CU 1  // resident 1024-thread workgroups per CU in the team kernel (2: the registers are capped at 64 per lane)
+#endif
 #ifndef TB_SC_PREFETCH
 #define TB_SC_PREFETCH 0
 #endif
@@ -328,7 +337,7 @@ __device__ __forceinline__ unsigned long long team_read(const DevProblem& P, con
 __device__ __forceinline__ void team_join(const DevProblem& P, BlockShared& sh) {
   TeamGrid* G = glob(P.teams);
   const unsigned xcc = P.team_all ? 0u : ((unsigned)__builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7u);
-  const unsigned split = P.team_all ? 1u : (unsigned)(P.team_split > 1 ? P.team_split : 1);
+  const unsigned split = P.team_all ? 1u : (unsigned)(P.team_split > 1 ? P.team_split : 1);  // 1, 2, 4 or 8
   const unsigned mx = __hip_atomic_fetch_add(&G->xcd_members[xcc], 1u, TB_RLX, TB_AGENT);  // my arrival on this XCD: dealt to its teams in turn
   (void)__hip_atomic_fetch_add(&G->registered, 1u, __ATOMIC_RELEASE, TB_AGENT);
   for (unsigned spins = 1; __hip_atomic_load(&G->registered, __ATOMIC_ACQUIRE, TB_AGENT) < gridDim.x; ++spins) {
@@ -661,14 +670,21 @@ __device__ __forceinline__ void append_change(const ChangeList& cl, int v) {
   if (pos < cl.cap) cl.list[pos] = v;  // an overflowing list degrades to "run every slice"
 }
 
-template <bool EVENT, int C>
+// The three operand domains of a record, gathered ahead of its evaluation (the sweeps over a store in global memory: `fixpoint`, TB_PREGATHER).
+struct Operands { Itv X, Y, Z; };
+template <int C>
+__device__ __forceinline__ Operands gather_operands(int2* store, const int ni, const int4 pr) {
+  return Operands{load_dom<C>(store, ni, pr.y), load_dom<C>(store, ni, pr.z), load_dom<C>(store, ni, pr.w)};
+}
+
+template <bool EVENT, int C, bool PRE = false>
 __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store, const int ni, int* bot, bool& changed, bool& un, ThreadCounters& tc, const int dbg = 0,
-                                      int* narrowed = nullptr) {
+                                      int* narrowed = nullptr, const Operands* pre = nullptr) {
   const int w0 = pr.x;
   if (dbg == 0 && ((__builtin_amdgcn_readfirstlane(w0) >> 16) & CLASS_SET_MASK) == (1 << K_LEQ_T)) {
     // Class-pure slice of `y <= z` (x is the constant true; two thirds of wordpress7_500 after sorting the records by
     // class): two gathers instead of three, no candidate bookkeeping for x, one comparison per bound.
-    const Itv Y = load_dom<C>(store, ni, pr.z), Z = load_dom<C>(store, ni, pr.w);
+    const Itv Y = PRE ? pre->Y : load_dom<C>(store, ni, pr.z), Z = PRE ? pre->Z : load_dom<C>(store, ni, pr.w);
     const bool ny = Z.ub < Y.ub, nz = Y.lb > Z.lb;                    // y.ub := z.ub, z.lb := y.lb
     const bool empty_in = (Y.lb > Y.ub) | (Z.lb > Z.ub);
     const bool touched = act & (ny | nz | empty_in);
@@ -689,9 +705,10 @@ __device__ __forceinline__ void apply(const int4 pr, const bool act, int2* store
   }
   // three gathers issued back to back, one s_waitcnt (the LDS is ~1 % busy: gathers are cheap, VALU is not)
   Itv X{0, 1}, Y{0, 1}, Z{0, 1};
-  if (!(dbg & 2)) { X = load_dom<C>(store, ni, pr.y); Y = load_dom<C>(store, ni, pr.z); Z = load_dom<C>(store, ni, pr.w); }
+  if (PRE) { X = pre->X; Y = pre->Y; Z = pre->Z; }
+  else if (!(dbg & 2)) { X = load_dom<C>(store, ni, pr.y); Y = load_dom<C>(store, ni, pr.z); Z = load_dom<C>(store, ni, pr.w); }
   Cand c;
-  if (!(dbg & 1)) c = evaluate_packed<((C == 3 || C == 5) ? 1 : ((!EVENT && C == 0) ? 2 : 0))>(w0, X, Y, Z); else c.ent = (pr.y != 0x7fffffff);
+  if (!(dbg & 1)) c = evaluate_packed<((C == 3 || C == 5) ? 1 : 0)>(w0, X, Y, Z); else c.ent = (pr.y != 0x7fffffff);
   if (dbg & 4) { un |= act & !c.ent; return; }
   const bool empty_in = (X.lb > X.ub) | (Y.lb > Y.ub) | (Z.lb > Z.ub);
   const bool cx = (c.xl > X.lb) | (c.xu < X.ub), cy = (c.yl > Y.lb) | (c.yu < Y.ub), cz = (c.zl > Z.lb) | (c.zu < Z.ub);
@@ -757,10 +774,19 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     // (layout 5, workgroup teams: member m of M takes the slices m, m + M, ... of every wave's share -- TS is the stride of the whole team)
     const int TS = C == 5 ? T * team_size(sh) : T;
     const int wave_base = __builtin_amdgcn_readfirstlane(tid - lane) + (C == 5 ? T * team_member(sh) : 0);  // wave-uniform: slice addressing stays in SGPRs
+    // Operands gathered one slice ahead (PREG; r05): with the store in global memory (hot tier, workgroup teams) a slice is a dependent chain record -> three gathers ->
+    // compare -> atomics, the gathers an L2 round trip each time, and a CU has its 16 waves and no more to hide it behind.  The next slice's operands are requested before
+    // the current slice is evaluated.  What they read may be older than what the current slice is about to write: a wider domain, from which the rules derive a weaker but
+    // valid narrowing (the store only shrinks, and the writes are atomic min / max) and possibly a `changed` that changes nothing; the sweep that ends the fixpoint wrote
+    // nothing, so everything it read was current, and its entailment flags are exact.  Same fixpoint, same tree.
+    // Measured r05 (profiles/r05_pregather_ab.txt, same box): teams, plain sweeps 1.115e11 -> 1.225e11 propagations/s and 1.296e4 -> 1.364e4 nodes/s; not the WAC1 sweeps (a
+    // wave's first local pass on older operands costs more passes than the overlap saves: teams -3 % nodes/s, hot tier -7 %), not the hot tier's plain sweeps (-1 %).
+    constexpr bool PREG = TB_PREGATHER && !RM && C == 5;
     // one slice of a plain (AC1) sweep
-    auto ac1_step = [&](const int4 pr, const int base) {
+    auto ac1_step = [&](const int4 pr, const int base, const Operands* g = nullptr) {
       const int i = base + lane;
       const bool act = i < n;
+      if (PREG) { apply<false, C, PREG>(pr, act, store, P.n_int, &sh.bot, changed, un, tc, 0, nullptr, g); return; }
       if (rm) {
         if (slice_unent[base >> 6] == 0) return;
         bool ch = false, un_i = false;
@@ -790,7 +816,13 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
           break;
         }
         changed = true;
+#if TB_TEAM_LOCAL_FENCE
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#else
+        // (a team's store is read and narrowed with agent-scope atomics: the next pass may read it before this pass's narrowings have landed -- an older, wider domain, which
+        //  is sound (PREG above) -- instead of waiting a round trip to the L2 for their acknowledgement)
+        if (C != 5) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#endif
         if (ld(&sh.bot)) break;
         // watchdog inside the wave-local loop: a slowly converging pair in one slice (x < y < x over 2^31 values) never
         // reaches the block-level check below (wave-uniform counter: scalar work, once per 1024 iterations)
@@ -800,7 +832,18 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         }
       }
     };
-    if (!wac1) {
+    if (PREG && !wac1 && n > 0) {
+      int4 pr_next = props[imin(wave_base, last_base) + lane], pr_next2 = props[imin(wave_base + TS, last_base) + lane];
+      Operands g_next = gather_operands<C>(store, P.n_int, pr_next);
+      for (int base = wave_base; base < n; base += TS) {
+        const int4 pr = pr_next;
+        const Operands g = g_next;
+        pr_next = pr_next2;
+        g_next = gather_operands<C>(store, P.n_int, pr_next);
+        pr_next2 = props[imin(base + 2 * TS, last_base) + lane];
+        ac1_step(pr, base, &g);
+      }
+    } else if (!wac1) {
       int4 pr_next = idle_record();
       if (n > 0) pr_next = props[imin(wave_base, last_base) + lane];
       for (int base = wave_base; base < n; base += TS) {
@@ -1834,7 +1877,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       const bool act = i < n;
       const int4 pr = props[TB_IDX(19, act ? i : 0, records)];
       const Itv X = load_dom<C>(store, P.n_int, pr.y), Y = load_dom<C>(store, P.n_int, pr.z), Z = load_dom<C>(store, P.n_int, pr.w);
-      const Cand c = evaluate_single<((C == 3 || C == 5) ? 1 : 0)>(pr.x, X, Y, Z);
+      // (the witness is ONE record, the same in every lane: its own class as the slice's class set sends it down that class's body instead of every body behind selects)
+      const Cand c = whole_slice ? evaluate_single<((C == 3 || C == 5) ? 1 : 0)>(pr.x, X, Y, Z)
+                                 : evaluate_packed<((C == 3 || C == 5) ? 1 : 0)>((pr.x & 0xffff) | ((1 << (__builtin_amdgcn_readfirstlane(pr.x) & 0xff)) << 16), X, Y, Z);
       return wave_ballot(act && !c.ent);
     };
     int wit = __builtin_amdgcn_readfirstlane(ld(&sh.witness));
@@ -2835,7 +2880,7 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_
 // and the host.  Sweeping fixpoints only (AC1 / WAC1), 1024 threads, the PLAIN layout.
 // Between "the last read of this node's store" and "the first write for the next node" stands a team barrier: a member that is still selecting a variable must
 // not see the decision a faster member has already applied.
-__global__ void __launch_bounds__(1024, 1) solve_kernel_team(DevProblem P, Mailbox* mbox) {
+__global__ void __launch_bounds__(1024, 4 * TB_TEAM_WG_PER_CU) solve_kernel_team(DevProblem P, Mailbox* mbox) {
   __builtin_amdgcn_s_dcache_inv();
   constexpr int C = 5;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

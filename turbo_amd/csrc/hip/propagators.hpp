@@ -194,18 +194,11 @@ __host__ __device__ inline int class_of(int op, bool x_const, int x_value) {
   }
 }
 
-// A class-pure slice of heavy records as a function of its own (NNF = 2, the sweeps of LDS-resident plain stores): the products of non-negative operands take evaluate_mul_nn, the
-// rest evaluate_heavy -- out of line, so that the sweep loop around it keeps its registers and its size (inlined there, the fast path cost wordpress7_500's WAC1 sweeps 15 %).
-__device__ __noinline__ Cand evaluate_heavy_slice(int w0, const Itv X, const Itv Y, const Itv Z) {
-  const int op = (w0 >> 12) & 0x7;
-  const bool nn = op == OP_MUL && X.lb >= 0 && Y.lb >= 0 && Z.lb >= 0 && X.lb <= X.ub && Y.lb <= Y.ub && Z.lb <= Z.ub;
-  if (__builtin_amdgcn_ballot_w64(!nn) == 0ull) return evaluate_mul_nn(X, Y, Z);
-  return evaluate_heavy(op, X, Y, Z);
-}
-
 // NNF: compile the fast path for products of non-negative operands (evaluate_mul_nn) into the heavy branch.  Only the kernels of networks in GLOBAL memory with the caller's record order
 // (store layouts 3 and 5: the synthetic 100k x 500k network, where one product sits in almost every slice) take it: measured r05, same box -- synthetic wac1 +17 %, event +25 %, ac1 +16 %;
-// but wordpress7_500 wac1 -15 %, ac1 -8 %, event -2 % when it is compiled into the LDS-resident kernels too (their five product slices gain, everything else pays for the registers).
+// but wordpress7_500 wac1 -15 %, ac1 -8 %, event -2 % when it is compiled into the LDS-resident kernels too (their five product slices gain, everything else pays for the registers),
+// and as an out-of-line function for class-pure heavy slices of the LDS sweeps +0.6 % there against -7 % on accap_a3, which has no product at all (a call in the loop changes its
+// register allocation): the LDS-resident sweeps keep the general rule.
 template <int NNF = 0>
 __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y, const Itv Z);
 // The rules for lanes holding ARBITRARY records (not the 64 records of one slice): the slice-level class set of word0 is
@@ -345,10 +338,7 @@ __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y
     // the wave is such a product (one vote) they take evaluate_mul_nn; a TDIV / TMOD or a factor that may be negative sends the wave's heavy lanes down the general rule.
     const bool heavy = cls == K_HEAVY;
     const bool nn = heavy && ((w0 >> 12) & 0x7) == OP_MUL && X.lb >= 0 && Y.lb >= 0 && Z.lb >= 0 && X.lb <= X.ub && Y.lb <= Y.ub && Z.lb <= Z.ub;
-    if (NNF == 2 && present == (1 << K_HEAVY)) {  // (idle lanes of a padded slice evaluate a harmless record of their own class: the result of a lane without a propagator is never used)
-      c = evaluate_heavy_slice(w0, X, Y, Z);
-      ent = c.ent;
-    } else if (NNF == 1 && __builtin_amdgcn_ballot_w64(heavy && !nn) == 0ull) {
+    if (NNF == 1 && __builtin_amdgcn_ballot_w64(heavy && !nn) == 0ull) {
       if (heavy) { c = evaluate_mul_nn(X, Y, Z); ent = c.ent; }
     } else if (heavy) {
       c = evaluate_heavy((w0 >> 12) & 0x7, X, Y, Z);
