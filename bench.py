@@ -531,7 +531,7 @@ def main() -> int:
             t_load = time.perf_counter()
             tcn2 = load_workload(name)
             t_load = time.perf_counter() - t_load
-            for fp in (("event", "wac1") if name == "synthetic" else ("event",)):
+            for fp in (("event", "wac1", "ac1") if name == "synthetic" else ("event",)):
                 b2 = WORKLOADS[name][1] if fp == "event" else WORKLOADS[name][2]
                 sess2, _ = make_session(fp, b2, tcn2)
                 pl2 = sess2.plan()

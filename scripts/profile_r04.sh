@@ -47,10 +47,10 @@ done;;
 esac
 case $parts in *s*)
 i=0
-for cfg in "wac1 0 hot" "event 0 hot" "wac1 256 hot" "wac1 0 nohot"; do
+for cfg in "wac1 0 team" "event 0 hot" "wac1 256 hot" "wac1 0 hotonly" "ac1 0 team"; do
   set -- $cfg
   i=$((i+1))
-  unset TB_NO_HOT_TIER; [ $3 = nohot ] && export TB_NO_HOT_TIER=1   # (the hot tier of a store in global memory, kernels.hpp layout 3: off for the A/B pass)
+  unset TB_TEAM; [ $3 = hotonly ] && export TB_TEAM=0   # (r05: the sweeps of this network are planned in workgroup teams, kernels.hpp layout 5; TB_TEAM=0: the hot tier, r04's plan)
   args="--workload synthetic --fixpoint $1 --threads $2 --steps 2 --warmup 1 --side-steps 0 --other-steps 0 --reference-seconds 0 --no-cpu-baseline"
   python3 bench.py $args > $out/syn${i}_plain.log 2>&1
   pass syn${i}_fetch FETCH_SIZE -- $args
@@ -59,6 +59,6 @@ for cfg in "wac1 0 hot" "event 0 hot" "wac1 256 hot" "wac1 0 nohot"; do
   pass syn${i}_ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -- $args
 done;;
 esac
-unset TB_NO_HOT_TIER
+unset TB_TEAM
 python3 scripts/summarize_r04.py $tag $out
 mkdir -p gpurun_out/profiles_$tag && cp profiles/${tag}_kernel_stats.txt profiles/${tag}_counters.json gpurun_out/profiles_$tag/

@@ -123,10 +123,14 @@ for fp, key in (("event", "wordpress7_500/event"), ("wac1", "wordpress7_500/wac1
                               "register spills (scratch); WRITE_SIZE is not calibrated"})
     rec[key] = r
 
-for i, (fp, what) in enumerate((("wac1", "256 workgroups x 1024 threads, hot tier (19 456 most-read intervals in LDS): the stores (205 MB) inside the Infinity Cache"),
+team_round = tag >= "r05"  # r05: the sweeps are planned in workgroup teams; pass 4 is the hot tier (TB_TEAM=0), pass 5 the plain sweeps
+for i, (fp, what) in enumerate((("wac1", "256 workgroups x 1024 threads in workgroup teams (four per XCD, 32 shared stores of 800 KB; solve_kernel_team)" if team_round else
+                                         "256 workgroups x 1024 threads, hot tier (19 456 most-read intervals in LDS): the stores (205 MB) inside the Infinity Cache"),
                                 ("event", "256 workgroups x 1024 threads, hot tier, event fixpoint"),
                                 ("wac1", "256-thread workgroups (no hot tier): > 1 GB of stores, beyond the Infinity Cache"),
-                                ("wac1", "256 workgroups x 1024 threads WITHOUT the hot tier (TB_NO_HOT_TIER: r03's configuration)")), 1):
+                                ("wac1", "256 workgroups x 1024 threads, hot tier (TB_TEAM=0: r04's plan; 205 MB of stores inside the Infinity Cache)" if team_round else
+                                         "256 workgroups x 1024 threads WITHOUT the hot tier (TB_NO_HOT_TIER: r03's configuration)"),
+                                ("ac1", "workgroup teams, plain sweeps (operands gathered one slice ahead)")), 1):
     b = bench_line(f"syn{i}_plain.log")
     if not b:
         continue
@@ -156,7 +160,7 @@ for i, (fp, what) in enumerate((("wac1", "256 workgroups x 1024 threads, hot tie
         if pe:
             r["ea_read_requests_per_propagation"] = ea["TCC_EA0_RDREQ_sum"] / pe
             r["ea_read_requests_32B_share"] = ea.get("TCC_EA0_RDREQ_32B_sum", 0.0) / max(1.0, ea["TCC_EA0_RDREQ_sum"])
-    key = "synthetic/" + fp + ("" if i < 3 else ("_beyond_mall" if i == 3 else "_no_hot_tier"))
+    key = "synthetic/" + fp + ("" if i < 3 or i == 5 else ("_beyond_mall" if i == 3 else ("_hot_tier" if team_round else "_no_hot_tier")))
     rec[key] = r
 for k, v in earlier.items():
     if k not in rec:

@@ -72,6 +72,7 @@ int query_caps(int device, DeviceCaps* caps) {
 // ---- launch planning -----------------------------------------------------------------------------
 
 constexpr int TEAM_SWEEP_OPT = 10;  // kernel_opt of a plan that searches in workgroup teams (sweeps, layout 5 << 1)
+constexpr long TEAM_AC1_SORT_WINDOW = 1024;  // records per window of the class sort for a team's plain sweeps (to_internal): one workgroup's 16 slices
 constexpr int HOT_EVENT_OPT = 3, HOT_SWEEP_OPT = 6;  // kernel_opt of a plan with the hot tier (event: the layout; sweeps: layout << 1)
 struct LaunchPlan {
   int threads = 256, tmax = 256;
@@ -1074,7 +1075,7 @@ int32_t padded_count(int32_t n_props, const tb_prop* props, const tb_itv* store)
   for (int c = 0; c < 16; ++c) total += c == last ? cnt[c] : (cnt[c] + 63) / 64 * 64;
   return (int32_t)std::min<long long>(total, 0x7fffffff);
 }
-InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, const tb_prop* props, bool keep_order, bool event = false, bool pad = false) {
+InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, const tb_prop* props, bool keep_order, bool event = false, bool pad = false, long window = 0) {
   InternalNet n;
   n.store.resize((size_t)L.n_vars);
   for (int v = 0; v < L.n_vars; ++v) n.store[(size_t)L.perm[(size_t)v]] = store[v];
@@ -1098,10 +1099,13 @@ InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, c
     return class_of(q.op, xc, xc ? d.lb : 0) * 16 + q.op;
   };
   if (keep_order) {
-    // (r05, experiment: TB_GLOBAL_SORT_WINDOW=W) the caller's order kept at the scale of W records, the class sort applied inside each window: slices become class-pure
+    // (r05; `window`, TB_GLOBAL_SORT_WINDOW=W overrides) the caller's order kept at the scale of W records, the class sort applied inside each window: slices become class-pure
     // (two gathers and one comparison for `y <= z` instead of every class body behind selects) while the topological order of the stream survives at window granularity.
+    // Synthetic 100k x 500k in workgroup teams, same box (profiles/r05_window_team_ab.txt): the plain sweeps 1.23e11 -> 1.52e11 propagations/s and 1.37e4 -> 2.08e4 nodes/s at
+    // W = 1024 (one workgroup's 16 slices; 512: 1.74e4, 2048: 1.86e4, 8192: 1.41e4) -- the team kernel is VALU bound, a mixed slice pays every class body --; the WAC1 sweeps lose
+    // (1.78e4 -> 1.57e4 nodes/s: a definition and the constraints on it no longer share a slice, the local passes find less), the event fixpoint too (3.66e4 -> 2.36e4).
     const char* e = std::getenv("TB_GLOBAL_SORT_WINDOW");
-    const long W = e != nullptr ? std::atol(e) : 0;
+    const long W = e != nullptr ? std::atol(e) : window;
     if (W >= 128)
       for (size_t a = 0; a < n.props.size(); a += (size_t)W)
         std::stable_sort(n.props.begin() + (long)a, n.props.begin() + (long)std::min(n.props.size(), a + (size_t)W), [&](const tb_prop& x, const tb_prop& y) { return key(x) < key(y); });
@@ -1575,7 +1579,8 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   if ((rc = s->bufs.alloc(&d_off, (size_t)n_strats + 1)) != TB_OK) return rc;
   if ((rc = s->bufs.alloc(&d_sv, (size_t)total_svars)) != TB_OK) return rc;
   {
-    const InternalNet net = to_internal(lay, root_store, n_props, props, (s->cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL, s->cfg.fixpoint == 2 && !(s->cfg.reserved[0] & 0x8000000), n_rec != n_props);
+    const InternalNet net = to_internal(lay, root_store, n_props, props, (s->cfg.reserved[0] & 0x200000) != 0 || plan.mem_kind == TB_MEM_GLOBAL, s->cfg.fixpoint == 2 && !(s->cfg.reserved[0] & 0x8000000), n_rec != n_props,
+                                        plan.team && s->cfg.fixpoint == 0 ? TEAM_AC1_SORT_WINDOW : 0);
     if ((int32_t)net.props.size() != n_rec) return fail(TB_ERR_INVALID, "internal: record padding does not match its plan");
     std::vector<char> is_const;
     std::vector<int> value;
