@@ -1,4 +1,4 @@
-"""Workgroup teams (store layout 5, kernels.hpp: solve_kernel_team; opt-in: TB_TEAM=1): the workgroups of one XCD search ONE subproblem together on ONE store in global
+"""Workgroup teams (store layout 5, kernels.hpp: solve_kernel_team; the plan for sweeps over stores too big for the hot tier, TB_TEAM=1 forces it on smaller ones): the workgroups of one XCD search ONE subproblem together on ONE store in global
 memory -- partitioned sweeps, replicated control, the leader talks to the queue / grid words / host.  Same fixpoints, same trees:
   * TB_TEAM_ALL=1 makes the whole grid one team (whatever the XCDs: the protocol only uses agent-scope accesses), and one team walking 2^d subproblems in order must
     walk the ORACLE's tree, node for node, however many members share the sweeps (1, 3, 16, 40 workgroups);
@@ -44,6 +44,27 @@ def test_one_team_walks_the_oracles_tree(team_env, rel, fixpoint, members):
     has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power, cutnodes=cut)
     cfg = dict(or_nodes=members, subproblems_power=power, stop_after_n_nodes=cut, timeout_ms=120000, fixpoint=fixpoint, **TEAM)
     assert plan_of(tcn, **cfg)["kernel_opt"] == 10, "the team kernel was not planned"
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(**cfg))
+    assert has_g == has_o
+    for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
+        assert st_g[k] == st_o[k], k
+    if has_o:
+        np.testing.assert_array_equal(best_g, best_o)
+
+
+@pytest.mark.parametrize("members", [1, 5, 24])
+@pytest.mark.parametrize("fixpoint", [1, 0], ids=["wac1", "ac1"])
+def test_one_team_walks_the_oracles_tree_on_a_synthetic_network(team_env, fixpoint, members):
+    """A small instance of the synthetic generator: mixed-class slices, products of non-negative operands.  That is the network on which the team kernel takes its short cuts
+    -- the product rule with the narrowing pre-test before its divisions, slices handed out on demand (wac1), class-sorted 1024-record windows with the operands gathered a
+    slice ahead (ac1) -- and the tree must still be the oracle's, node for node."""
+    from turbo_amd.synth import make_synthetic
+    team_env.setenv("TB_TEAM_ALL", "1")
+    tcn = make_synthetic(3000, 14000, seed=11)
+    power, cut = 3, 600
+    has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power, cutnodes=cut)
+    cfg = dict(or_nodes=members, subproblems_power=power, stop_after_n_nodes=cut, timeout_ms=120000, fixpoint=fixpoint, **TEAM)
+    assert plan_of(tcn, **cfg)["kernel_opt"] == 10
     has_g, best_g, st_g = capi.solve(tcn, capi.make_config(**cfg))
     assert has_g == has_o
     for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):

@@ -39,6 +39,12 @@
 #ifndef TB_PREGATHER
 #define TB_PREGATHER 1  // the sweeps over stores in global memory gather a slice's operands one slice ahead (kernels.hpp: fixpoint, PREG)
 #endif
+#ifndef TB_DYNAMIC_DEEP
+#define TB_DYNAMIC_DEEP 1  // also the WAC1 sweeps of the LDS-resident 1024-thread kernels, from DYN_MIN_PROPS propagators on (0: A/B)
+#endif
+#ifndef TB_TEAM_DYNAMIC
+#define TB_TEAM_DYNAMIC 1  // the waves of a team workgroup take their slices from a counter in LDS (kernels.hpp: fixpoint, DYN)
+#endif
 #ifndef TB_TEAM_LOCAL_FENCE
 #define TB_TEAM_LOCAL_FENCE 1  // (0: the WAC1 pass of a team does not wait for its narrowings before the next local pass -- A/B)
 #endif
@@ -91,6 +97,8 @@ struct Mailbox {
 };
 
 // Workgroup control block, first bytes of the dynamic LDS segment.
+constexpr int DYN_MIN_PROPS = 32 * 16 * 64;  // slices on demand in the LDS-resident WAC1 sweeps (fixpoint: DYN): from 32 slices per wave on
+
 struct alignas(16) BlockShared {
   int bot;        // VStore::is_bot
   int abort;      // the watchdog fired (must follow `bot`: the hot loops read both with one 8-byte load, dead_node)
@@ -754,7 +762,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
   const bool wac1 = P.fixpoint == 1 && n > P.wac1_threshold;
   constexpr bool rm = RM;  // compiled in or out: the headline sweep pays nothing for the option
   const int dbg = knobs(P) & 0xff, force_sweeps = (knobs(P) >> 8) & 0xff;  // profiling knobs, 0 in production
-  if (tid == 0) { st(&sh.flag[0], 0); st(&sh.unent[0], 0); }
+  if (tid == 0) { st(&sh.flag[0], 0); st(&sh.unent[0], 0); if (TB_TEAM_DYNAMIC && (C == 5 || (TB_DYNAMIC_DEEP && DEEP))) { st(&sh.chg_count[0], 0); st(&sh.chg_count[1], 0); } }
   __syncthreads();
   int it = 0, k = 0;
   unsigned wave_evals = 0;  // wave-uniform: slice evaluations of this wave (x 64 = deduce calls, barebones:958-960)
@@ -773,7 +781,8 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     const int last_base = ((n - 1) >> 6) << 6;
     // (layout 5, workgroup teams: member m of M takes the slices m, m + M, ... of every wave's share -- TS is the stride of the whole team)
     const int TS = C == 5 ? T * team_size(sh) : T;
-    const int wave_base = __builtin_amdgcn_readfirstlane(tid - lane) + (C == 5 ? T * team_member(sh) : 0);  // wave-uniform: slice addressing stays in SGPRs
+    const int member_base = C == 5 ? T * team_member(sh) : 0;
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid - lane) + member_base;  // wave-uniform: slice addressing stays in SGPRs
     // Operands gathered one slice ahead (PREG; r05): with the store in global memory (hot tier, workgroup teams) a slice is a dependent chain record -> three gathers ->
     // compare -> atomics, the gathers an L2 round trip each time, and a CU has its 16 waves and no more to hide it behind.  The next slice's operands are requested before
     // the current slice is evaluated.  What they read may be older than what the current slice is about to write: a wider domain, from which the rules derive a weaker but
@@ -832,7 +841,36 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         }
       }
     };
-    if (PREG && !wac1 && n > 0) {
+    // Slices handed out on demand (DYN; r05, teams): the waves of a workgroup take the workgroup's slices of the sweep -- the same ones, in the same order -- from a counter in
+    // LDS instead of every 16th each.  A sweep ends when its slowest wave does, and slices differ: a WAC1 wave iterates where something moves, a class-pure slice of sums
+    // costs several times one of `<=`, a product may divide.  A wave keeps the records of its next slices in flight as before, so it holds two or three slices it cannot
+    // give away: that is the grain of the balance.
+    // Measured r05 (profiles/r05_dyn_ab.txt, same box, synthetic 100k x 500k in teams): WAC1 sweeps 1.196e11 -> 1.324e11 propagations/s, 1.955e4 -> 2.214e4 nodes/s.  Not the
+    // plain sweeps: the rate rises there too (1.535e11 -> 1.577e11) but the order in which a sweep meets the slices is no longer the same from sweep to sweep, the fixpoint
+    // takes 16 % more evaluations, and the nodes per second fall (2.10e4 -> 1.87e4): they keep every 16th slice per wave.
+    constexpr bool DYN = TB_TEAM_DYNAMIC && (C == 5 || (TB_DYNAMIC_DEEP && DEEP));
+    // The LDS-resident 1024-thread WAC1 sweeps take it when a wave has enough slices for the balance to outweigh the three slices every wave takes beyond the end
+    // (same box, -fp wac1: wordpress7_500, 45 slices per wave, 2.07e6 -> 2.18e6 nodes/s; trains15, 10 per wave, 6.36e6 -> 6.28e6; accap_a3 5.44e7 -> 5.37e7).
+    const bool dyn = DYN && wac1 && T == 1024 && (C == 5 || n >= DYN_MIN_PROPS);
+    int* const next_step = &sh.chg_count[it & 1];  // (the event fixpoint's change-list fill: unused by the sweeps; two counters, the idle one is reset during the sweep)
+    auto take = [&]() -> int {  // base of the next slice of this workgroup, wave-uniform (>= n: none left)
+      int v = 0;
+      if (lane == 0) v = __hip_atomic_fetch_add(next_step, 1, TB_RLX, TB_WG);
+      v = __builtin_amdgcn_readfirstlane(v);
+      return (v >> 4) * TS + member_base + (v & 15) * 64;  // (16 waves per workgroup: the team plan is 1024 threads, engine.hip: team_mode)
+    };
+    if (dyn) {
+      int b0 = take(), b1 = take(), b2 = take();
+      int4 q0 = props[imin(b0, last_base) + lane], q1 = props[imin(b1, last_base) + lane], q2 = props[imin(b2, last_base) + lane];
+      for (;;) {
+        if (b0 >= n) break;
+        { const int4 pr = q0; const int base = b0; b0 = take(); q0 = props[imin(b0, last_base) + lane]; wac1_step(pr, base); }
+        if (b1 >= n) break;
+        { const int4 pr = q1; const int base = b1; b1 = take(); q1 = props[imin(b1, last_base) + lane]; wac1_step(pr, base); }
+        if (b2 >= n) break;
+        { const int4 pr = q2; const int base = b2; b2 = take(); q2 = props[imin(b2, last_base) + lane]; wac1_step(pr, base); }
+      }
+    } else if (PREG && !wac1 && n > 0) {
       int4 pr_next = props[imin(wave_base, last_base) + lane], pr_next2 = props[imin(wave_base + TS, last_base) + lane];
       Operands g_next = gather_operands<C>(store, P.n_int, pr_next);
       for (int base = wave_base; base < n; base += TS) {
@@ -874,6 +912,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
     if (tid == 0) {
       const int k1 = (k + 1) % 3;
       st(&sh.flag[k1], 0); st(&sh.unent[k1], 0);
+      if (TB_TEAM_DYNAMIC && (C == 5 || (TB_DYNAMIC_DEEP && DEEP))) st(&sh.chg_count[(it + 1) & 1], 0);  // (nobody touches the next sweep's counter before the barrier below)
       // watchdog: a pathological network (x < y < x over 2^31 values) must not outlive the deadline
       if ((it & 255) == 255 && deadline_passed(P)) st(&sh.abort, 1);
     }

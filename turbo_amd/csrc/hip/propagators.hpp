@@ -153,7 +153,15 @@ __device__ __forceinline__ Cand evaluate_mul_nn(const Itv X, const Itv Y, const 
   }
   const bool x_fin = X.ub != PINF;
   const unsigned uxl = (unsigned)X.lb, uxu = (unsigned)imax(X.ub, 0);
-  const bool dy = x_fin && Z.lb > 0 && Z.ub != PINF, dz = x_fin && Y.lb > 0 && Y.ub != PINF;
+  bool dy = x_fin && Z.lb > 0 && Z.ub != PINF, dz = x_fin && Y.lb > 0 && Y.ub != PINF;
+  // Would a quotient narrow anything?  ceil(x.lb / z.ub) > y.lb <=> x.lb > y.lb * z.ub, floor(x.ub / z.lb) < y.ub <=> x.ub < y.ub * z.lb (and the same with y and z exchanged: the
+  // same two products).  Two multiplications answer for the four divisions, ~25 VALU instructions each, which a sweep near its fixpoint -- most sweeps -- would compute to
+  // learn nothing: a candidate that does not narrow is dropped by the caller's meet (r05: the synthetic network has one product in nearly every 64-record slice).
+  {
+    const unsigned long long p_ylzu = (unsigned long long)(unsigned)Y.lb * (unsigned long long)(unsigned)Z.ub, p_yuzl = (unsigned long long)(unsigned)Y.ub * (unsigned long long)(unsigned)Z.lb;
+    dy = dy && ((unsigned long long)uxl > p_ylzu || (unsigned long long)uxu < p_yuzl);
+    dz = dz && ((unsigned long long)uxl > p_yuzl || (unsigned long long)uxu < p_ylzu);
+  }
   if (__builtin_amdgcn_ballot_w64(dy) != 0ull) {
     const unsigned du = udiv1(Z.ub), dl = udiv1(Z.lb);
     const int lo = (int)((uxl + du - 1u) / du), hi = (int)(uxu / dl);
@@ -164,7 +172,7 @@ __device__ __forceinline__ Cand evaluate_mul_nn(const Itv X, const Itv Y, const 
     const int lo = (int)((uxl + du - 1u) / du), hi = (int)(uxu / dl);
     if (dz) { c.zl = imax(c.zl, lo); c.zu = imin(c.zu, hi); }
   }
-  c.ent = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub && x_fin && Y.ub != PINF && Z.ub != PINF && (long long)X.lb == (long long)Y.lb * (long long)Z.lb;
+  c.ent = X.lb == X.ub && Y.lb == Y.ub && Z.lb == Z.ub && x_fin && Y.ub != PINF && Z.ub != PINF && X.lb == c.xl;  // (c.xl is y.lb * z.lb, saturated: a finite x never equals the saturated value)
   return c;
 }
 
