@@ -221,7 +221,8 @@ typedef struct {
   uint64_t eps_local_subproblems;
   int32_t kernel_event, kernel_opt; /* which kernel start() launches: event-driven fixpoint or sweeps; its option flag (event: 0 plain store,
                                      * 1 COMPACT, 2 COMPACT16, 3 plain store in global memory with its most-read intervals in LDS, 4 COMPACT8; sweeps: 0 plain,
-                                     * 1 entailed-slice removal, 2 COMPACT, 4 COMPACT16, 6 the hot tier) */
+                                     * 1 entailed-slice removal, 2 COMPACT, 4 COMPACT16, 6 the hot tier, 10 workgroup teams: the workgroups of an XCD share stores in
+                                     * global memory, one subproblem per team) */
 } tb_plan;
 int tb_session_plan(tb_session* s, tb_plan* plan_out);
 /*

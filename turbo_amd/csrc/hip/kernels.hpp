@@ -859,18 +859,7 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
       v = __builtin_amdgcn_readfirstlane(v);
       return (v >> 4) * TS + member_base + (v & 15) * 64;  // (16 waves per workgroup: the team plan is 1024 threads, engine.hip: team_mode)
     };
-    if (dyn) {
-      int b0 = take(), b1 = take(), b2 = take();
-      int4 q0 = props[imin(b0, last_base) + lane], q1 = props[imin(b1, last_base) + lane], q2 = props[imin(b2, last_base) + lane];
-      for (;;) {
-        if (b0 >= n) break;
-        { const int4 pr = q0; const int base = b0; b0 = take(); q0 = props[imin(b0, last_base) + lane]; wac1_step(pr, base); }
-        if (b1 >= n) break;
-        { const int4 pr = q1; const int base = b1; b1 = take(); q1 = props[imin(b1, last_base) + lane]; wac1_step(pr, base); }
-        if (b2 >= n) break;
-        { const int4 pr = q2; const int base = b2; b2 = take(); q2 = props[imin(b2, last_base) + lane]; wac1_step(pr, base); }
-      }
-    } else if (PREG && !wac1 && n > 0) {
+    if (PREG && !wac1 && n > 0) {
       int4 pr_next = props[imin(wave_base, last_base) + lane], pr_next2 = props[imin(wave_base + TS, last_base) + lane];
       Operands g_next = gather_operands<C>(store, P.n_int, pr_next);
       for (int base = wave_base; base < n; base += TS) {
@@ -897,11 +886,17 @@ __device__ __forceinline__ int fixpoint(const DevProblem& P, BlockShared& sh, in
         wac1_step(pr, base);
       }
     } else {
-      int4 q0 = props[imin(wave_base, last_base) + lane], q1 = props[imin(wave_base + TS, last_base) + lane], q2 = props[imin(wave_base + 2 * TS, last_base) + lane];  // (n > 0: WAC1 runs above its threshold)
-      for (int base = wave_base; base < n; base += 3 * TS) {
-        { const int4 pr = q0; q0 = props[imin(base + 3 * TS, last_base) + lane]; wac1_step(pr, base); }
-        if (base + TS < n) { const int4 pr = q1; q1 = props[imin(base + 4 * TS, last_base) + lane]; wac1_step(pr, base + TS); }
-        if (base + 2 * TS < n) { const int4 pr = q2; q2 = props[imin(base + 5 * TS, last_base) + lane]; wac1_step(pr, base + 2 * TS); }
+      // (one loop for both ways of dealing the slices -- every 16th per wave, or on demand: as a second loop the hand-out cost the plain sweeps of the same kernel 9 % through
+      //  its register allocation, wordpress7_500 -fp ac1 6.34e11 -> 5.74e11 propagations/s)
+      int b0 = dyn ? take() : wave_base, b1 = dyn ? take() : wave_base + TS, b2 = dyn ? take() : wave_base + 2 * TS;
+      int4 q0 = props[imin(b0, last_base) + lane], q1 = props[imin(b1, last_base) + lane], q2 = props[imin(b2, last_base) + lane];  // (n > 0: WAC1 runs above its threshold)
+      for (;;) {
+        if (b0 >= n) break;
+        { const int4 pr = q0; const int base = b0; b0 = dyn ? take() : b0 + 3 * TS; q0 = props[imin(b0, last_base) + lane]; wac1_step(pr, base); }
+        if (b1 >= n) break;
+        { const int4 pr = q1; const int base = b1; b1 = dyn ? take() : b1 + 3 * TS; q1 = props[imin(b1, last_base) + lane]; wac1_step(pr, base); }
+        if (b2 >= n) break;
+        { const int4 pr = q2; const int base = b2; b2 = dyn ? take() : b2 + 3 * TS; q2 = props[imin(b2, last_base) + lane]; wac1_step(pr, base); }
       }
     }
     const bool any_changed = wave_any(changed), any_un = wave_any(un);
