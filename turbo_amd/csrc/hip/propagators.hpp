@@ -289,7 +289,14 @@ __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y
   asm volatile("" : "+v"(cls));
   // predicates shared by the comparison classes
   const bool xt = X.lb >= 1, xf = X.ub <= 0;
-  if (present & ((1 << K_LEQ_T) | (1 << K_LEQ_F) | (1 << K_LEQ_R))) {
+  if (NNF == 1 && (present & ((1 << K_LEQ_T) | (1 << K_LEQ_F) | (1 << K_LEQ_R))) == (1 << K_LEQ_T)) {
+    // (r05, the kernels of stores in global memory, whose records keep the caller's order and whose slices therefore mix classes as a rule: the synthetic network's
+    //  comparisons are all `y <= z` and `y != z` with constant truth values -- the bodies for just those, without the reified and negated cases, are a third as long)
+    const bool t = cls == K_LEQ_T;
+    c.yu = sel(t, Z.ub, c.yu);
+    c.zl = sel(t, Y.lb, c.zl);
+    ent = t && Y.ub <= Z.lb;
+  } else if (present & ((1 << K_LEQ_T) | (1 << K_LEQ_F) | (1 << K_LEQ_R))) {
     // x = (y <= z); T/F: x is a constant of that value
     const bool t = cls == K_LEQ_T || (cls == K_LEQ_R && xt);
     const bool f = cls == K_LEQ_F || (cls == K_LEQ_R && xf);
@@ -303,7 +310,15 @@ __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y
     c.zu = sel(f, add_hi(Y.ub, -1), c.zu);
     ent = (t && le) || (f && gt);
   }
-  if (present & ((1 << K_EQ_T) | (1 << K_EQ_F) | (1 << K_EQ_R))) {
+  if (NNF == 1 && (present & ((1 << K_EQ_T) | (1 << K_EQ_F) | (1 << K_EQ_R))) == (1 << K_EQ_F)) {
+    const bool f = cls == K_EQ_F;  // y != z
+    const bool fy = f && Y.lb == Y.ub, fz = f && Z.lb == Z.ub;
+    c.yl = sel(fz && Y.lb == Z.lb, sat_add(Z.lb, 1), c.yl);
+    c.yu = sel(fz && Y.ub == Z.lb, sat_sub(Z.lb, 1), c.yu);
+    c.zl = sel(fy && Z.lb == Y.lb, sat_add(Y.lb, 1), c.zl);
+    c.zu = sel(fy && Z.ub == Y.lb, sat_sub(Y.lb, 1), c.zu);
+    ent = ent || (f && (Y.ub < Z.lb || Y.lb > Z.ub));
+  } else if (present & ((1 << K_EQ_T) | (1 << K_EQ_F) | (1 << K_EQ_R))) {
     // x = (y = z)
     const bool t = cls == K_EQ_T || (cls == K_EQ_R && xt);
     const bool f = cls == K_EQ_F || (cls == K_EQ_R && xf);
