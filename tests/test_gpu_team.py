@@ -73,6 +73,25 @@ def test_one_team_walks_the_oracles_tree_on_a_synthetic_network(team_env, fixpoi
         np.testing.assert_array_equal(best_g, best_o)
 
 
+@pytest.mark.parametrize("window", [0, 128, 4096])
+@pytest.mark.parametrize("fixpoint", [1, 0], ids=["wac1", "ac1"])
+def test_record_windows_do_not_change_the_tree(team_env, fixpoint, window):
+    """TB_GLOBAL_SORT_WINDOW: the records of a store in global memory class-sorted inside windows of W records (engine.hip: to_internal; 1024 by default for a team's plain
+    sweeps, the caller's order otherwise).  The order of the records changes how long the fixpoint takes, never what it is: same tree as the oracle's for every W."""
+    from turbo_amd.synth import make_synthetic
+    team_env.setenv("TB_TEAM_ALL", "1")
+    team_env.setenv("TB_GLOBAL_SORT_WINDOW", str(window))
+    tcn = make_synthetic(3000, 14000, seed=12)
+    power, cut = 2, 300
+    has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power, cutnodes=cut)
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(or_nodes=7, subproblems_power=power, stop_after_n_nodes=cut, timeout_ms=120000, fixpoint=fixpoint, **TEAM))
+    assert has_g == has_o
+    for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
+        assert st_g[k] == st_o[k], k
+    if has_o:
+        np.testing.assert_array_equal(best_g, best_o)
+
+
 @pytest.mark.parametrize("rule", [0, 1], ids=["barebones_rule", "gpu_rule"])
 def test_one_team_under_both_leaf_rules(team_env, rule):
     team_env.setenv("TB_TEAM_ALL", "1")
