@@ -33,31 +33,44 @@ $(LIBDIR)/libturbo_front.so: $(FRONT_SRC) $(FRONT_HDR)
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(FRONT_SRC)
 
-$(LIBDIR)/libturbo_hip.so: $(HIP_SRC) $(HIP_HDR)
-	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+# The engine's ~90 kernel instantiations are dealt to nine translation units (turbo_amd/csrc/hip/kernel_units.hpp): `make -j8` builds a library in the time of its
+# slowest unit (~1.5 min) instead of 4-6 minutes of one core.  Objects under build/obj/<variant>/ (scratch, not shipped); the .so files are what travels.
+UNITS := 1 2 3 4 5 6 7 8 9
+HIP_DIR := turbo_amd/csrc/hip
+HIP_DEP := $(HIP_HDR) $(HIP_DIR)/kernel_units.inc
+define HIP_VARIANT  # $(1) = variant name, $(2) = extra flags, $(3) = library file
+build/obj/$(1)/engine.o: $(HIP_SRC) $$(HIP_DEP)
+	@mkdir -p build/obj/$(1)
+	$$(HIPCC) $$(HIPFLAGS) $(2) -c -o $$@ $(HIP_SRC)
+build/obj/$(1)/unit_%.o: $(HIP_DIR)/unit_%.hip $$(HIP_DEP)
+	@mkdir -p build/obj/$(1)
+	$$(HIPCC) $$(HIPFLAGS) $(2) -c -o $$@ $$<
+$(3): build/obj/$(1)/engine.o $$(foreach n,$$(UNITS),build/obj/$(1)/unit_$$(n).o)
+	@mkdir -p $$(LIBDIR)
+	$$(HIPCC) $$(HIPFLAGS) -shared -o $$@ $$^
+endef
+$(eval $(call HIP_VARIANT,hip,,$(LIBDIR)/libturbo_hip.so))
 
 # the same engine with the device-side tuning / profiling knobs of tb_config.reserved[0] compiled in (scripts/*_probe.py;
 # select it with TURBO_HIP_LIB=turbo_amd/lib/libturbo_hip_tuning.so)
 tuning: $(LIBDIR)/libturbo_hip_tuning.so
-$(LIBDIR)/libturbo_hip_tuning.so: $(HIP_SRC) $(HIP_HDR)
-	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -DTB_TUNING -shared -o $@ $(HIP_SRC)
+$(eval $(call HIP_VARIANT,tuning,-DTB_TUNING,$(LIBDIR)/libturbo_hip_tuning.so))
 
 # the same engine with a range check in front of every index the kernels form from host-packed fields (kernels.hpp: TB_BOUNDS): a report
 # {site, index, limit, workgroup} instead of a memory fault.  scripts/bounds_soak.py runs the bench workloads and the fuzz families on it.
+# (one translation unit: the report lives in `__device__` variables the host shim and every kernel share)
 bounds: $(LIBDIR)/libturbo_hip_bounds.so
-$(LIBDIR)/libturbo_hip_bounds.so: $(HIP_SRC) $(HIP_HDR)
+$(LIBDIR)/libturbo_hip_bounds.so: $(HIP_SRC) $(HIP_DEP)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -DTB_BOUNDS -shared -o $@ $(HIP_SRC)
+	$(HIPCC) $(HIPFLAGS) -DTB_BOUNDS -DTB_SINGLE_TU -shared -o $@ $(HIP_SRC)
 
 # one library per phase of the event kernels, each the production kernels with exactly that phase executed twice (compile-time choice:
 # scripts/phase_budget.py measures the difference in SQ_INSTS_* to the production library)
 PHASES := 1 2 3 4 5 6 7 8 9 10 11 12 13 14
 phases: $(foreach n,$(PHASES),$(LIBDIR)/phases/phase_$(n).so)
-$(LIBDIR)/phases/phase_%.so: $(HIP_SRC) $(HIP_HDR)
+$(LIBDIR)/phases/phase_%.so: $(HIP_SRC) $(HIP_DEP)
 	@mkdir -p $(LIBDIR)/phases
-	$(HIPCC) $(HIPFLAGS) -DTB_DOUBLE_PHASE=$* -shared -o $@ $(HIP_SRC)
+	$(HIPCC) $(HIPFLAGS) -DTB_DOUBLE_PHASE=$* -DTB_SINGLE_TU -shared -o $@ $(HIP_SRC)
 
 $(BINDIR)/turbo: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libturbo_front.so $(LIBDIR)/libturbo_hip.so
 	@mkdir -p $(BINDIR)

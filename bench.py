@@ -64,7 +64,7 @@ def pinned_core() -> int | None:
         return None
 
 
-def cpu_baseline(tcn, subproblems_power: int, seconds: float) -> dict:
+def cpu_baseline(tcn, subproblems_power: int, seconds: float, leaf_rule: str = "barebones") -> dict:
     """The oracle (CPU restatement of cpu_solving.hpp) on a bounded sample of the SAME node population the GPU step
     explores: the same 2^d EPS decomposition walked in index order (dive nodes + solve nodes of the first subproblems),
     1 core, pinned, built -O3 -march=native on this machine.  The plain DFS (the reference's own `-arch cpu` order) is a
@@ -80,9 +80,12 @@ def cpu_baseline(tcn, subproblems_power: int, seconds: float) -> dict:
         pyoracle.use_library(native)
     core = pinned_core()
     try:
-        # (cpu_solving.hpp:36 calls a node a solution only when the store is extractable: the cpu path's leaf rule, whatever rule the GPU rows ran)
-        _, _, st = pyoracle.solve(tcn, subproblems_power=subproblems_power, timeout_ms=int(seconds * 1000), leaf_requires_assignment=1)
-        _, _, dfs = pyoracle.solve(tcn, subproblems_power=0, timeout_ms=int(seconds * 300), leaf_requires_assignment=1)
+        # The CPU leg walks the SAME tree as the GPU rows: the leaf rule of the GPU rows (`--leaf-rule`; r05 always ran cpu_solving.hpp:36's rule here, under which an
+        # all-entailed box with open variables is an inner node -- a different tree wherever such boxes occur; on a bounded sample of the headline instance none does
+        # and the measured rates were identical, but "like for like" should not rest on that).  The rule is recorded in the row.
+        lra = int(leaf_rule == "gpu")
+        _, _, st = pyoracle.solve(tcn, subproblems_power=subproblems_power, timeout_ms=int(seconds * 1000), leaf_requires_assignment=lra)
+        _, _, dfs = pyoracle.solve(tcn, subproblems_power=0, timeout_ms=int(seconds * 300), leaf_requires_assignment=lra)
     finally:
         if before is not None:
             try:
@@ -98,8 +101,9 @@ def cpu_baseline(tcn, subproblems_power: int, seconds: float) -> dict:
     return {"value": st["num_deductions"] / secs, "unit": "propagations/s", "cores": 1, "kind": "port",
             "nodes_per_sec": st["nodes"] / secs,
             "sample": f"first {secs:.1f} s of the sequential walk over the same 2^{subproblems_power} EPS subproblems the GPU step explores "
-                      f"(dive + solve nodes, AC1 Gauss-Seidel, leaf rule of cpu_solving.hpp:36): {st['nodes']} nodes, {st['num_deductions']} propagations, "
+                      f"(dive + solve nodes, AC1 Gauss-Seidel, leaf rule of -arch {leaf_rule}, the same as the GPU rows): {st['nodes']} nodes, {st['num_deductions']} propagations, "
                       f"{st['eps_solved_subproblems'] + st['eps_skipped_subproblems']} subproblems done",
+            "leaf_rule": leaf_rule,
             "build": "gcc -O3 -march=native (built on this host)" if native else "gcc -O3 (prebuilt, portable)",
             "pinned_core": core, "host_cpus": os.cpu_count(), "cpu_model": model,
             "dfs_sample": {"value": dfs["num_deductions"] / dsecs, "nodes_per_sec": dfs["nodes"] / dsecs,
@@ -146,7 +150,7 @@ def reference_invocation(seconds: float) -> dict:
 def profile_figures(workload: str, fixpoint: str) -> dict | None:
     """Counter-derived figures of the same command, collected by scripts/profile_round.sh in separate rocprofv3 --pmc
     passes and committed under profiles/ (they are NOT measured in this run: the source file is named)."""
-    for name in ("r05_counters.json", "r04_counters.json", "r03_counters.json", "r02_counters.json"):
+    for name in ("r06_counters.json", "r05_counters.json", "r04_counters.json", "r03_counters.json", "r02_counters.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -160,18 +164,29 @@ def profile_figures(workload: str, fixpoint: str) -> dict | None:
 
 
 def roofline_record(info: dict, mem_kind: int, props: float, writes: float, kernel_s: float) -> dict:
-    """algorithmic bytes per propagation = 16 B record + 3 x 8 B domains (+ 8 B per narrowed bound).  The level that serves the
-    domains bounds the kernel's memory side: LDS when the store is LDS resident (records from L2), HBM when the store lives in global memory.
-    Every fraction is achieved / peak of THAT level, so it cannot exceed 1.  `props`, `writes`: per launch; `kernel_s`: average launch duration."""
+    """algorithmic bytes per propagation = 16 B record + 3 x 8 B domains (+ 8 B per narrowed bound).  `levels` prices the algorithmic bytes each level of
+    the memory system would have to serve against THAT level's peak (so no fraction can exceed 1); `bound` names the level that actually serves the domains:
+    "lds" when the store is LDS resident (records then come from the L2), and for a store in global memory "hbm" until attach_counters() has looked at the counters of
+    the same command -- an L2 hit rate above one half and fabric reads well under the 40 algorithmic bytes per propagation mean the L2 serves the kernel, and `bound` /
+    `frac` / `peak` are switched to that level (the team rows read "0.68 of HBM" while HBM carried 0.11 of its peak).
+    `props`, `writes`: per launch; `kernel_s`: average launch duration."""
     lds_peak = info["compute_units"] * LDS_BYTES_PER_CLK_CU * info["clock_khz"] * 1e3 / 1e9
-    dom_gbps = (props * DOMAIN_BYTES + writes * 8) / max(kernel_s, 1e-12) / 1e9
-    rec_gbps = props * RECORD_BYTES / max(kernel_s, 1e-12) / 1e9
+    dt = max(kernel_s, 1e-12)
+    dom_gbps = (props * DOMAIN_BYTES + writes * 8) / dt / 1e9
+    rec_gbps = props * RECORD_BYTES / dt / 1e9
+    alg = dom_gbps + rec_gbps
     if mem_kind != 0:
-        roof = {"bound": "lds", "achieved": dom_gbps, "peak": lds_peak, "unit": "GB/s", "frac": dom_gbps / lds_peak,
+        levels = {"lds": {"what": "3 x 8 B domains per propagation + 8 B per narrowed bound", "achieved": dom_gbps, "peak": lds_peak, "frac": dom_gbps / lds_peak},
+                  "l2": {"what": "16 B record per propagation", "achieved": rec_gbps, "peak": L2_PEAK_GBPS, "frac": rec_gbps / L2_PEAK_GBPS},
+                  "hbm": {"what": "nothing in steady state (records and snapshot slabs are L2 / Infinity Cache resident); measured bytes: hbm_counters", "achieved": None, "peak": HBM_PEAK_GBPS, "frac": None}}
+        roof = {"bound": "lds", "achieved": dom_gbps, "peak": lds_peak, "unit": "GB/s", "frac": dom_gbps / lds_peak, "levels": levels,
                 "records_from_l2": {"achieved": rec_gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": rec_gbps / L2_PEAK_GBPS}}
     else:
-        alg = dom_gbps + rec_gbps
-        roof = {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBPS}
+        levels = {"lds": {"what": "the hot tier's share of the gathers (event kernel of a store in global memory), not counted separately", "achieved": None, "peak": lds_peak, "frac": None},
+                  "l2": {"what": "all 40 B per propagation (+ writes) if the L2 serves them", "achieved": alg, "peak": L2_PEAK_GBPS, "frac": alg / L2_PEAK_GBPS},
+                  "hbm": {"what": "all 40 B per propagation (+ writes) if every access went to memory", "achieved": alg, "peak": HBM_PEAK_GBPS, "frac": alg / HBM_PEAK_GBPS}}
+        roof = {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBPS, "levels": levels,
+                "bound_chosen_by": "residence (no counters of this command found under profiles/)"}
     roof.update({"traffic": None, "kernel": "tb::solve_kernel", "avg_launch_ms": kernel_s * 1000.0,
                  "algorithmic_bytes_per_launch": props * (RECORD_BYTES + DOMAIN_BYTES) + writes * 8})
     return roof
@@ -189,6 +204,18 @@ def attach_counters(roof: dict, workload: str, fixpoint: str, launch_s: float) -
         roof["traffic_note"] = ("(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B of the counter passes named in traffic_source, per launch, scaled by this run's launch duration over "
                                 "the profiled one; MALL hits included (the guide's correction for 16-byte-per-lane streams)")
     roof["hbm_counters"] = {k: prof[k] for k in ("hbm_bytes_per_launch", "hbm_gbps", "hbm_frac_of_peak", "launch_ms", "tcc_hit_rate", "fabric_read_bytes_per_propagation") if k in prof}
+    if "hbm" in roof.get("levels", {}) and prof.get("hbm_gbps") is not None:
+        roof["levels"]["hbm"]["measured_gbps"] = prof["hbm_gbps"]
+        roof["levels"]["hbm"]["measured_frac"] = prof["hbm_gbps"] / HBM_PEAK_GBPS
+    if roof["bound"] == "hbm":
+        # a store in global memory: which level serves the gathers is a measured fact, not a property of the plan
+        hit, fab = prof.get("tcc_hit_rate"), prof.get("fabric_read_bytes_per_propagation")
+        if hit is not None:
+            served_by_l2 = hit >= 0.5 and (fab is None or fab < 0.5 * (RECORD_BYTES + DOMAIN_BYTES))
+            lvl = "l2" if served_by_l2 else "hbm"
+            roof.update({"bound": lvl, "peak": roof["levels"][lvl]["peak"], "frac": roof["levels"][lvl]["frac"],
+                         "bound_chosen_by": f"counters of the same command ({prof.get('source')}): L2 hit rate {hit:.2f}" + (f", {fab:.1f} B of fabric reads per propagation" if fab is not None else "")
+                                            + (" -- the L2 serves the 40 algorithmic bytes" if served_by_l2 else " -- most gathers go to memory")})
     roof["issue"] = {k: prof[k] for k in ("valu_busy", "salu_busy", "lds_busy", "wait_any_share", "wait_inst_any_share",
                                           "valu_per_64_propagations", "salu_per_64_propagations", "valu_per_node", "salu_per_node", "icache_hit_rate") if k in prof}
     roof["issue"]["note"] = "binding resource; rocprofv3 --pmc SQ_* passes of this command, not measured in this run"
@@ -211,15 +238,24 @@ SOLVE_DEFAULTS = {
 }
 
 
-def solve_mode(args, tcn, fzn, rank, world, local_rank, dist, tdev, capi, tdist, torch) -> int:
-    """Whole searches instead of node budgets: what `reduce_blocks` (barebones:1033-1067) and `first_block_idle_time` (barebones:887-894) are about.
-    Every rank runs this collectively; rank 0 prints one JSON line."""
-    d_bound, d_target, d_power = SOLVE_DEFAULTS[args.workload]
-    bound = args.fixed_bound if args.fixed_bound is not None else d_bound
-    target = args.target if args.target is not None else d_target
-    power = args.subproblems_power if args.subproblems_power >= 0 else d_power
+def share_of_device(args, tcn, base: dict, world: int, capi) -> int:
+    """--share-device (the one-GPU stand-in for an N-GPU node): N full-grid persistent kernels of N processes are NOT co-resident on one GPU -- the second one's
+    workgroups only start when the first one's leave, and `tb_session_start` of the second rank (a clock kernel on its stream) waits behind the first rank's search --
+    so every rank takes 1/N of the workgroups the engine would launch: the ranks then run side by side like N smaller GPUs.  Returns the or_nodes to use (0: as planned)."""
+    if not args.share_device or world <= 1 or base.get("or_nodes", 0) != 0:
+        return base.get("or_nodes", 0)
+    probe = capi.Session(tcn, capi.make_config(**base))
+    blocks = probe.plan()["num_blocks"]
+    probe.close()
+    return max(1, blocks // world)
+
+
+def make_search_runner(args, tcn, rank, world, local_rank, dist, tdev, capi, tdist, torch, power: int):
+    """Whole searches instead of node budgets (`--mode solve`, and the `sharded_search` record of the default line): returns run(cfg_extra, stop_at) -> record.
+    Every rank calls run() collectively."""
     base = dict(fixpoint=FP_CODE[args.fixpoint], or_nodes=args.or_nodes, threads_per_block=args.threads, timeout_ms=int(args.solve_timeout * 1000), device=local_rank,
                 rank=rank, world_size=world, debug=args.debug_bits, subproblems_power=power, leaf_requires_assignment=int(args.leaf_rule == "gpu"))
+    base["or_nodes"] = share_of_device(args, tcn, base, world, capi)
 
     def run(cfg_extra: dict, stop_at: int | None):
         sess = capi.Session(tcn, capi.make_config(**base, **cfg_extra))
@@ -232,12 +268,18 @@ def solve_mode(args, tcn, fzn, rank, world, local_rank, dist, tdev, capi, tdist,
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         sess.start()
-        first_hit = None
+        t_started = time.perf_counter() - t0
+        first_hit, t_stop_seen = None, None
         if world > 1:
             # collective loop over the gloo side group: agrees on the group's incumbent, relays it when the cells are not linked, ends every rank together
-            gbest, _ = tdist.exchange_until_done(sess, dist, period_s=0.0005, max_seconds=args.solve_timeout, target=stop_at)
+            trace = {}
+            gbest, _ = tdist.exchange_until_done(sess, dist, period_s=0.0005, max_seconds=args.solve_timeout, target=stop_at, trace=trace)
+            if trace.get("t_target") is not None:
+                first_hit = trace["t_target"] - t0   # the round in which the GROUP's incumbent was first <= target (the same round on every rank)
+            t_own_done = (trace["t_own_done"] - t0) if trace.get("t_own_done") is not None else None
         else:
             gbest = 2**31 - 1
+            t_own_done = None
             while True:
                 best, done = sess.poll()
                 gbest = min(gbest, best)
@@ -245,8 +287,10 @@ def solve_mode(args, tcn, fzn, rank, world, local_rank, dist, tdev, capi, tdist,
                     first_hit = time.perf_counter() - t0
                     sess.stop()
                 if done:
+                    t_own_done = time.perf_counter() - t0
                     break
                 time.sleep(0.0005)
+        t_loop = time.perf_counter() - t0
         has, best, st = sess.finish()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
@@ -258,7 +302,9 @@ def solve_mode(args, tcn, fzn, rank, world, local_rank, dist, tdev, capi, tdist,
         row = {"kernel_ms": st["kernel_ns"] * 1e-6, "nodes": st["nodes"], "eps_solved": st["eps_solved_subproblems"], "eps_skipped": st["eps_skipped_subproblems"],
                "stolen_subproblems": st["eps_stolen_subproblems"], "wait_share": st["wait_time_ns"] / max(1, st["cumulative_time_block_ns"]),
                "first_block_idle_ms": st["min_block_ns"] * 1e-6, "last_block_ms": st["max_block_ns"] * 1e-6, "blocks_done": st["num_blocks_done"],
-               "exhaustive": st["exhaustive"], "has_solution": int(has), "best_bound": st["best_bound"] if has else 2**31 - 1, "propagations": st["num_deductions"]}
+               "exhaustive": st["exhaustive"], "has_solution": int(has), "best_bound": st["best_bound"] if has else 2**31 - 1, "propagations": st["num_deductions"],
+               # per-rank timeline (host clock, seconds after the group's barrier): launch call returned / this rank's kernel seen finished / the agreement loop left
+               "t_start_returned_s": t_started, "t_own_kernel_done_s": t_own_done if t_own_done is not None else -1.0, "t_loop_left_s": t_loop}
         per_rank = tdist.gather_rank_rows(row, dist if world > 1 else None, tdev)
         sess.close()
         tot = {k: sum(r[k] for r in per_rank) for k in ("nodes", "eps_solved", "eps_skipped", "stolen_subproblems", "propagations")}
@@ -270,12 +316,27 @@ def solve_mode(args, tcn, fzn, rank, world, local_rank, dist, tdev, capi, tdist,
                "nodes_per_sec": tot["nodes"] / max(wall, 1e-9), "per_rank": per_rank}
         return rec
 
+    return run
+
+
+PROOF_WHAT = ("canonical pass under the constant constraint objective <= B: no incumbent is exchanged, the tree is the same at every N; "
+              "exhaustive and no solution = B is proved infeasible (every subproblem solved or skipped exactly once)")
+
+
+def solve_mode(args, tcn, fzn, rank, world, local_rank, dist, tdev, capi, tdist, torch) -> int:
+    """Whole searches instead of node budgets: what `reduce_blocks` (barebones:1033-1067) and `first_block_idle_time` (barebones:887-894) are about.
+    Every rank runs this collectively; rank 0 prints one JSON line."""
+    d_bound, d_target, d_power = SOLVE_DEFAULTS[args.workload]
+    bound = args.fixed_bound if args.fixed_bound is not None else d_bound
+    target = args.target if args.target is not None else d_target
+    power = args.subproblems_power if args.subproblems_power >= 0 else d_power
+    run = make_search_runner(args, tcn, rank, world, local_rank, dist, tdev, capi, tdist, torch, power)
+
     out = {"mode": "solve", "n_gpus": world, "workload": fzn, "fixpoint": args.fixpoint, "leaf_rule": args.leaf_rule, "scaling": "strong", "data": "reference instance file (no randomness)"}
     if bound is not None:
         rec = run(dict(use_fixed_bound=1, fixed_bound=int(bound)), None)
         rec["fixed_bound"] = int(bound)
-        rec["what"] = ("canonical pass under the constant constraint objective <= B: no incumbent is exchanged, the tree is the same at every N; "
-                       "exhaustive and no solution = B is proved infeasible (every subproblem solved or skipped exactly once)")
+        rec["what"] = PROOF_WHAT
         out["proof"] = rec
     if target is not None or bound is None:
         rec = run(dict(), target)
@@ -343,6 +404,8 @@ def main() -> int:
     ap.add_argument("--fixed-bound", type=int, default=None, help="--mode solve: the bound B of the proof run (default: per workload, SOLVE_DEFAULTS)")
     ap.add_argument("--target", type=int, default=None, help="--mode solve: the target objective of the time-to-target run (default: per workload)")
     ap.add_argument("--solve-timeout", type=float, default=120.0, help="--mode solve: give up after this many seconds per run")
+    ap.add_argument("--sharded-search", type=int, default=1, help="append the `sharded_search` record (proof under a fixed bound: fixed total work) to the default line (0 = skip)")
+    ap.add_argument("--sharded-reps", type=int, default=2, help="runs of the sharded search (the fastest is reported, all are listed)")
     ap.add_argument("--debug-bits", type=lambda v: int(v, 0), default=0, help="tuning knobs of tb_config.reserved[0] (experiments only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -408,9 +471,11 @@ def main() -> int:
         tcn = tcn if tcn is not None else main_tcn
         linked = world > 1 and args.exchange == "peer"
         per_rank_budget = budget if (world == 1 or linked) else max(1, budget // world)  # unlinked ranks count on their own
-        cfg = capi.make_config(fixpoint=FP_CODE[fixpoint], stop_after_n_nodes_total=per_rank_budget, stop_after_n_nodes=args.cutnodes,
-                               or_nodes=args.or_nodes, threads_per_block=args.threads, timeout_ms=600000, device=local_rank, rank=rank, world_size=world, debug=args.debug_bits,
-                               subproblems_power=args.subproblems_power, leaf_requires_assignment=int(args.leaf_rule == "gpu"))
+        kw = dict(fixpoint=FP_CODE[fixpoint], stop_after_n_nodes_total=per_rank_budget, stop_after_n_nodes=args.cutnodes,
+                  or_nodes=args.or_nodes, threads_per_block=args.threads, timeout_ms=600000, device=local_rank, rank=rank, world_size=world, debug=args.debug_bits,
+                  subproblems_power=args.subproblems_power, leaf_requires_assignment=int(args.leaf_rule == "gpu"))
+        kw["or_nodes"] = share_of_device(args, tcn, kw, world, capi)  # (--share-device: 1/N of the workgroups each, so that the N kernels are co-resident)
+        cfg = capi.make_config(**kw)
         sess = capi.Session(tcn, cfg)  # inputs uploaded to HBM here, outside the timed region
         tdist.agree_on_plan(sess, dist, tdev)
         if linked:
@@ -546,6 +611,21 @@ def main() -> int:
                                "subproblems_power": pl2["subproblems_power"], "kernel_opt": pl2["kernel_opt"], "roofline": roof2, "load_and_simplify_s": t_load})
                 sess2.close()
 
+    # The sharded search itself, in the DEFAULT command: the node-budget steps above measure N kernels' node rate -- on the headline instance no
+    # subproblem completes inside a step, so queue, subtree skips, stealing never enter `value`.  This record is a WHOLE search of fixed total work: the proof that
+    # `objective <= B` is infeasible (B below the optimum, a constant constraint: no incumbent travels, the tree is the same at every N), every one of the 2^d
+    # subproblems solved or skipped exactly once whichever GPU takes it.  Its `seconds` at N = 1, 2, 4, 8 IS the strong-scaling curve of the sharded search.
+    sharded = None
+    if args.sharded_search and SOLVE_DEFAULTS.get(args.workload, (None,))[0] is not None and args.fixpoint == "event":
+        session.close()  # one persistent search at a time
+        d_bound, _, d_power = SOLVE_DEFAULTS[args.workload]
+        runner = make_search_runner(args, main_tcn, rank, world, local_rank, dist, tdev, capi, tdist, torch, d_power)
+        runner(dict(use_fixed_bound=1, fixed_bound=int(d_bound)), None)  # warm-up (code object, allocations)
+        reps = [runner(dict(use_fixed_bound=1, fixed_bound=int(d_bound)), None) for _ in range(max(1, args.sharded_reps))]
+        sharded = min(reps, key=lambda r: r["seconds"])
+        sharded.update({"fixed_bound": int(d_bound), "what": PROOF_WHAT, "seconds_all_runs": [r["seconds"] for r in reps], "scaling": "strong",
+                        "metric": "seconds of the whole sharded search that refutes objective <= B (fixed total work at every N; lower is better)"})
+
     if rank == 0:
         kernel_s = tot["kernel_ns"] * 1e-9 / steps                 # average launch duration of solve_kernel (HIP events on its stream, rank 0)
         props = tot["num_deductions"] / steps                     # propagations of one launch, rank 0
@@ -592,14 +672,18 @@ def main() -> int:
             out[f"{side['fixpoint']}_mode"] = side
         if others:
             out["other_workloads"] = others
+        if sharded is not None:
+            out["sharded_search"] = sharded
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tcn, plan["subproblems_power"], args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(tcn, plan["subproblems_power"], args.cpu_seconds, args.leaf_rule)
             out["speedup_vs_cpu_baseline"] = {"propagations": out["value"] / max(out["cpu_baseline"]["value"], 1e-9),
                                               "nodes": out["nodes_per_sec"] / max(out["cpu_baseline"]["nodes_per_sec"], 1e-9)}
             ac1 = next((sd for sd in sides if sd["fixpoint"] == "ac1"), None)
             if ac1 is not None:  # the same fixpoint loop on both sides (`-fp ac1` on the GPU, AC1 on the CPU)
                 out["speedup_vs_cpu_baseline"]["ac1_like_for_like"] = {"propagations": ac1["propagations_per_sec"] / max(out["cpu_baseline"]["value"], 1e-9),
-                                                                       "nodes": ac1["nodes_per_sec"] / max(out["cpu_baseline"]["nodes_per_sec"], 1e-9)}
+                                                                       "nodes": ac1["nodes_per_sec"] / max(out["cpu_baseline"]["nodes_per_sec"], 1e-9),
+                                                                       "note": f"same fixpoint loop (AC1) and same leaf rule (-arch {args.leaf_rule}) on both sides; the GPU walks its "
+                                                                               "subproblems in parallel, the CPU in index order"}
         if world == 1 and args.workload == "wordpress7_500" and args.reference_seconds > 0:
             session.close()  # the CLI run gets the whole GPU
             out["reference_invocation"] = reference_invocation(args.reference_seconds)

@@ -141,6 +141,80 @@ def test_teams_per_xcd_and_barrier_flavours(team_env, rel, expected, split, rela
         assert st_g[k] == st_o[k], k
 
 
+@pytest.mark.parametrize("or_nodes", [1, 3, 8, 24])
+def test_small_grids_of_real_xcd_teams_keep_to_their_own_slabs(team_env, or_nodes):
+    """r05 indexed a team's store and snapshot stack by XCD x split + k -- up to 31 (63 with eight teams per XCD) -- while g_store / g_snap hold one slab per
+    WORKGROUP: a grid smaller than that (`-or 8`) wrote past their end.  The slabs are now those of the team's leader.  Grids of 1, 3, 8 and 24 workgroups, teams formed from the
+    XCDs they really land on (no TB_TEAM_ALL), eight teams per XCD too: the known optimum, every subproblem exactly once, and with one workgroup the oracle's tree."""
+    rows = [r for r in FAST if r[0].split("/")[-1] in ("pat2.fzn", "pennies5.fzn", "sudoku_opt4.fzn")]
+    for split in (4, 8):
+        team_env.setenv("TB_TEAM_SPLIT", str(split))
+        for rel, expected in rows:
+            tcn = frontend.load_fzn(os.path.join(BENCH, rel))
+            cfg = dict(or_nodes=or_nodes, subproblems_power=6, timeout_ms=120000, fixpoint=1, **TEAM)
+            assert plan_of(tcn, **cfg)["kernel_opt"] == 10 and plan_of(tcn, **cfg)["num_blocks"] == or_nodes
+            has, best, st = capi.solve(tcn, capi.make_config(**cfg))
+            assert has and st["exhaustive"] == 1 and tcn.objective_of(best) == expected, (rel, split)
+            assert st["eps_solved_subproblems"] + st["eps_skipped_subproblems"] == 64
+            _, failed, ent, _, _ = pyoracle.propagate(best, tcn.props)
+            assert not failed and ent
+            if or_nodes == 1:
+                has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=6)
+                for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
+                    assert st[k] == st_o[k], (rel, k)
+                np.testing.assert_array_equal(best, best_o)
+
+
+JOIN_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, os.environ["TB_ROOT"])
+from turbo_amd import capi, frontend
+from turbo_amd.synth import make_synthetic
+TEAM = dict(only_global_memory=1, threads_per_block=1024)
+cus = capi.device_info(0)["compute_units"]
+tcn = make_synthetic(30000, 120000, seed=7)
+big = capi.Session(tcn, capi.make_config(fixpoint=1, timeout_ms=0, or_nodes=cus // 2, **TEAM))   # one 1024-thread workgroup on half of the CUs, until told to stop
+os.environ["TB_TEAM_JOIN_MS"] = "1"
+small = frontend.load_fzn(os.path.join(os.environ["TB_ROOT"], "benchmarks", "test_data", "pat7.fzn"))
+late = capi.Session(small, capi.make_config(fixpoint=1, timeout_ms=0, **TEAM))                      # one workgroup per CU: half of them cannot become resident beside the first grid
+assert late.plan()["kernel_opt"] == 10 and late.plan()["num_blocks"] == cus, late.plan()
+big.start()
+time.sleep(0.5)
+late.start()
+t0 = time.time()
+while not late.poll()[1]:
+    assert time.time() - t0 < 60, "the second team kernel hangs"
+    time.sleep(0.01)
+try:
+    late.finish()
+    print("RESULT no error")
+except capi.TurboHipError as e:
+    print("RESULT", e)
+late.close()
+big.stop()
+while not big.poll()[1]:
+    time.sleep(0.01)
+has, best, st = big.finish()
+print("BIG nodes", st["nodes"])
+big.close()
+"""
+
+
+def test_a_grid_that_never_becomes_resident_is_reported_not_waited_for():
+    """team formation waits for every workgroup of the grid to register, and the launch is an ordinary one.  With the limit of the wait set to 1 ms
+    (TB_TEAM_JOIN_MS) and a first search holding half of the CUs, the second session's team kernel (one workgroup per CU: half of them cannot become resident) must come
+    back with TB_ERR_STATE "team formation failed" -- no hang, whatever timeout_ms is -- and the first search must be unharmed.  In a process of its own: a hang must not
+    take the suite with it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(BENCH)
+    p = subprocess.run([sys.executable, "-c", JOIN_SCRIPT], env=dict(os.environ, TB_ROOT=root, TB_TEAM="1"), capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "RESULT" in p.stdout and "team formation failed" in p.stdout, p.stdout[-2000:]
+    big = [l for l in p.stdout.splitlines() if l.startswith("BIG nodes")]
+    assert big and int(big[0].split()[-1]) > 0
+
+
 def test_teams_enumerate_every_solution_once(team_env):
     from test_gpu_streaming import MANY, run_streaming
     tcn = frontend.Model.from_string(MANY).tcn()

@@ -110,8 +110,8 @@ struct alignas(64) TeamCtl {
   unsigned flags;       // barrier: OR of the members' contributions
   unsigned gen;         // barrier generation
   unsigned result[2];   // merged flags of generation g in result[g & 1]
-  unsigned pad[2];
-  unsigned long long bcast[4];  // leader -> members (subproblem, bound), read between two barriers
+  unsigned pad[2];      // pad[0]: blockIdx of the team's leader (whose slabs of g_store / g_snap the team works on), written at team formation
+  unsigned long long bcast[4];  // leader -> members (subproblem, bound, the final verdict), read between two barriers
 };
 struct alignas(64) TeamGrid {
   unsigned registered;      // workgroups of the grid that have joined a team
@@ -226,10 +226,16 @@ struct DevProblem {
   TeamGrid* teams;           // store layout 5: the per-XCD team control blocks (nullptr otherwise)
   int team_all, team_split;  // store layout 5.  team_all, test aid (TB_TEAM_ALL=1): the whole grid is ONE team whatever the XCDs (agent-scope accesses are coherent device-wide: slower,
                              // same results); team_split (TB_TEAM_SPLIT, 1 / 2 / 4): teams per XCD -- more independent searches, fewer members per barrier, k stores in the XCD's L2
-  int team_relaxed, pad_team; // team barrier with relaxed agent-scope atomics and an explicit wait for the wave's own memory operations instead of acq_rel fences (TB_TEAM_RELAXED=1)
+  int team_relaxed;           // team barrier with relaxed agent-scope atomics and an explicit wait for the wave's own memory operations instead of acq_rel fences (TB_TEAM_RELAXED=1)
+  int team_join_ticks;        // wall-clock ticks a workgroup waits for the whole grid to register before it gives up (kernels.hpp: team_join; 10 s, TB_TEAM_JOIN_MS)
   PeerCell* cell;            // this device's cell
   PeerCell* const* peers;    // [world] cells of every rank (peers[rank] == cell; nullptr = not reachable), device array
   SolutionRing ring;
+  // Basic-block execution counts of an INSTRUMENTED build (scripts/instr_blocks.py rewrites the compiled assembly of the headline kernels: one s_atomic_add per straight-line
+  // segment into this array, one copy per XCD, BLK_COUNT_STRIDE bytes apart).  No compiled C++ code reads it: the rewritten kernels fetch it from the kernel arguments by
+  // its offset.  nullptr unless TB_BLOCK_COUNTS is set when the session is created.
+  unsigned* blk_counts;
 };
+constexpr size_t BLK_COUNT_STRIDE = 1u << 16;  // bytes per XCD copy (16 384 segments)
 
 }  // namespace tb

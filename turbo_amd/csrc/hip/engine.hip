@@ -20,7 +20,10 @@
 #include <thread>
 #include <vector>
 
-#include "kernels.hpp"
+#include "kernel_units.hpp"
+#ifdef TB_SINGLE_TU
+#include "kernel_units.inc"
+#endif
 
 using namespace tb;
 
@@ -71,9 +74,7 @@ int query_caps(int device, DeviceCaps* caps) {
 
 // ---- launch planning -----------------------------------------------------------------------------
 
-constexpr int TEAM_SWEEP_OPT = 10;  // kernel_opt of a plan that searches in workgroup teams (sweeps, layout 5 << 1)
 constexpr long TEAM_AC1_SORT_WINDOW = 1024;  // records per window of the class sort for a team's plain sweeps (to_internal): one workgroup's 16 slices
-constexpr int HOT_EVENT_OPT = 3, HOT_SWEEP_OPT = 6;  // kernel_opt of a plan with the hot tier (event: the layout; sweeps: layout << 1)
 struct LaunchPlan {
   int threads = 256, tmax = 256;
   int blocks_per_cu = 1, num_blocks = 1;
@@ -919,89 +920,31 @@ void find_constants(int32_t n_vars, int32_t n_stores, const tb_itv* stores, std:
   }
 }
 
-template <int MEM, int TMAX, bool EVENT, int C>
-int prepare_solve(int bytes, int threads, int* max_blocks_per_cu) {
-  const void* k = reinterpret_cast<const void*>(&solve_kernel<MEM, TMAX, EVENT, C>);
-  HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  int nb = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, threads, (size_t)bytes));
-  *max_blocks_per_cu = nb;
-  return TB_OK;
+// Kernel selection -> translation unit (kernel_units.hpp): the host shim instantiates no kernel itself.
+#define TB_ROUTE(unit, call)                                                                    \
+  ((unit) == 1 ? unit1_##call : (unit) == 2 ? unit2_##call : (unit) == 3 ? unit3_##call : (unit) == 4 ? unit4_##call : (unit) == 5 ? unit5_##call : \
+   (unit) == 6 ? unit6_##call : (unit) == 7 ? unit7_##call : (unit) == 8 ? unit8_##call : unit9_##call)
+int hip_rc(int e, const char* what) {
+  if (e == 0) return TB_OK;
+  if (e < 0) return fail(TB_ERR_INVALID, std::string(what) + ": no such kernel instantiation");
+  if ((hipError_t)e == hipErrorOutOfMemory) return fail(TB_ERR_OOM, std::string(what) + ": " + hipGetErrorString((hipError_t)e));
+  return fail(TB_ERR_HIP, std::string(what) + ": " + hipGetErrorString((hipError_t)e));
 }
-template <int MEM, int TMAX, bool EVENT, int C>
-int prepare_prop(int bytes, int threads, int* max_blocks_per_cu) {
-  const void* k = reinterpret_cast<const void*>(&propagate_kernel<MEM, TMAX, EVENT, C>);
-  HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  int nb = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, threads, (size_t)bytes));
-  *max_blocks_per_cu = nb;
-  return TB_OK;
+int launch_solve(const KernelSel& k, const KernelGrid& g, const DevProblem& P, const DevProblem* dP, Mailbox* mbox) {
+  const int u = kernel_unit(true, k);
+  return hip_rc(TB_ROUTE(u, launch_solve(k, g, P, dP, mbox)), "search kernel launch");
 }
-
-#define DISPATCH_MEM(FN, TM, EV, CP, mem, ...)                                          \
-  do {                                                                                  \
-    if ((mem) == TB_MEM_GLOBAL) FN<TB_MEM_GLOBAL, TM, EV, CP> __VA_ARGS__;              \
-    else if ((mem) == TB_MEM_STORE_SHARED || (EV) || (CP) >= 2) FN<TB_MEM_STORE_SHARED, TM, EV, CP> __VA_ARGS__; /* (plan_launch never plans TCN_SHARED for these) */ \
-    else FN<TB_MEM_TCN_SHARED, ((EV) ? 256 : TM), false, ((CP) >= 2 ? 0 : (CP))> __VA_ARGS__; /* (dead for EV / CP >= 2: names an instantiation that exists anyway) */ \
-  } while (0)
-// Fourth template flag (`opt`): the COMPACT store layout for the event-driven kernels (the sweeps are VALU bound:
-// decoding 2-bit Booleans would cost them more than the LDS it frees), entailed-slice removal for the sweeps.
-// (The run-time selectors are evaluated ONCE into locals: callers pass expressions, and `a == 2 && a == 2 ? x : y` is not
-//  what an unparenthesised `event && opt` was meant to be -- r02 found the solve launch of "sweeps + entailed removal" going
-//  to the event kernel that way.)
-// DISPATCH_KERNEL_WIDE: the 256- and 1024-thread instantiations (everything but the search with two-wave event workgroups);
-// DISPATCH_KERNEL adds the 128-thread event instantiations of the search kernel.
-#define DISPATCH_KERNEL(FN, mem, tmax, event, opt, ...)                                 \
-  do {                                                                                  \
-    if ((opt) == HOT_EVENT_OPT && (event)) FN<TB_MEM_GLOBAL, 1024, true, 3> __VA_ARGS__;    /* hot tier (kernels.hpp: layout 3): 1024 threads, GLOBAL only */ \
-    else if ((opt) == HOT_SWEEP_OPT && !(event)) FN<TB_MEM_GLOBAL, 1024, false, 6> __VA_ARGS__; \
-    else if ((tmax) == 128) {                                                                \
-      const int dk_mem = (mem), dk_opt = (opt);                                         \
-      if (dk_opt == 4) FN<TB_MEM_STORE_SHARED, 128, true, 4> __VA_ARGS__;               /* COMPACT8: LDS only */ \
-      else if (dk_opt == 2) DISPATCH_MEM(FN, 128, true, 2, dk_mem, __VA_ARGS__);        \
-      else if (dk_opt) DISPATCH_MEM(FN, 128, true, 1, dk_mem, __VA_ARGS__);             \
-      else DISPATCH_MEM(FN, 128, true, 0, dk_mem, __VA_ARGS__);                         \
-    } else DISPATCH_KERNEL_WIDE(FN, mem, tmax, event, opt, __VA_ARGS__);                \
-  } while (0)
-#define DISPATCH_KERNEL_WIDE(FN, mem, tmax, event, opt, ...)                            \
-  do {                                                                                  \
-    const int dk_mem = (mem), dk_tmax = (tmax), dk_opt = (opt);                         \
-    const bool dk_event = (event);                                                      \
-    if (dk_tmax <= 256) {                                                               \
-      if (dk_event && dk_opt == 4) FN<TB_MEM_STORE_SHARED, 256, true, 4> __VA_ARGS__;   \
-      else if (dk_event && dk_opt == 2) DISPATCH_MEM(FN, 256, true, 2, dk_mem, __VA_ARGS__); \
-      else if (dk_event && dk_opt) DISPATCH_MEM(FN, 256, true, 1, dk_mem, __VA_ARGS__); \
-      else if (dk_event) DISPATCH_MEM(FN, 256, true, 0, dk_mem, __VA_ARGS__);           \
-      else if (dk_opt == 4) DISPATCH_MEM(FN, 256, false, 4, dk_mem, __VA_ARGS__);       \
-      else if (dk_opt == 2) DISPATCH_MEM(FN, 256, false, 2, dk_mem, __VA_ARGS__);       \
-      else if (dk_opt) DISPATCH_MEM(FN, 256, false, 1, dk_mem, __VA_ARGS__);            \
-      else DISPATCH_MEM(FN, 256, false, 0, dk_mem, __VA_ARGS__);                        \
-    } else {                                                                            \
-      if (dk_event && dk_opt == 2) DISPATCH_MEM(FN, 1024, true, 2, dk_mem, __VA_ARGS__); \
-      else if (dk_event && dk_opt) DISPATCH_MEM(FN, 1024, true, 1, dk_mem, __VA_ARGS__); \
-      else if (dk_event) DISPATCH_MEM(FN, 1024, true, 0, dk_mem, __VA_ARGS__);          \
-      else if (dk_opt == 4) DISPATCH_MEM(FN, 1024, false, 4, dk_mem, __VA_ARGS__);      \
-      else if (dk_opt == 2) DISPATCH_MEM(FN, 1024, false, 2, dk_mem, __VA_ARGS__);      \
-      else if (dk_opt) DISPATCH_MEM(FN, 1024, false, 1, dk_mem, __VA_ARGS__);           \
-      else DISPATCH_MEM(FN, 1024, false, 0, dk_mem, __VA_ARGS__);                       \
-    }                                                                                   \
-  } while (0)
+int launch_prop(const KernelSel& k, const KernelGrid& g, const DevProblem& P, int2* stores, PropagateOut* out, int n_stores) {
+  const int u = kernel_unit(false, k);
+  return hip_rc(TB_ROUTE(u, launch_prop(k, g, P, stores, out, n_stores)), "propagation kernel launch");
+}
 
 // Sets the dynamic-LDS limit of the kernel that will run and returns how many of its workgroups a CU holds
 // (register / LDS limited).  A persistent kernel gains nothing from queued workgroups, so the grid is capped.
 int prepare_kernel(bool solve, int mem, int tmax, bool event, int opt, int bytes, int threads, int* max_blocks_per_cu) {
-  int rc = TB_OK;
-  if (solve && opt == TEAM_SWEEP_OPT && !event) {  // the team kernel is not an instantiation of solve_kernel
-    const void* k = reinterpret_cast<const void*>(&solve_kernel_team);
-    HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    int nb = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, threads, (size_t)bytes));
-    *max_blocks_per_cu = std::min(nb, TB_TEAM_WG_PER_CU);  // one workgroup per CU (TB_TEAM_WG_PER_CU): every workgroup of the grid must be resident (the teams form by waiting for the whole grid)
-    return TB_OK;
-  }
-  if (solve) DISPATCH_KERNEL(rc = prepare_solve, mem, tmax, event, opt, (bytes, threads, max_blocks_per_cu));
-  else DISPATCH_KERNEL_WIDE(rc = prepare_prop, mem, tmax, event, opt, (bytes, threads, max_blocks_per_cu));  // (batch propagation: no 128-thread instantiation)
-  return rc;
+  const KernelSel k{mem, tmax, event, opt};
+  const int u = kernel_unit(solve, k);
+  return hip_rc(TB_ROUTE(u, prepare(k, bytes, threads, max_blocks_per_cu)), "hipFuncSetAttribute / occupancy");
 }
 
 // Layout + launch plan of a network.  The COMPACT layout is chosen for the event-driven fixpoint when it brings a
@@ -1169,7 +1112,7 @@ struct DevBuffers {
 
 // device wall clock "now" (the in-kernel watchdogs compare against it)
 int device_now(hipStream_t stream, long long* d_now, long long* now_out) {
-  clock_kernel<<<1, 1, 0, stream>>>(d_now);
+  clock_kernel<0><<<1, 1, 0, stream>>>(d_now);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(stream));
   HIP_TRY(hipMemcpy(now_out, d_now, sizeof(long long), hipMemcpyDeviceToHost));
@@ -1477,8 +1420,7 @@ int tb_propagate(const tb_config* cfg_in, int32_t n_vars, int32_t n_props, const
   { const int none[2] = {1 << 30, 1 << 30}; if ((rc = bounds_arm(P, plan, 1, 0, event ? g_adj_sizes : none, nullptr)) != TB_OK) return rc; }
 #endif
   HIP_TRY(hipEventRecord(e0, stream));
-  DISPATCH_KERNEL_WIDE(propagate_kernel, plan.mem_kind, plan.tmax, event, compact, <<<dim3(grid), dim3(plan.threads), plan.shared_bytes, stream>>>(P, d_stores, d_out, n_stores));
-  HIP_TRY(hipGetLastError());
+  if ((rc = launch_prop(KernelSel{plan.mem_kind, plan.tmax, event, compact}, KernelGrid{grid, plan.threads, plan.shared_bytes, stream}, P, d_stores, d_out, n_stores)) != TB_OK) return rc;
   HIP_TRY(hipEventRecord(e1, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   float ms = 0.f;
@@ -1648,7 +1590,13 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   P.team_all = (std::getenv("TB_TEAM_ALL") != nullptr && std::getenv("TB_TEAM_ALL")[0] == '1') ? 1 : 0;
   { const char* e = std::getenv("TB_TEAM_SPLIT"); const int k = e ? std::atoi(e) : 4; P.team_split = (k == 1 || k == 2 || k == 4 || k == 8) ? k : 4; }  // four teams per XCD by default
   P.team_relaxed = (std::getenv("TB_TEAM_RELAXED") != nullptr && std::getenv("TB_TEAM_RELAXED")[0] == '0') ? 0 : 1;  // (TB_TEAM_RELAXED=0: acq_rel fences around the barrier, -3 .. -4 %)
+  { const char* e = std::getenv("TB_TEAM_JOIN_MS"); const long long ms = e ? std::max(1, std::atoi(e)) : 10000; P.team_join_ticks = (int)std::min<long long>(0x7fffffff, ms * (long long)s->caps.wall_khz); }
   if (plan.team && (rc = s->bufs.alloc(&P.teams, 1)) != TB_OK) return rc;
+  P.blk_counts = nullptr;
+  if (std::getenv("TB_BLOCK_COUNTS") != nullptr) {  // (instrumented build, scripts/instr_blocks.py: per-XCD arrays of basic-block execution counts, zeroed here, written out by tb_session_finish)
+    if ((rc = s->bufs.alloc(&P.blk_counts, 8 * BLK_COUNT_STRIDE / sizeof(unsigned))) != TB_OK) return rc;
+    HIP_TRY(hipMemset(P.blk_counts, 0, 8 * BLK_COUNT_STRIDE));
+  }
   // the cell other GPUs reach over xGMI: fine-grained device memory (coherent at system scope while kernels run)
   {
     void* c = nullptr;
@@ -1716,8 +1664,7 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
 #ifdef TB_BOUNDS
     if ((rc = bounds_arm(Q, plan, std::max(1, n_strats), s->strat_total, s->adj_sizes, nullptr)) != TB_OK) return rc;
 #endif
-    DISPATCH_KERNEL_WIDE(propagate_kernel, plan.mem_kind, plan.tmax, event, opt, <<<dim3(1), dim3(plan.threads), plan.shared_bytes, s->stream>>>(Q, d_root, d_out, 1));
-    HIP_TRY(hipGetLastError());
+    if ((rc = launch_prop(KernelSel{plan.mem_kind, plan.tmax, event, opt}, KernelGrid{1, plan.threads, plan.shared_bytes, s->stream}, Q, d_root, d_out, 1)) != TB_OK) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
 #ifdef TB_BOUNDS
     if ((rc = bounds_collect("root fixpoint of tb_session_create")) != TB_OK) return rc;
@@ -1865,12 +1812,9 @@ int tb_session_start(tb_session* s) {
   if ((rc = bounds_arm(s->P, plan, std::max(1, s->P.n_strats), s->strat_total, s->adj_sizes, s->P.ctrl)) != TB_OK) return rc;
 #endif
   HIP_TRY(hipEventRecord(s->ev_start, s->stream));
-  if (plan.team) {
-    HIP_TRY(hipMemsetAsync(s->P.teams, 0, sizeof(TeamGrid), s->stream));
-    solve_kernel_team<<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->mbox_dev);
-  } else
-  DISPATCH_KERNEL(solve_kernel, plan.mem_kind, plan.tmax, plan.kernel_event != 0, plan.kernel_opt, <<<dim3(plan.num_blocks), dim3(plan.threads), plan.shared_bytes, s->stream>>>(s->P, s->d_P, s->mbox_dev));
-  HIP_TRY(hipGetLastError());
+  if (plan.team) HIP_TRY(hipMemsetAsync(s->P.teams, 0, sizeof(TeamGrid), s->stream));
+  if ((rc = launch_solve(KernelSel{plan.mem_kind, plan.tmax, plan.kernel_event != 0, plan.kernel_opt}, KernelGrid{plan.num_blocks, plan.threads, plan.shared_bytes, s->stream},
+                         s->P, s->d_P, s->mbox_dev)) != TB_OK) return rc;
   HIP_TRY(hipEventRecord(s->ev_stop, s->stream));
   s->started = true;
   return TB_OK;
@@ -2007,10 +1951,21 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
   HIP_TRY(hipMemcpy(bst.data(), s->P.g_stats, B * sizeof(BlockStats), hipMemcpyDeviceToHost));
   Ctrl c{};
   HIP_TRY(hipMemcpy(&c, s->P.ctrl, sizeof(c), hipMemcpyDeviceToHost));
+  if (c.error == 2) return fail(TB_ERR_STATE, "team formation failed: the " + std::to_string(s->plan.num_blocks) + " workgroups of the team kernel did not all become resident within " +
+                                "TB_TEAM_JOIN_MS (10 s) -- another process, a CU mask or a concurrent kernel holds part of the GPU; TB_TEAM=0 plans one workgroup per subproblem instead");
   if (c.error != 0) return fail(TB_ERR_DEPTH, "decision stack overflow: a workgroup went deeper than " + std::to_string((MAX_DEC_SEGS + 1) * (long long)s->plan.max_depth) +
                                 " decisions, or the pool of " + std::to_string(s->P.dec_pool_segments) + " extra segments of " + std::to_string(s->plan.max_depth) +
                                 " decisions ran out (tb_config.decision_stack_depth sets the segment size)");
 
+  if (s->P.blk_counts != nullptr && std::getenv("TB_BLOCK_COUNTS") != nullptr) {  // instrumented build: the block counts of this search, summed over the XCDs, as raw uint64 to the file named
+    std::vector<unsigned> raw(8 * BLK_COUNT_STRIDE / sizeof(unsigned));
+    HIP_TRY(hipMemcpy(raw.data(), s->P.blk_counts, raw.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    const size_t n = BLK_COUNT_STRIDE / sizeof(unsigned);
+    std::vector<unsigned long long> sum(n, 0ull);
+    for (size_t x = 0; x < 8; ++x) for (size_t i = 0; i < n; ++i) sum[i] += raw[x * n + i];
+    if (FILE* f = std::fopen(std::getenv("TB_BLOCK_COUNTS"), "wb")) { std::fwrite(sum.data(), sizeof(unsigned long long), n, f); std::fclose(f); }
+    HIP_TRY(hipMemset(s->P.blk_counts, 0, 8 * BLK_COUNT_STRIDE));
+  }
   // reduce_blocks (barebones:1033-1067): sum the statistics, pick the winning workgroup.
   tb_stats st;
   std::memset(&st, 0, sizeof(st));

@@ -115,10 +115,11 @@ struct alignas(16) BlockShared {
   int has_work, witness;       // witness: index of a propagator found un-entailed (fixpoint_event), -1 = none
   long long ticket;  // streaming: sequence number of the solution being handed to the host, -1 if none
   Decision* dec_seg[MAX_DEC_SEGS];  // segments 1.. of this workgroup's decision stack (segment 0 is its slab in g_dec)
-  int n_dec_seg, team;        // team (layout 5): member index | team size << 12 | XCD << 24
+  int n_dec_seg, team;        // team (layout 5): member index | team size << 12 | control block (XCD x split + k) << 24
   long long t_start, t_mark;  // thread 0's clocks (kernel start, last phase boundary): LDS, not registers that live through every loop
   long long t_dive;           // start of the current dive (0: not diving)
   int last_obj_ub, team_gen;  // upper bound last imposed on the objective in this subproblem (PINF: none): test aid, tb_session_debug_path; team_gen: barriers passed (layout 5)
+  int team_slab, pad_slab;    // layout 5: the workgroup whose slabs of g_store / g_snap the team works on (its leader's blockIdx)
   unsigned long long red_key[MAX_WAVES];
   int red_first[MAX_WAVES];
   BlockStats bs;  // written by thread 0 only
@@ -340,22 +341,44 @@ __device__ __forceinline__ void team_post(const DevProblem& P, const BlockShared
 __device__ __forceinline__ unsigned long long team_read(const DevProblem& P, const BlockShared& sh, int slot) {
   return __hip_atomic_load(&team_ctl(P, sh)->bcast[slot], TB_RLX, TB_AGENT);
 }
-// Join the team of the XCD this workgroup runs on (thread 0; kernel start).  Every workgroup of the grid is resident (the plan launches at most one per CU), so
-// waiting for the whole grid to register cannot deadlock; after it the member counts are final.
+// Join the team of the XCD this workgroup runs on (thread 0; kernel start).  The plan launches at most one workgroup per CU, so normally the whole grid is resident and
+// everybody registers within microseconds; after that the member counts are final.  The launch is an ordinary one, though: another process on the same GPU, a CU mask
+// or a concurrent persistent kernel can keep part of the grid from becoming resident.  The wait is therefore bounded by a wall-clock limit of its own
+// (DevProblem::team_join_ticks, 10 s; independent of timeout_ms): whoever runs into it poisons the registration word (TEAM_JOIN_POISON), so that workgroups that
+// start later do not form teams with members that have left, reports Ctrl::error = 2 (tb_session_finish: TB_ERR_STATE "team formation failed") and goes on as a team
+// of one that has been told to stop -- no team barrier ever waits for anybody.
+constexpr unsigned TEAM_JOIN_POISON = 0x80000000u;
 __device__ __forceinline__ void team_join(const DevProblem& P, BlockShared& sh) {
   TeamGrid* G = glob(P.teams);
   const unsigned xcc = P.team_all ? 0u : ((unsigned)__builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7u);
   const unsigned split = P.team_all ? 1u : (unsigned)(P.team_split > 1 ? P.team_split : 1);  // 1, 2, 4 or 8
   const unsigned mx = __hip_atomic_fetch_add(&G->xcd_members[xcc], 1u, TB_RLX, TB_AGENT);  // my arrival on this XCD: dealt to its teams in turn
-  (void)__hip_atomic_fetch_add(&G->registered, 1u, __ATOMIC_RELEASE, TB_AGENT);
-  for (unsigned spins = 1; __hip_atomic_load(&G->registered, __ATOMIC_ACQUIRE, TB_AGENT) < gridDim.x; ++spins) {
+  const unsigned k = mx % split, m = mx / split;
+  // the team's slabs (store, snapshot stack) are those of its LEADER's workgroup: a slot below num_blocks whatever the grid size (r05 used XCD x split + k, which runs up to
+  // 63 and indexed past g_store / g_snap for grids smaller than that -- `-or 8`, or the 2e8 / n_vars cap of a very large network)
+  if (m == 0) __hip_atomic_store(&G->team[xcc * split + k].pad[0], (unsigned)blockIdx.x, TB_RLX, TB_AGENT);
+  unsigned seen = __hip_atomic_fetch_add(&G->registered, 1u, __ATOMIC_RELEASE, TB_AGENT) + 1u;
+  const long long t_join = wall_clock64();
+  for (unsigned spins = 1; (seen & ~TEAM_JOIN_POISON) < gridDim.x && !(seen & TEAM_JOIN_POISON); ++spins) {
     __builtin_amdgcn_s_sleep(8);
-    if ((spins & 4095u) == 0u && deadline_passed(P)) { sh.abort = 1; sh.stop = 1; break; }  // (a grid that is not fully resident: give up at the deadline instead of hanging)
+    if ((spins & 1023u) == 0u && (deadline_passed(P) || wall_clock64() - t_join > (long long)P.team_join_ticks)) {
+      (void)__hip_atomic_fetch_or(&G->registered, TEAM_JOIN_POISON, TB_RLX, TB_AGENT);
+    }
+    seen = __hip_atomic_load(&G->registered, __ATOMIC_ACQUIRE, TB_AGENT);
+  }
+  sh.team_gen = 0; sh.team_res = 0;
+  if (seen & TEAM_JOIN_POISON) {  // the grid never became co-resident: give up loudly instead of hanging
+    __hip_atomic_store(&glob(P.ctrl)->error, 2, TB_RLX, TB_AGENT);
+    (void)__hip_atomic_fetch_or(&glob(P.ctrl)->stop, STOP_HOST, TB_RLX, TB_AGENT);
+    sh.abort = 1; sh.stop = 1;
+    sh.team = (int)(0u | (1u << 12) | ((xcc * split + k) << 24));
+    sh.team_slab = (int)blockIdx.x;
+    return;
   }
   const unsigned Mx = __hip_atomic_load(&G->xcd_members[xcc], TB_RLX, TB_AGENT);
-  const unsigned k = mx % split, m = mx / split, M = Mx / split + (k < Mx % split ? 1u : 0u);
+  const unsigned M = Mx / split + (k < Mx % split ? 1u : 0u);
   sh.team = (int)(m | (M << 12) | ((xcc * split + k) << 24));
-  sh.team_gen = 0; sh.team_res = 0;
+  sh.team_slab = (int)__hip_atomic_load(&G->team[xcc * split + k].pad[0], TB_RLX, TB_AGENT);
 }
 
 // Store slab of a workgroup: [ni x int2 {lb,ub}] [Boolean words: 16 variables x 2 bits] [one byte per slice].
@@ -2914,7 +2937,9 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_
 // and the host.  Sweeping fixpoints only (AC1 / WAC1), 1024 threads, the PLAIN layout.
 // Between "the last read of this node's store" and "the first write for the next node" stands a team barrier: a member that is still selecting a variable must
 // not see the decision a faster member has already applied.
-__global__ void __launch_bounds__(1024, 4 * TB_TEAM_WG_PER_CU) solve_kernel_team(DevProblem P, Mailbox* mbox) {
+// (a template only so that it is instantiated by the translation unit that launches it, kernel_units.inc: unit 5)
+template <int WG_PER_CU>
+__global__ void __launch_bounds__(1024, 4 * WG_PER_CU) solve_kernel_team(DevProblem P, Mailbox* mbox) {
   __builtin_amdgcn_s_dcache_inv();
   constexpr int C = 5;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2942,11 +2967,11 @@ __global__ void __launch_bounds__(1024, 4 * TB_TEAM_WG_PER_CU) solve_kernel_team
     team_join(P, sh);
   }
   __syncthreads();
-  const int M = team_size(sh), m = team_member(sh), xcd = team_xcd(sh);
+  const int M = team_size(sh), m = team_member(sh), slab = sh.team_slab;
   const bool lead = m == 0;
-  // the team's store and snapshot stack: the slabs of "workgroup" xcd (every workgroup has slabs; a team uses one set); the leader's best store is its own slab
-  int2* const store = glob(P.g_store) + (size_t)xcd * VX;
-  int2* const snap = glob(P.g_snap) + (size_t)xcd * P.snapshot_levels * VX;
+  // the team's store and snapshot stack: the slabs of its leader's workgroup (every workgroup has slabs; a team uses one set); the leader's best store is its own slab
+  int2* const store = glob(P.g_store) + (size_t)slab * VX;
+  int2* const snap = glob(P.g_snap) + (size_t)slab * P.snapshot_levels * VX;
   Decision* const dec = glob(P.g_dec) + (size_t)b * P.max_depth;  // (a copy of the decision stack per member: the control is replicated)
   const int4* const props = P.props;
   // rows of a block copy that are this member's (even boundaries: 16-byte granules stay whole)
@@ -3033,6 +3058,8 @@ __global__ void __launch_bounds__(1024, 4 * TB_TEAM_WG_PER_CU) solve_kernel_team
             Decision& dd = dec_at(P, sh, dec, sh.depth - 1);
             const int c = ++dd.cur;
             (void)embed0<C>(store, P.n_int, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+            // test aid (tb_session_debug_path): the objective bound in force when this decision was taken (the leader's copy of the stack is the one handed out)
+            if (P.g_path_ub != nullptr && lead && sh.depth <= P.max_depth) glob(P.g_path_ub)[(size_t)b * P.max_depth + (sh.depth - 1)] = sh.last_obj_ub;
           }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3076,14 +3103,26 @@ __global__ void __launch_bounds__(1024, 4 * TB_TEAM_WG_PER_CU) solve_kernel_team
     fetch();
   }
   __syncthreads();
+  // test aid (tb_config.reserved[0] & 0x800000, tb_session_debug_path): where the TEAM stood when it left -- reported in its leader's slot; the other members report "no work"
+  // (they hold copies of the same decision stack, and nobody counts their nodes)
+  if (P.g_path_hdr != nullptr && tid == 0) {
+    PathHeader h;
+    h.sub_idx = sh.sub_idx; h.remaining = sh.remaining; h.depth = sh.depth; h.last_obj_ub = sh.last_obj_ub; h.failed = sh.bot;
+    h.has_work = lead ? sh.has_work : 0; h.nodes = (int)bs.nodes;
+    glob(P.g_path_hdr)[b] = h;
+  }
   if (P.g_last != nullptr && lead) store_out<C, 0>(glob(P.g_last) + (size_t)b * VX, store, VX);  // test aid: the store the team stopped on (the leader's slot)
+  // "did this workgroup finish its work" (barebones:889-891) is the TEAM's verdict: only the leader counts nodes, so only it can tell a -cutnodes stop from the end of the queue
+  if (tid == 0 && lead) {
+    const int stopped = __hip_atomic_load(&glob(P.ctrl)->stop, TB_RLX, TB_AGENT) & STOP_HOST;
+    team_post(P, sh, 3, (!(P.cut_nodes != 0 && bs.nodes >= P.cut_nodes) && !stopped) ? 1ull : 0ull);
+  }
   (void)team_sync(P, sh, 0u);
   flush_writes(sh, tc, true);
   __syncthreads();
   if (tid == 0) {
     bs.best_bound = lead ? sh.best_bound : PINF;
-    const int stopped = __hip_atomic_load(&glob(P.ctrl)->stop, TB_RLX, TB_AGENT) & STOP_HOST;
-    if (!(P.cut_nodes != 0 && bs.nodes >= P.cut_nodes) && !stopped) bs.num_blocks_done = 1;
+    if (team_read(P, sh, 3) != 0ull && !sh.abort) bs.num_blocks_done = 1;
     const long long t_end = wall_clock64();
     bs.timers[TB_T_FIRST_BLOCK_IDLE] = t_end - sh.t_start;
     bs.timers[TB_T_OVERALL] = t_end - sh.t_start;
@@ -3093,6 +3132,7 @@ __global__ void __launch_bounds__(1024, 4 * TB_TEAM_WG_PER_CU) solve_kernel_team
   }
 }
 
+template <int UNUSED = 0>
 __global__ void clock_kernel(long long* out) { *out = wall_clock64(); }
 
 // ---- batch propagation kernel: one store per workgroup (tb_propagate) ----------------------------

@@ -114,7 +114,8 @@ def relay_group(dist):
     return _relay_group
 
 
-def exchange_until_done(session, dist=None, tensor_device="cpu", period_s: float = 0.0005, max_seconds: float | None = None, target: int | None = None):
+def exchange_until_done(session, dist=None, tensor_device="cpu", period_s: float = 0.0005, max_seconds: float | None = None, target: int | None = None,
+                        trace: dict | None = None):
     """Host relay (fallback when the cells are not linked): drive one started session to completion.
 
     `session` needs poll() -> (local_best, done), push_bound(b) and stop().  With a process group,
@@ -123,6 +124,9 @@ def exchange_until_done(session, dist=None, tensor_device="cpu", period_s: float
     The all-reduce runs on CPU tensors over the gloo side group (relay_group), never on the GPU the search kernel occupies;
     `tensor_device` is kept for callers of earlier rounds and ignored.
     `target`: stop every rank as soon as the group's incumbent is <= target (bench.py --mode solve: time to a target objective).
+    `trace` (optional dict) receives host timestamps (time.perf_counter): `t_target` -- the round in which the group's incumbent was first <= target (the same
+    round on every rank, so the time to target is defined for any world size), `t_stop` -- when this rank asked its kernel to stop, `t_own_done` -- when this
+    rank's own kernel was first seen finished.
     Returns (global_best, rounds).
     """
     world = dist.get_world_size() if dist is not None else 1
@@ -133,9 +137,13 @@ def exchange_until_done(session, dist=None, tensor_device="cpu", period_s: float
         buf = torch.empty(2, dtype=torch.int32, device="cpu")
     gbest, rounds, t0 = PINF, 0, time.perf_counter()
     stopped = False
+    if trace is not None:
+        trace.update({"t_target": None, "t_stop": None, "t_own_done": None})
     while True:
         best, done = session.poll()
         rounds += 1
+        if trace is not None and done and trace["t_own_done"] is None:
+            trace["t_own_done"] = time.perf_counter()
         if world > 1:
             buf[0] = int(best)
             buf[1] = 1 if done else 0
@@ -146,11 +154,15 @@ def exchange_until_done(session, dist=None, tensor_device="cpu", period_s: float
         if rbest < gbest:
             gbest = rbest
             session.push_bound(gbest)
+        if trace is not None and target is not None and gbest <= target and trace["t_target"] is None:
+            trace["t_target"] = time.perf_counter()
         if all_done:
             return gbest, rounds
         if not stopped and ((max_seconds is not None and time.perf_counter() - t0 > max_seconds) or (target is not None and gbest <= target)):
             session.stop()
             stopped = True
+            if trace is not None:
+                trace["t_stop"] = time.perf_counter()
         time.sleep(period_s)
 
 
