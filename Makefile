@@ -46,7 +46,7 @@ build/obj/$(1)/unit_%.o: $(HIP_DIR)/unit_%.hip $$(HIP_DEP)
 	@mkdir -p build/obj/$(1)
 	$$(HIPCC) $$(HIPFLAGS) $(2) -c -o $$@ $$<
 $(3): build/obj/$(1)/engine.o $$(foreach n,$$(UNITS),build/obj/$(1)/unit_$$(n).o)
-	@mkdir -p $$(LIBDIR)
+	@mkdir -p $$(dir $$@)
 	$$(HIPCC) $$(HIPFLAGS) -shared -o $$@ $$^
 endef
 $(eval $(call HIP_VARIANT,hip,,$(LIBDIR)/libturbo_hip.so))
@@ -55,6 +55,12 @@ $(eval $(call HIP_VARIANT,hip,,$(LIBDIR)/libturbo_hip.so))
 # select it with TURBO_HIP_LIB=turbo_amd/lib/libturbo_hip_tuning.so)
 tuning: $(LIBDIR)/libturbo_hip_tuning.so
 $(eval $(call HIP_VARIANT,tuning,-DTB_TUNING,$(LIBDIR)/libturbo_hip_tuning.so))
+
+# A/B variants of the engine: `make -j8 variant NAME=foo FLAGS="-DTB_SOMETHING=1"` -> turbo_amd/lib/ab/foo.so (objects under build/obj/foo/; select it with TURBO_HIP_LIB)
+ifdef NAME
+variant: $(LIBDIR)/ab/$(NAME).so
+$(eval $(call HIP_VARIANT,$(NAME),$(FLAGS),$(LIBDIR)/ab/$(NAME).so))
+endif
 
 # the same engine with a range check in front of every index the kernels form from host-packed fields (kernels.hpp: TB_BOUNDS): a report
 # {site, index, limit, workgroup} instead of a memory fault.  scripts/bounds_soak.py runs the bench workloads and the fuzz families on it.
@@ -91,4 +97,4 @@ clean:
 	rm -rf $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all front hip cli oracle sanitize clean tuning phases bounds
+.PHONY: all front hip cli oracle sanitize clean tuning phases bounds variant

@@ -270,6 +270,19 @@ def make_search_runner(args, tcn, rank, world, local_rank, dist, tdev, capi, tdi
         sess.start()
         t_started = time.perf_counter() - t0
         first_hit, t_stop_seen = None, None
+        guard = None
+        if world > 1 and args.check_relay:
+            # (test aid) between start and finish nothing the ranks exchange may touch the GPU: every collective must run on CPU tensors over the gloo side group --
+            # a collective of the RCCL group would queue a kernel behind the persistent search kernel and deliver the bound when the search is over
+            guard = {"calls": 0, "orig": dist.all_reduce}
+            relay = tdist.relay_group(dist)
+
+            def checked_all_reduce(tensor, *a, **kw):
+                assert tensor.device.type == "cpu", f"a {tensor.device} tensor was all-reduced while the search kernel runs"
+                assert kw.get("group") is relay, "a collective outside the gloo side group while the search kernel runs"
+                guard["calls"] += 1
+                return guard["orig"](tensor, *a, **kw)
+            dist.all_reduce = checked_all_reduce
         if world > 1:
             # collective loop over the gloo side group: agrees on the group's incumbent, relays it when the cells are not linked, ends every rank together
             trace = {}
@@ -291,6 +304,8 @@ def make_search_runner(args, tcn, rank, world, local_rank, dist, tdev, capi, tdi
                     break
                 time.sleep(0.0005)
         t_loop = time.perf_counter() - t0
+        if guard is not None:
+            dist.all_reduce = guard["orig"]
         has, best, st = sess.finish()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
@@ -314,6 +329,8 @@ def make_search_runner(args, tcn, rank, world, local_rank, dist, tdev, capi, tdi
                "best_objective_bound": int(min(r["best_bound"] for r in per_rank)), **tot,
                "every_subproblem_accounted_once": int(tot["eps_solved"] + tot["eps_skipped"]) == (1 << plan["subproblems_power"]),
                "nodes_per_sec": tot["nodes"] / max(wall, 1e-9), "per_rank": per_rank}
+        if guard is not None:
+            rec["relay_rounds_checked_cpu_only"] = guard["calls"]
         return rec
 
     return run
@@ -404,6 +421,8 @@ def main() -> int:
     ap.add_argument("--fixed-bound", type=int, default=None, help="--mode solve: the bound B of the proof run (default: per workload, SOLVE_DEFAULTS)")
     ap.add_argument("--target", type=int, default=None, help="--mode solve: the target objective of the time-to-target run (default: per workload)")
     ap.add_argument("--solve-timeout", type=float, default=120.0, help="--mode solve: give up after this many seconds per run")
+    ap.add_argument("--fail-import-rank", type=int, default=-1, help="test aid: this rank refuses to map its peers' cells (TB_FAIL_IMPORT): the group must fall back to the host relay as a whole")
+    ap.add_argument("--check-relay", action="store_true", help="test aid (--mode solve, N > 1): assert that every collective between start and finish runs on CPU tensors over the gloo side group")
     ap.add_argument("--sharded-search", type=int, default=1, help="append the `sharded_search` record (proof under a fixed bound: fixed total work) to the default line (0 = skip)")
     ap.add_argument("--sharded-reps", type=int, default=2, help="runs of the sharded search (the fastest is reported, all are listed)")
     ap.add_argument("--debug-bits", type=lambda v: int(v, 0), default=0, help="tuning knobs of tb_config.reserved[0] (experiments only)")
@@ -426,6 +445,8 @@ def main() -> int:
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.fail_import_rank == rank:
+        os.environ["TB_FAIL_IMPORT"] = "1"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` or under "

@@ -109,14 +109,23 @@ def instrument(lines, want, karg_off):
                 file_ids[int(mf.group(1))] = mf.group(2)
             ml = re.match(r"\.loc\s+(\d+)\s+(\d+)", s)
             if ml:
-                line_ctx = (int(ml.group(1)), int(ml.group(2)))
+                # the assembly comment behind a .loc holds the whole inline stack: `; file:line:col @[ caller:line:col @[ ... ] ]` -- kept as "file:line>file:line>..." (innermost first)
+                mc = re.search(r";\s*(\S.*)$", s)
+                frames = []
+                if mc:
+                    for fr in mc.group(1).replace("]", " ").split("@["):
+                        mm = re.match(r"\s*(\S+?):(\d+)(?::\d+)?\s*$", fr.strip())
+                        if mm:
+                            frames.append(f"{os.path.basename(mm.group(1))}:{mm.group(2)}")
+                line_ctx = (int(ml.group(1)), int(ml.group(2)), ">".join(frames))
                 out.append(raw)
                 continue
             if t == k:
                 out.append(raw.replace(str(free), str(base + 3)))
                 continue
-            if re.match(r"^\.?L?[A-Za-z_0-9.$]+:", s) and not s.startswith(";"):  # a label
-                start_new = True
+            if re.match(r"^\.?L?[A-Za-z_0-9.$]+:", s) and not s.startswith(";"):  # a label: only basic-block labels are branch targets (.Ltmp / .Lfunc_begin are debug-info marks)
+                if re.match(r"^\.LBB\d+_\d+:", s):
+                    start_new = True
                 out.append(raw)
                 continue
             if not s or s[0] in ";." or s.startswith("//"):
@@ -126,13 +135,20 @@ def instrument(lines, want, karg_off):
             if start_new:
                 sid = len(segs) - kernel_first
                 assert 4 * sid < (1 << STRIDE_LOG2)
-                cur = {"kernel": name, "id": sid, "counts": collections.Counter(), "locs": collections.Counter(), "first_loc": line_ctx, "text": []}
+                cur = {"kernel": name, "id": sid, "counts": collections.Counter(), "locs": collections.Counter(), "first_loc": line_ctx[2] if line_ctx else "", "text": []}
                 segs.append(cur)
+                # The counting atomic is fenced: it is never outstanding together with the kernel's own LDS / scalar-memory operations.  Unfenced (TB_INSTR_FENCE=0), one
+                # 12 M-node search of wordpress7_500 in five took a wrong decision (a variable-selection reduction over ds_bpermute consumed a stale value) -- the returnless
+                # scalar atomics interfere with the lgkmcnt waits the compiler counts for in-order LDS returns; fenced, 0 of 24 runs did.
+                if os.environ.get("TB_INSTR_FENCE", "1") != "0":
+                    out.append("\ts_waitcnt lgkmcnt(0)")
                 out.append(f"\ts_atomic_add s{one}, s[{base}:{base + 1}], {hex(4 * sid)}")
+                if os.environ.get("TB_INSTR_FENCE", "1") != "0":
+                    out.append("\ts_waitcnt lgkmcnt(0)")
                 start_new = False
             c = classify(op)
             cur["counts"][c] += 1
-            cur["locs"][f"{line_ctx[0]}:{line_ctx[1]}" if line_ctx else "0:0", c] += 1
+            cur["locs"][(line_ctx[2] or f"#{line_ctx[0]}:{line_ctx[1]}") if line_ctx else "?:0", c] += 1
             if len(cur["text"]) < 400:
                 cur["text"].append(s.split(";")[0].strip())
             out.append(raw)
@@ -187,7 +203,7 @@ def cmd_build(out_so):
     os.makedirs(WORK, exist_ok=True)
     os.chdir(WORK)
     src = os.path.join(ROOT, "turbo_amd", "csrc", "hip", "unit_1.hip")
-    log = subprocess.run(["/opt/rocm/bin/hipcc"] + HIPFLAGS + ["-gline-tables-only", "-c", "-save-temps", "-v", "-o", "unit_1.o", src], capture_output=True, text=True)
+    log = subprocess.run(["/opt/rocm/bin/hipcc"] + HIPFLAGS + os.environ.get("TB_INSTR_FLAGS", "").split() + ["-gline-tables-only", "-c", "-save-temps", "-v", "-o", "unit_1.o", src], capture_output=True, text=True)
     assert log.returncode == 0, log.stderr[-3000:]
     steps = [l.strip() for l in log.stderr.splitlines() if l.startswith(' "')]
     dev_s = "unit_1-hip-amdgcn-amd-amdhsa-gfx950.s"
@@ -207,11 +223,15 @@ def cmd_build(out_so):
     # the rest of the pipeline, as hipcc ran it: device assembler, lld, bundler, host compile (which embeds the new bundle), host assembler
     import shlex
     replay = [s for s in steps if ("-cc1as" in s and "amdgcn" in s) or "lld" in s.split()[0] or "clang-offload-bundler" in s.split()[0]]
-    host = [s for s in steps if "-triple x86_64-unknown-linux-gnu" in s and ("-emit-llvm-bc" in s or " -S " in s or "-cc1as" in s)]
+    host = [s for s in steps if re.search(r"(?<![\w-])-triple x86_64-unknown-linux-gnu", s) and ("-emit-llvm-bc" in s or " -S " in s or "-cc1as" in s)]  # (not the device steps: -aux-triple x86_64)
     for s in replay + host:
         r = subprocess.run(shlex.split(s), capture_output=True, text=True)
         assert r.returncode == 0, (s[:200], r.stderr[-3000:])
     objs = [os.path.join(ROOT, "build", "obj", "hip", f) for f in ["engine.o"] + [f"unit_{u}.o" for u in range(2, 10)]]
+    if os.environ.get("TB_INSTR_FLAGS"):  # (a variant that changes shared structures: its own host shim)
+        eng = os.path.join(WORK, "engine_variant.o")
+        subprocess.run(["/opt/rocm/bin/hipcc"] + HIPFLAGS + os.environ["TB_INSTR_FLAGS"].split() + ["-c", "-o", eng, os.path.join(ROOT, "turbo_amd", "csrc", "hip", "engine.hip")], check=True, capture_output=True)
+        objs[0] = eng
     for o in objs:
         assert os.path.exists(o), f"{o}: run `make -j8 hip` first"
     subprocess.run(["/opt/rocm/bin/hipcc"] + HIPFLAGS + ["-shared", "-o", out_so, os.path.join(WORK, "unit_1.o")] + objs, check=True, capture_output=True)
@@ -253,55 +273,81 @@ def cmd_table(seg_path, counts_path, kernel_sub, nodes=None, m_valu=None, m_salu
     kernels = sorted(set(s["kernel"] for s in segs))
     assert len(kernels) == 1, f"'{kernel_sub}' selects {kernels}"
     marks, src = regions_of_source()
-    fn_start = {}  # helper functions: lines before the first region marker's function are attributed to the context
-    first_mark = min(l for l, _ in marks)
-
-    # top-level functions of kernels.hpp (a definition starts at column 0 with template / __device__ / __global__ / static __device__): a line belongs to the last start
-    # at or above it; a function without TB_REGION points is a helper -- its instructions are charged to the region of the code it was inlined into
-    starts = [ln for ln, l in enumerate(src, 1) if re.match(r"^(static\s+)?(__device__|__global__|template\s*<)", l)]
+    psrc = open(os.path.join(ROOT, "turbo_amd", "csrc", "hip", "propagators.hpp")).read().split("\n")
     import bisect
 
-    def fn_of(ln):
-        k = bisect.bisect_right(starts, ln) - 1
-        while k > 0 and starts[k] - starts[k - 1] == 1:  # `template <...>` on the line above the declarator
-            k -= 1
-        return starts[k] if k >= 0 else 0
+    def functions_of(text):
+        """[(first line, name)] of the top-level function definitions of a header (a definition starts at column 0 with template / __device__ / __global__ / static / inline)."""
+        fns = []
+        for ln, l in enumerate(text, 1):
+            if not re.match(r"^(static\s+|inline\s+)?(__device__|__global__|__host__|template\s*<|constexpr\s+\w+\s+\w+\()", l):
+                continue
+            if fns and fns[-1][0] == ln - 1 and text[ln - 2].startswith("template"):
+                start = fns.pop()[0]  # `template <...>` on the line above the declarator
+            else:
+                start = ln
+            decl = " ".join(text[ln - 1:ln + 2])
+            decl = re.sub(r"__launch_bounds__\s*\((?:[^()]|\([^()]*\))*\)", "", decl)
+            names = [m.group(1) for m in re.finditer(r"(\w+)\s*\(", decl) if m.group(1) not in ("__launch_bounds__", "__attribute__", "address_space", "alignas", "aligned", "if", "while", "for", "sizeof", "decltype")]
+            fns.append((start, names[0] if names else "?"))
+        return fns
+    kfns, pfns = functions_of(src), functions_of(psrc)
+    kstarts, pstarts = [f[0] for f in kfns], [f[0] for f in pfns]
     fn_marks = collections.defaultdict(list)
     for l, rid in marks:
-        fn_marks[fn_of(l)].append((l, rid))
+        k = bisect.bisect_right(kstarts, l) - 1
+        fn_marks[kfns[k][1] if k >= 0 else "?"].append((l, rid))
 
-    def region_of_line(ln):
-        ms = fn_marks.get(fn_of(ln))
-        if not ms:
-            return None  # a helper
-        r = ms[0][1]
-        for l, rid in ms:
-            if l <= ln:
-                r = rid
-        return r
+    def frame_fn(frame):
+        """(function, region or None) of one frame "file:line"."""
+        name, ln = frame.rsplit(":", 1)
+        ln = int(ln)
+        if name == "kernels.hpp" and ln > 0:
+            k = bisect.bisect_right(kstarts, ln) - 1
+            fn = kfns[k][1] if k >= 0 else "?"
+            ms = fn_marks.get(fn)
+            if not ms:
+                return fn, None
+            r = ms[0][1]
+            for l, rid in ms:
+                if l <= ln:
+                    r = rid
+            return fn, r
+        if name == "propagators.hpp" and ln > 0:
+            k = bisect.bisect_right(pstarts, ln) - 1
+            return "propagators.hpp: " + (pfns[k][1] if k >= 0 else "?"), None
+        return (name + " (line 0: compiler-generated)" if ln == 0 else name), None
 
-    # lines of kernels.hpp that belong to small helpers (everything above fixpoint_event's seeding marker, except `fixpoint` which the event kernels do not run) are charged to
-    # the region of the instruction stream around them: the last "own" line seen in layout order
+    def where(loc):
+        """loc = "file:line>file:line>..." (innermost first).  Returns (innermost function, region): the region is that of the first frame, going outwards, that lies in a
+        function with TB_REGION points -- the call site the instruction was inlined into, taken from the compiler's inline stack (exact, no layout heuristics)."""
+        frames = [f for f in loc.lstrip("#").split(">") if f]
+        if not frames:
+            return "?", None
+        fn, reg = frame_fn(frames[0])
+        for fr in frames:
+            f2, r2 = frame_fn(fr)
+            if r2 is not None:
+                reg = r2
+                break
+        return fn, reg
+
     CLS = ("valu", "lane", "salu", "lds", "vmem", "scratch", "smem", "branch", "misc", "other")
     per_region = collections.defaultdict(collections.Counter)
+    per_reg_only = collections.defaultdict(collections.Counter)
     per_line = collections.defaultdict(collections.Counter)
     tot = collections.Counter()
-    ctx_region = 0
     seg_rows = []
     for s in segs:
         c = counts[s["id"]]
-        own = collections.Counter()
-        for f, ln_cls, v in [(int(k.split(":")[0]), (int(k.split(":")[1]), cl), v) for k, cl, v in s["locs"]]:
-            ln, cl = ln_cls
-            own_region = region_of_line(ln) if f == kfile and ln > 0 else None
-            if own_region is not None:
-                ctx_region = own_region
-            reg = ctx_region  # (helpers of kernels.hpp, propagators.hpp, HIP headers, line 0: the calling context)
-            per_region[reg][cl] += v * c
+        for loc, cl, v in s["locs"]:
+            fn, reg = where(loc)
+            per_region[(fn, reg)][cl] += v * c
+            per_reg_only[reg][cl] += v * c
             if c:
-                per_line[(files.get(f, "?").split("/")[-1], ln)][cl] += v * c
+                f0 = loc.lstrip("#").split(">")[0]
+                per_line[(f0.rsplit(":", 1)[0], int(f0.rsplit(":", 1)[1]) if ":" in f0 else 0)][cl] += v * c
             tot[cl] += v * c
-            own[reg] += v
         seg_rows.append((c * sum(s["counts"].values()), c, s))
     nodes = float(nodes) if nodes else None
     per = (lambda x: x / nodes) if nodes else (lambda x: x)
@@ -316,10 +362,19 @@ def cmd_table(seg_path, counts_path, kernel_sub, nodes=None, m_valu=None, m_salu
                            "salu_plus_branch_over_measured": round(per(tot["salu"] + tot["branch"]) / ms, 4),
                            "salu_plus_branch_misc_over_measured": round(per(tot["salu"] + tot["branch"] + tot["misc"]) / ms, 4)}
     rows = []
-    for reg, cnt in per_region.items():
-        rows.append({"region": reg, "what": NAMES.get(reg, "?"), **{k: round(per(cnt[k]), 1) for k in CLS if cnt[k]},
+    for (fn, reg), cnt in per_region.items():
+        rows.append({"function": fn, "region": reg, "what": NAMES.get(reg, "") if reg is not None else "(the function's own instructions, wherever it was inlined)",
+                     **{k: round(per(cnt[k]), 1) for k in CLS if cnt[k]},
                      "valu_share": round((cnt["valu"] + cnt["lane"]) / max(1, tot["valu"] + tot["lane"]), 4), "salu_share": round(cnt["salu"] / max(1, tot["salu"]), 4)})
     rows.sort(key=lambda r: -(r.get("valu", 0) + r.get("lane", 0) + r.get("salu", 0)))
+    by_region = []
+    for reg, cnt in per_reg_only.items():
+        by_region.append({"region": reg, "what": NAMES.get(reg, "?") if reg is not None else "outside every marked function", **{k: round(per(cnt[k]), 1) for k in CLS if cnt[k]},
+                          "valu_share": round((cnt["valu"] + cnt["lane"]) / max(1, tot["valu"] + tot["lane"]), 4), "salu_share": round(cnt["salu"] / max(1, tot["salu"]), 4)})
+    by_region.sort(key=lambda r: -(r.get("valu", 0) + r.get("lane", 0) + r.get("salu", 0)))
+    out["by_region"] = by_region
+    out["attribution"] = ("by_region: every instruction is charged to the TB_REGION point of the call site it was inlined into (the compiler's inline stack, kept by the assembly "
+                          "listing behind every .loc); regions: the same, split by the innermost function the instruction came from (helpers like load_dom, mark_slice, lean_class_run_t)")
     out["regions"] = rows
     lines = []
     for (f, ln), cnt in sorted(per_line.items(), key=lambda kv: -(kv[1]["valu"] + kv[1]["lane"] + kv[1]["salu"]))[:60]:

@@ -377,6 +377,12 @@ def test_bench_solve_mode_two_ranks_prove_a_fixed_bound_and_reach_a_target():
     assert proof["exhaustive"] == 1 and proof["has_solution"] == 0 and proof["every_subproblem_accounted_once"], proof
     assert proof["eps_solved"] + proof["eps_skipped"] == 4096 and len(proof["per_rank"]) == 2 and all(r["nodes"] > 0 for r in proof["per_rank"])
     assert tt["has_solution"] == 1 and tt["best_objective_bound"] <= 140 and tt["seconds"] < 60, tt
+    assert tt["time_to_target_s"] is not None and 0 < tt["time_to_target_s"] <= tt["seconds"], "the time to target is reported for any world size (the round in which the group agreed on it)"
+    # both kernels ran side by side and were stopped by the agreement, not by running out of time or work: each explored nodes, left within 0.5 s of the agreement, and
+    # nobody ran far past the target (r05's rows: one rank stopped 30-50 s late because the two full grids were not co-resident on the one GPU)
+    for r in tt["per_rank"]:
+        assert r["nodes"] > 0 and 0 <= r["t_own_kernel_done_s"] <= tt["time_to_target_s"] + 0.5, (r, tt["time_to_target_s"])
+    assert tt["best_objective_bound"] >= 140 - 60, tt
     # the same on one rank
     p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "solve", "--workload", "accap_a3", "--or-nodes", "256", "--subproblems-power", "12",
                          "--fixed-bound", "40", "--target", "140", "--solve-timeout", "60"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -385,6 +391,32 @@ def test_bench_solve_mode_two_ranks_prove_a_fixed_bound_and_reach_a_target():
     assert r1["proof"]["exhaustive"] == 1 and r1["proof"]["every_subproblem_accounted_once"] and r1["to_target"]["time_to_target_s"] is not None
     # (the tree under a constant bound does not depend on who walks it -- up to the dives into subtrees another workgroup is skipping at that moment)
     assert abs(r1["proof"]["nodes"] - proof["nodes"]) <= 0.1 * proof["nodes"]
+    # two ranks sharing the GPU's CUs are about as fast as one rank that has them all: 3 x (+ 0.3 s for the rendezvous of the stop) is the bound VERDICT r05 asked for
+    assert tt["seconds"] <= 3 * r1["to_target"]["seconds"] + 0.3 and proof["seconds"] <= 3 * r1["proof"]["seconds"] + 0.3, (tt["seconds"], r1["to_target"]["seconds"], proof["seconds"], r1["proof"]["seconds"])
+
+
+def test_a_rank_that_cannot_map_its_peers_sends_the_whole_group_to_the_host_relay():
+    """The code an 8-GPU box takes if the IPC import misbehaves: rank 1 of three refuses to map its peers' cells (TB_FAIL_IMPORT).  Linking is all
+    or nothing (distributed.link_group): every rank drops what it imported, the group runs on static shares with the incumbent relayed through the gloo side group -- and
+    still proves the fixed bound with every subproblem counted exactly once, within 1.5 x the time of the linked group; between start and finish every collective runs on
+    CPU tensors over the side group (--check-relay wraps dist.all_reduce)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--share-device", "--dist-backend", "gloo", "--mode", "solve", "--workload", "accap_a3",
+            "--or-nodes", "256", "--subproblems-power", "12", "--fixed-bound", "40", "--target", "140", "--solve-timeout", "60", "--check-relay"]
+    recs = {}
+    for tag, extra in (("linked", []), ("fallback", ["--fail-import-rank", "1"])):
+        p = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        recs[tag] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    for tag, linked in (("linked", True), ("fallback", False)):
+        proof, tt = recs[tag]["proof"], recs[tag]["to_target"]
+        assert proof["linked"] is linked and tt["linked"] is linked, (tag, proof["linked"])
+        assert proof["exhaustive"] == 1 and proof["has_solution"] == 0 and proof["every_subproblem_accounted_once"] and proof["eps_solved"] + proof["eps_skipped"] == 4096, (tag, proof)
+        assert len(proof["per_rank"]) == 3 and all(r["nodes"] > 0 for r in proof["per_rank"])
+        assert proof["relay_rounds_checked_cpu_only"] > 0 and tt["relay_rounds_checked_cpu_only"] > 0
+        assert tt["has_solution"] == 1 and tt["best_objective_bound"] <= 140 and tt["time_to_target_s"] is not None
+    assert recs["fallback"]["proof"]["stolen_subproblems"] == 0, "static shares: nothing is stolen without the cells"
+    assert recs["fallback"]["proof"]["seconds"] <= 1.5 * recs["linked"]["proof"]["seconds"] + 0.3, (recs["fallback"]["proof"]["seconds"], recs["linked"]["proof"]["seconds"])
 
 
 def test_bench_refuses_to_report_fewer_gpus_than_asked():

@@ -178,24 +178,30 @@ os.environ["TB_TEAM_JOIN_MS"] = "1"
 small = frontend.load_fzn(os.path.join(os.environ["TB_ROOT"], "benchmarks", "test_data", "pat7.fzn"))
 late = capi.Session(small, capi.make_config(fixpoint=1, timeout_ms=0, **TEAM))                      # one workgroup per CU: half of them cannot become resident beside the first grid
 assert late.plan()["kernel_opt"] == 10 and late.plan()["num_blocks"] == cus, late.plan()
+print("STAGE sessions created", flush=True)
 big.start()
 time.sleep(0.5)
+print("STAGE first search running", flush=True)
 late.start()
+print("STAGE second search launched", flush=True)
 t0 = time.time()
 while not late.poll()[1]:
     assert time.time() - t0 < 60, "the second team kernel hangs"
     time.sleep(0.01)
+print("STAGE second kernel left after %.3f s" % (time.time() - t0), flush=True)
 try:
     late.finish()
-    print("RESULT no error")
+    print("RESULT no error", flush=True)
 except capi.TurboHipError as e:
-    print("RESULT", e)
-late.close()
-big.stop()
+    print("RESULT", e, flush=True)
+big.stop()   # (the second session is closed after the first search has ended: hipFree waits for every kernel of the device)
+t0 = time.time()
 while not big.poll()[1]:
+    assert time.time() - t0 < 60, "the first search does not obey the stop request"
     time.sleep(0.01)
 has, best, st = big.finish()
-print("BIG nodes", st["nodes"])
+print("BIG nodes", st["nodes"], flush=True)
+late.close()
 big.close()
 """
 
@@ -208,7 +214,10 @@ def test_a_grid_that_never_becomes_resident_is_reported_not_waited_for():
     import subprocess
     import sys
     root = os.path.dirname(BENCH)
-    p = subprocess.run([sys.executable, "-c", JOIN_SCRIPT], env=dict(os.environ, TB_ROOT=root, TB_TEAM="1"), capture_output=True, text=True, timeout=240)
+    try:
+        p = subprocess.run([sys.executable, "-c", JOIN_SCRIPT], env=dict(os.environ, TB_ROOT=root, TB_TEAM="1"), capture_output=True, text=True, timeout=200)
+    except subprocess.TimeoutExpired as e:
+        pytest.fail("hung after: " + (e.stdout.decode() if isinstance(e.stdout, bytes) else str(e.stdout))[-600:])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     assert "RESULT" in p.stdout and "team formation failed" in p.stdout, p.stdout[-2000:]
     big = [l for l in p.stdout.splitlines() if l.startswith("BIG nodes")]

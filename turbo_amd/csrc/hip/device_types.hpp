@@ -42,6 +42,9 @@ struct alignas(16) Ctrl {
   unsigned long long nodes_folded;     // the part of nodes_local already added to PeerCell::nodes_total of rank 0
   int dec_pool_next;                   // next free segment of DevProblem::dec_pool (decision stacks grow on demand, barebones:401-403)
   int steal_lock;                      // one workgroup of this device at a time looks for work on the other GPUs
+#ifdef TB_TRAP_SEED
+  int trap[48];                        // debugging aid (r06): what a workgroup saw when it met a decision or a change-list entry that cannot be (kernels.hpp: trap_report)
+#endif
 };
 constexpr int STOP_HOST = 1, STOP_GPU = 2;
 

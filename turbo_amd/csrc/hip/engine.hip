@@ -479,8 +479,8 @@ Adjacency build_adjacency(int32_t n_vars, int32_t n_props, const tb_prop* props,
   return a;
 }
 
-// Rewrite the caller's bytecodes into the engine's packed records (propagators.hpp): word0 = pack-time class |
-// "operand is read by no other slice" bits 8-10 | original op << 12 | classes present in the 64-record slice << 16.
+// Rewrite the caller's bytecodes into the engine's packed records (propagators.hpp): word0 = pack-time class (bits 0-3) |
+// "a narrowing of operand k has a reader outside the record's slice" bits 4-9 | original op << 12 | classes present in the 64-record slice << 16.
 // An operand that is a constant kept out of the slab (internal id >= n_slab, Layout) is replaced by its value with the sign bit set.
 inline int operand_field(int v, int n_slab, const std::vector<int>& value) {
   return v >= n_slab ? (int)(0x80000000u | ((unsigned)value[(size_t)v] & 0x7fffffffu)) : v;
@@ -501,13 +501,13 @@ std::vector<int4> pack_props(int32_t n_props, const tb_prop* props, const std::v
       const bool xc = is_const[(size_t)p.x] != 0;
       const int cls = class_of(p.op, xc, xc ? value[(size_t)p.x] : 0);
       present |= 1 << cls;
-      int priv = 0;
+      int report = 0;  // bits 2k, 2k + 1: a narrowing of operand k (lower bound raised / upper bound lowered) has a reader outside this slice
       const int vs[3] = {p.x, p.y, p.z};
       for (int k = 0; k < 3; ++k) {
         const std::vector<Reader>& l = adj.lists[(size_t)vs[k]];
-        if (l.empty() || (l.size() == 1 && l[0].slice == s)) priv |= 1 << k;
+        if (!(l.empty() || (l.size() == 1 && l[0].slice == s))) report |= 3 << (2 * k);
       }
-      out[(size_t)i] = make_int4(cls | (priv << 8) | (p.op << 12), operand_field(p.x, n_slab, value), operand_field(p.y, n_slab, value), operand_field(p.z, n_slab, value));
+      out[(size_t)i] = make_int4(cls | (report << 4) | (p.op << 12), operand_field(p.x, n_slab, value), operand_field(p.y, n_slab, value), operand_field(p.z, n_slab, value));
     }
     // operand kinds of the slice (bits 26-31, two per operand): 1 all integer variables, 2 all Booleans of the COMPACT layout
     // (internal id >= n_int), 3 all constants, 0 mixed.  The event kernels have dedicated runs for the commonest signatures.
@@ -1608,6 +1608,11 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
     }
     s->cell = static_cast<PeerCell*>(c);
     HIP_TRY(hipMemset(s->cell, 0, sizeof(PeerCell)));
+    if (std::getenv("TB_PRINT_PTRS") != nullptr)  // (debugging aid: which buffer a faulting address belongs to)
+      std::fprintf(stderr, "%% ptrs B=%zu VX=%zu L=%d depth=%d: props %p root %p g_store %p g_snap %p [%zu B] g_best %p [%zu B] g_dec %p [%zu B] dec_pool %p [%d segs] g_stats %p ctrl %p blk_counts %p cell %p succ %p var_adj %p adj_rest %p slice_info %p cond2 %p\n",
+                   B, VX, plan.snapshot_levels, plan.max_depth, (const void*)P.props, (const void*)P.root_store, (void*)P.g_store, (void*)P.g_snap, B * (size_t)plan.snapshot_levels * VX * 8, (void*)P.g_best, B * VX * 8,
+                   (void*)P.g_dec, B * (size_t)plan.max_depth * sizeof(Decision), (void*)P.dec_pool, P.dec_pool_segments, (void*)P.g_stats, (void*)P.ctrl, (void*)P.blk_counts, (void*)s->cell,
+                   (const void*)P.succ, (const void*)P.var_adj, (const void*)P.adj_rest, (const void*)P.slice_info, (const void*)P.cond2);
     s->peer_cells.assign((size_t)P.world, nullptr);
     s->peer_cells[(size_t)P.rank] = s->cell;
     if ((rc = s->bufs.alloc(&s->d_peers, (size_t)P.world)) != TB_OK) return rc;
@@ -1708,6 +1713,9 @@ int tb_session_import_peer(tb_session* s, int32_t peer_rank, const tb_peer_handl
   if (!s || !handle) return fail(TB_ERR_INVALID, "null argument");
   if (s->started && !s->finished) return fail(TB_ERR_STATE, "session is running");
   if (peer_rank < 0 || peer_rank >= s->P.world || peer_rank == s->P.rank) return fail(TB_ERR_INVALID, "peer rank out of range");
+  // test knob: what an 8-GPU box does when the IPC import misbehaves on one rank -- this process refuses to map its peers' cells, and the group must fall back as a whole
+  // (distributed.link_group: all or nothing) to the host relay with static shares (tests/test_gpu_multi.py)
+  if (std::getenv("TB_FAIL_IMPORT") != nullptr) return fail(TB_ERR_HIP, "hipIpcOpenMemHandle: refused (TB_FAIL_IMPORT is set: a test of the fallback)");
   HIP_TRY(hipSetDevice(s->cfg.device));
   hipIpcMemHandle_t h;
   std::memcpy(&h, handle->bytes, sizeof(h));
@@ -1951,6 +1959,13 @@ int tb_session_finish(tb_session* s, tb_itv* best_store_out, int32_t* has_soluti
   HIP_TRY(hipMemcpy(bst.data(), s->P.g_stats, B * sizeof(BlockStats), hipMemcpyDeviceToHost));
   Ctrl c{};
   HIP_TRY(hipMemcpy(&c, s->P.ctrl, sizeof(c), hipMemcpyDeviceToHost));
+#ifdef TB_TRAP_SEED
+  if (c.error == 3) {
+    std::fprintf(stderr, "%% trap code %d: workgroup %d node %d depth %d new_depth %d dive-left %d segs %d;", c.trap[0], c.trap[1], c.trap[2], c.trap[3], c.trap[4], c.trap[5], c.trap[6]);
+    for (int i = 0; i < c.trap[7] && i < 40; ++i) std::fprintf(stderr, " %d", c.trap[8 + i]);
+    std::fprintf(stderr, "\n");
+  }
+#endif
   if (c.error == 2) return fail(TB_ERR_STATE, "team formation failed: the " + std::to_string(s->plan.num_blocks) + " workgroups of the team kernel did not all become resident within " +
                                 "TB_TEAM_JOIN_MS (10 s) -- another process, a CU mask or a concurrent kernel holds part of the GPU; TB_TEAM=0 plans one workgroup per subproblem instead");
   if (c.error != 0) return fail(TB_ERR_DEPTH, "decision stack overflow: a workgroup went deeper than " + std::to_string((MAX_DEC_SEGS + 1) * (long long)s->plan.max_depth) +

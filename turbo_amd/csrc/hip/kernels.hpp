@@ -277,6 +277,17 @@ __device__ __forceinline__ int g_bl_total() { return g_bl.strat_total > 0 ? g_bl
 __device__ __forceinline__ constexpr int g_bl_total() { return 1; }
 #endif
 
+#ifdef TB_TRAP_SEED
+// Debugging aid (r06): the first workgroup that meets something impossible writes what it saw into Ctrl::trap and stops the search (tb_session_finish prints it).
+__device__ __noinline__ void trap_report(const DevProblem& P, BlockShared& sh, int code, const int* words, int n) {
+  Ctrl* c = glob(P.ctrl);
+  if (__hip_atomic_exchange(&c->error, 3, TB_RLX, TB_AGENT) != 0) return;
+  c->trap[0] = code; c->trap[1] = (int)blockIdx.x; c->trap[2] = (int)sh.bs.nodes; c->trap[3] = sh.depth; c->trap[4] = sh.new_depth; c->trap[5] = sh.remaining; c->trap[6] = sh.n_dec_seg; c->trap[7] = n;
+  for (int i = 0; i < n && i < 40; ++i) c->trap[8 + i] = words[i];
+  (void)__hip_atomic_fetch_or(&c->stop, STOP_HOST, TB_RLX, TB_AGENT);
+}
+#endif
+
 // ---- workgroup teams (store layout 5, r05) -----------------------------------------------------------------------------------------------
 // The workgroups resident on one XCD search ONE subproblem together, on ONE store in global memory (device_types.hpp: TeamCtl):
 //   * the store is read with agent-scope relaxed loads (`global_load ... sc1`: served by the XCD's L2, never by a CU's L1) and narrowed with agent-scope
@@ -1081,9 +1092,11 @@ __device__ __forceinline__ unsigned run_slice(const RunEnv& E, int& nar_all, Eva
 // Returns true (wave-uniform) when something was marked.
 template <int C>
 __device__ __forceinline__ bool mark_successors(const DevProblem& P, BlockShared& sh, unsigned* nxt, int s, const int4 pr, const int4 sc, int nar_all, int* census = nullptr) {
-  const int priv = (pr.x >> 8) & 7;  // operands private to this slice are flagged at pack time
-  int ex = (priv & 1) ? 0 : (nar_all & 3), ey = (priv & 2) ? 0 : ((nar_all >> 2) & 3), ez = (priv & 4) ? 0 : ((nar_all >> 4) & 3);
-  if (!wave_any((ex | ey | ez) != 0)) return false;
+  // word0 bits 4-9 (pack_props): bits 2k, 2k + 1 = operand k has a reader outside this slice -- a narrowing of an operand private to the slice wakes nobody.  (r05 kept three
+  // "private" flags and rebuilt this mask per lane and run: 14 VALU of every run by the block counts of r06, a dozen more than the two it takes now.)
+  const int e6 = nar_all & (pr.x >> 4) & 63;
+  if (!wave_any(e6 != 0)) return false;
+  int ex = e6 & 3, ey = (e6 >> 2) & 3, ez = (e6 >> 4) & 3;
   TB_REGION(39);
   bool did = false;
 #ifdef TB_TUNING
@@ -1414,7 +1427,14 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       TB_REGION(3);
       const int e = e0 + lane;
       const int entry = e < cnt ? es.list[TB_IDX(20, e, chg_cap)] : 0;
-      const int ev = e < cnt ? ((entry >> 30) & 3) : 0;
+      int ev = e < cnt ? ((entry >> 30) & 3) : 0;
+#ifdef TB_TRAP_SEED
+      // (debugging aid, r06: the intermittent memory fault of r04 is a change-list entry whose variable is -1 .. -128 -- var_adj + 32 GiB - 4 KiB; catch it before the load)
+      if (ev != 0 && (unsigned)(entry & 0x3fffffff) >= (unsigned)P.n_vars) {
+        { const int w[4] = {entry, e, cnt, es.list[1 - (e & 1)]}; trap_report(P, sh, 3, w, 4); }
+        ev = 0;
+      }
+#endif
       int deg = 0, off = 0;
       bool did = false;
       const bool more = mark_var(P, bm0, entry & 0x3fffffff, -1, ev, deg, off, did);
@@ -1429,8 +1449,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   if (tid == 0 && prof) { const long long t = wall_clock64(); TB_PROF_ADD(sh.bs, TB_PROF_SEEDING, t - tp0); tp0 = t; }  // profiling: seeding
   // ---- rounds
   // bits of a bitmap word owned by this wave: slices s with s % nw == wave (nw divides 32)
-  unsigned own = 0;
-  for (int b = wave; b < 32; b += nw) own |= 1u << b;
+  // (nw is 1, 2, 4, 8 or 16: the pattern 0...010...01 with a one every nw bits, shifted to this wave's residue -- r05 built it with a 16-iteration scalar loop, 210 SALU per
+  //  node and wave of accap_a3 by the block counts of r06, 4 % of the kernel's scalar instructions)
+  const unsigned own = (0xffffffffu / ((1u << nw) - 1u)) << wave;
   int rounds = 0;
   unsigned wave_iters_total = 0;  // wave-uniform
   unsigned wave_active_total = 0; // wave-uniform: the same, times the propagators of each slice (idle lanes of padded slices not counted)
@@ -1936,7 +1957,7 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
       const Itv X = load_dom<C>(store, P.n_int, pr.y), Y = load_dom<C>(store, P.n_int, pr.z), Z = load_dom<C>(store, P.n_int, pr.w);
       // (the witness is ONE record, the same in every lane: its own class as the slice's class set sends it down that class's body instead of every body behind selects)
       const Cand c = whole_slice ? evaluate_single<((C == 3 || C == 5) ? 1 : 0)>(pr.x, X, Y, Z)
-                                 : evaluate_packed<((C == 3 || C == 5) ? 1 : 0)>((pr.x & 0xffff) | ((1 << (__builtin_amdgcn_readfirstlane(pr.x) & 0xff)) << 16), X, Y, Z);
+                                 : evaluate_packed<((C == 3 || C == 5) ? 1 : 0)>((pr.x & 0xffff) | ((1 << (__builtin_amdgcn_readfirstlane(pr.x) & 0xf)) << 16), X, Y, Z);
       return wave_ballot(act && !c.ent);
     };
     int wit = __builtin_amdgcn_readfirstlane(ld(&sh.witness));
@@ -2136,6 +2157,9 @@ __device__ __forceinline__ bool push_decision(const DevProblem& P, BlockShared& 
   if (depth > 0) { const Decision& up = dec_at(P, sh, dec, depth - 1); d.rope[1] = up.rope[up.cur]; }
   else d.rope[1] = -1;
   dec_at(P, sh, dec, depth) = d;
+#ifdef TB_TRAP_SEED
+  if (var < 0) { const int w[10] = {d.var, d.cur, d.child[0].x, d.child[0].y, d.child[1].x, d.child[1].y, d.rope[0], d.rope[1], depth, val_order}; trap_report(P, sh, 1, w, 10); }
+#endif
   sh.depth = depth + 1;
   return true;
 }
@@ -2879,6 +2903,22 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_
         if (tid == 0) {
           TB_REGION(37);
           Decision& dd = dec_at(P, sh, dec, depth - 1);
+#ifdef TB_TRAP_SEED
+          if (dd.var < 0 || dd.var >= P.n_vars + 100000 || dd.cur < -1 || dd.cur > 0) {
+            int w[40];
+            const int* a = reinterpret_cast<const int*>(&dd);
+            for (int q = 0; q < 8; ++q) w[q] = a[q];
+            const int* bq = reinterpret_cast<const int*>(&dec_at(P, sh, dec, dcur - 1));
+            for (int q = 0; q < 8; ++q) w[8 + q] = bq[q];
+            w[16] = dcur; w[17] = depth; w[18] = lvl;
+            const int* cq = reinterpret_cast<const int*>(&dec_at(P, sh, dec, depth > 1 ? depth - 2 : 0));
+            for (int q = 0; q < 8; ++q) w[19 + q] = cq[q];
+            const int* dq = reinterpret_cast<const int*>(&dec_at(P, sh, dec, depth));
+            for (int q = 0; q < 8; ++q) w[27 + q] = dq[q];
+            w[35] = (int)(reinterpret_cast<size_t>(&dd) & 0xffffffffu); w[36] = (int)(reinterpret_cast<size_t>(dec) & 0xffffffffu);
+            trap_report(P, sh, 2, w, 37);
+          }
+#endif
           const int c = ++dd.cur;
           embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
           sh.cur_strategy = sh.snap_strategy;
@@ -2990,6 +3030,7 @@ __global__ void __launch_bounds__(1024, 4 * WG_PER_CU) solve_kernel_team(DevProb
     (void)team_sync(P, sh, 0u);  // (the slots may be written again after this)
   };
   fetch();
+  bool stopped_searching = false;  // the team was stopped in the middle of a subproblem (test aid: the path header)
 
   while (sh.has_work && !sh.stop) {
     // C. restore the root, striped over the members
@@ -3100,6 +3141,7 @@ __global__ void __launch_bounds__(1024, 4 * WG_PER_CU) solve_kernel_team(DevProb
       if (sh.t_dive != 0) end_of_dive_timer(sh);
       if (exhausted && !sh.stop && lead) bs.eps_solved += 1;
     }
+    stopped_searching = sh.stop != 0;  // (uniform: last written before a barrier) -- the fetch below reports "no work" after a stop
     fetch();
   }
   __syncthreads();
@@ -3108,7 +3150,7 @@ __global__ void __launch_bounds__(1024, 4 * WG_PER_CU) solve_kernel_team(DevProb
   if (P.g_path_hdr != nullptr && tid == 0) {
     PathHeader h;
     h.sub_idx = sh.sub_idx; h.remaining = sh.remaining; h.depth = sh.depth; h.last_obj_ub = sh.last_obj_ub; h.failed = sh.bot;
-    h.has_work = lead ? sh.has_work : 0; h.nodes = (int)bs.nodes;
+    h.has_work = (lead && (sh.has_work || stopped_searching)) ? 1 : 0; h.nodes = (int)bs.nodes;
     glob(P.g_path_hdr)[b] = h;
   }
   if (P.g_last != nullptr && lead) store_out<C, 0>(glob(P.g_last) + (size_t)b * VX, store, VX);  // test aid: the store the team stopped on (the leader's slot)

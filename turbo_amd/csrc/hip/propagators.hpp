@@ -219,7 +219,7 @@ __device__ __forceinline__ Cand evaluate_single(int w0, const Itv X, const Itv Y
 template <int NNF>
 __device__ __forceinline__ Cand evaluate_packed(int w0, const Itv X, const Itv Y, const Itv Z) {
   Cand c;
-  int cls = w0 & 0xff;
+  int cls = w0 & 0xf;  // (bits 4-9: which narrowings of the record's operands have a reader outside its slice, kernels.hpp: mark_successors)
   const int present = (__builtin_amdgcn_readfirstlane(w0) >> 16) & CLASS_SET_MASK;
   bool ent = false;
   // Class-pure slices (the records are sorted by class, engine.hip: to_internal): the commonest classes get a body
