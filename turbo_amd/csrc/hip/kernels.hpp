@@ -54,6 +54,7 @@
 #ifndef TB_SC_PREFETCH
 #define TB_SC_PREFETCH 0
 #endif
+
 #if TB_OUTLINE & 1
 #define TB_FIX_ATTR __noinline__
 #else
@@ -1238,12 +1239,17 @@ __device__ __forceinline__ unsigned lean_class_run_t(const RunEnv& E, const int 
       yl = sel(xnz && Y.lb == 0, 1, yl); yu = sel(xnz && Y.ub == 0, -1, yu);
       zl = sel(xnz && Z.lb == 0, 1, zl); zu = sel(xnz && Z.ub == 0, -1, zu);
       const unsigned uxl = (unsigned)imax(X.lb, 0), uxu = (unsigned)imax(X.ub, 0);
-      if (wave_any(act && Z.lb > 0)) {  // y within x / z (0 not in z)
+      // A narrowing pre-test before the divisions (r05 had it in the product rule of the global-memory kernels only): ceil(x.lb / z.ub) > y.lb <=> x.lb > y.lb * z.ub and
+      // floor(x.ub / z.lb) < y.ub <=> x.ub < y.ub * z.lb, and the same two cross products answer for z.  Near the fixpoint, where most passes happen, no lane needs a
+      // quotient: two multiplications instead of four unsigned divisions (~30 VALU each, for the whole wave).  r06 block counts: 430 VALU per product run of wordpress7_500.
+      const unsigned p1 = (unsigned)Y.lb * (unsigned)Z.ub, p2 = (unsigned)Y.ub * (unsigned)Z.lb;  // (products of a flagged slice stay below 2^30)
+      const bool need_y = Z.lb > 0 && (uxl > p1 || uxu < p2), need_z = Y.lb > 0 && (uxl > p2 || uxu < p1);
+      if (wave_any(act && need_y)) {  // y within x / z (0 not in z)
         const unsigned dzu = umax1(Z.ub), dzl = umax1(Z.lb);
         const int lo = (int)((uxl + dzu - 1u) / dzu), hi = (int)(uxu / dzl);
         yl = sel(Z.lb > 0, imax(yl, lo), yl); yu = sel(Z.lb > 0, imin(yu, hi), yu);
       }
-      if (wave_any(act && Y.lb > 0)) {  // z within x / y
+      if (wave_any(act && need_z)) {  // z within x / y
         const unsigned dyu = umax1(Y.ub), dyl = umax1(Y.lb);
         const int lo = (int)((uxl + dyu - 1u) / dyu), hi = (int)(uxu / dyl);
         zl = sel(Y.lb > 0, imax(zl, lo), zl); zu = sel(Y.lb > 0, imin(zu, hi), zu);
@@ -2710,6 +2716,9 @@ __device__ __forceinline__ void end_of_dive(const DevProblem& P, BlockShared& sh
 // SIMD (<= 72 VGPRs) so that 7 workgroups are resident per CU when their stores fit (wordpress7_500: 7 x 22.7 KB of
 // LDS; measured 17.9 / 20.5 / 22.3 / 23.4e6 nodes/s with 4 / 5 / 6 / 7); the sweep variants are VALU bound and keep 4.
 // OPT: the COMPACT store layout for the event kernels, entailed-slice removal for the sweeping ones.
+// (r06, measured and dropped: stating the occupancy as an exact range -- amdgpu_waves_per_eu(7, 7) -- does not buy scalar registers.  The 70-94 SGPRs these kernels spill into
+//  VGPR lanes (~500 v_readlane / v_writelane per node of wordpress7_500 by the block counts, 6 % of its vector issue) are the price of 7 waves per SIMD: 800 SGPRs / 7 = 114,
+//  minus the 16 the trap handler reserves, rounded down to the granule of 16 = 96 including VCC and friends -- 88 for the allocator, whatever the attribute says.  Six waves get 102.)
 template <int MEM, int TMAX, bool EVENT, int OPT>
 __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_EVENT_WAVES_C8 : TB_EVENT_WAVES) : ((EVENT && TMAX == 256) ? TB_EVENT_WAVES_256 : (TMAX == 256 ? 5 : 4))) solve_kernel(DevProblem by_value, const DevProblem* __restrict__ problem, Mailbox* mbox) {
   // The problem description is read through a pointer, not passed by value: as kernel arguments its ~70 scalars were all
