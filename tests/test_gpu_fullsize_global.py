@@ -95,3 +95,26 @@ def test_hot_tier_event_kernel_stands_on_the_oracles_stores_at_full_size(net, mo
     s.close()
     assert checked >= 16 and compared >= 8, f"{checked} workgroups replayed, {compared} stores compared"
     print(f"synthetic 100k x 500k, event on the hot tier: {checked} workgroups replayed, {compared} stores identical to the oracle's, deepest path {deepest}")
+
+
+def test_event_teams_of_the_real_xcds_stand_on_the_oracles_stores_at_full_size(net, monkeypatch):
+    """The event fixpoint shared by the workgroups of a team (r06, TB_TEAM_EVENT=1: kernel_opt 5 -- dirty bitmaps in global memory, slices owned by the team's 128 waves, one
+    team barrier per round): the 32 real-XCD teams of the full-size network under a node budget, every team's path replayed by the oracle."""
+    for k in ("TB_TEAM", "TB_TEAM_ALL", "TB_TEAM_SPLIT", "TB_TEAM_RELAXED", "TB_GLOBAL_SORT_WINDOW"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TB_TEAM_EVENT", "1")
+    s = capi.Session(net, capi.make_config(fixpoint=2, threads_per_block=1024, stop_after_n_nodes_total=2600, timeout_ms=300000, debug=KEEP))
+    plan = s.plan()
+    assert plan["kernel_opt"] == 5 and plan["kernel_event"] == 1 and plan["threads_per_block"] == 1024 and plan["mem_kind"] == 0, plan
+    s.start()
+    while not s.poll()[1]:
+        pass
+    has, best, st = s.finish()
+    assert st["nodes"] >= 2600 and not st["exhaustive"], "the budget must end the search"
+    leaders = [wg for wg in range(plan["num_blocks"]) if s.debug_path(wg)[0]["nodes"] > 0]
+    assert 8 <= len(leaders) <= 64, f"{len(leaders)} teams"
+    checked, compared, deepest = replay_sampled(net, s, plan, leaders, 32)
+    s.close()
+    # (all 32 teams are replayed: decisions, failed flags -- most of them stand on a failed node when the budget ends -- and the stores of those that do not)
+    assert checked >= 16 and compared >= 4, f"{checked} teams replayed, {compared} stores compared"
+    print(f"synthetic 100k x 500k, event fixpoint in teams: {len(leaders)} teams, {checked} replayed, {compared} stores identical to the oracle's, deepest path {deepest}")

@@ -73,6 +73,59 @@ def test_one_team_walks_the_oracles_tree_on_a_synthetic_network(team_env, fixpoi
         np.testing.assert_array_equal(best_g, best_o)
 
 
+@pytest.mark.parametrize("members", [1, 3, 16, 40])
+@pytest.mark.parametrize("rel", ["test_data/sudoku_opt4.fzn", "test_data/pat2.fzn", "test_data/pat7.fzn", "test_data/pennies5.fzn", "accap_a3.fzn"])
+def test_one_team_shares_the_rounds_of_the_event_fixpoint_and_walks_the_oracles_tree(team_env, rel, members):
+    """r06: the event-driven fixpoint of a team (kernels.hpp: fixpoint_event_team; TB_TEAM_EVENT=1, kernel_opt 5) -- dirty bitmaps in global memory, slices owned by the
+    team's waves, one team barrier per round, the change list replicated.  One team of 1 / 3 / 16 / 40 workgroups (ownership tables for team sizes that are not powers of
+    two) walks the ORACLE's tree node for node."""
+    team_env.setenv("TB_TEAM_ALL", "1")
+    team_env.setenv("TB_TEAM_EVENT", "1")
+    tcn = frontend.load_fzn(os.path.join(BENCH, rel))
+    power, cut = 4, 3000
+    has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power, cutnodes=cut)
+    cfg = dict(or_nodes=members, subproblems_power=power, stop_after_n_nodes=cut, timeout_ms=120000, fixpoint=2, **TEAM)
+    plan = plan_of(tcn, **cfg)
+    assert plan["kernel_opt"] == 5 and plan["kernel_event"] == 1, f"the event team kernel was not planned: {plan}"
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(**cfg))
+    assert has_g == has_o
+    for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
+        assert st_g[k] == st_o[k], k
+    if has_o:
+        np.testing.assert_array_equal(best_g, best_o)
+
+
+@pytest.mark.parametrize("members", [1, 5, 24])
+def test_one_event_team_walks_the_oracles_tree_on_a_synthetic_network(team_env, members):
+    from turbo_amd.synth import make_synthetic
+    team_env.setenv("TB_TEAM_ALL", "1")
+    team_env.setenv("TB_TEAM_EVENT", "1")
+    tcn = make_synthetic(3000, 14000, seed=11)
+    power, cut = 3, 600
+    has_o, best_o, st_o = pyoracle.solve(tcn, subproblems_power=power, cutnodes=cut)
+    cfg = dict(or_nodes=members, subproblems_power=power, stop_after_n_nodes=cut, timeout_ms=120000, fixpoint=2, **TEAM)
+    assert plan_of(tcn, **cfg)["kernel_opt"] == 5
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(**cfg))
+    assert has_g == has_o
+    for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
+        assert st_g[k] == st_o[k], k
+    if has_o:
+        np.testing.assert_array_equal(best_g, best_o)
+
+
+@pytest.mark.parametrize("rel,expected", [r for r in FAST if r[0].split("/")[-1] in ("pat2.fzn", "pat7.fzn", "pennies5.fzn", "sudoku_opt4.fzn", "bug4.fzn", "pat11.fzn", "reified_in.fzn", "sudoku_opt_p0.fzn")])
+def test_event_teams_of_the_real_xcds_prove_the_known_optima(team_env, rel, expected):
+    team_env.setenv("TB_TEAM_EVENT", "1")
+    tcn = frontend.load_fzn(os.path.join(BENCH, rel))
+    has, best, st = capi.solve(tcn, capi.make_config(timeout_ms=120000, fixpoint=2, **TEAM))
+    assert st["threads_per_block"] == 1024 and st["mem_kind"] == 0
+    assert has and st["exhaustive"] == 1
+    assert tcn.objective_of(best) == expected
+    _, failed, ent, _, _ = pyoracle.propagate(best, tcn.props)
+    assert not failed and ent
+    assert st["eps_solved_subproblems"] + st["eps_skipped_subproblems"] == 1 << st["subproblems_power"], "every subproblem exactly once"
+
+
 @pytest.mark.parametrize("window", [0, 128, 4096])
 @pytest.mark.parametrize("fixpoint", [1, 0], ids=["wac1", "ac1"])
 def test_record_windows_do_not_change_the_tree(team_env, fixpoint, window):

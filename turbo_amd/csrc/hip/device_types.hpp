@@ -219,6 +219,7 @@ struct DevProblem {
   int2* g_store;     // [B][V]  working store (GLOBAL mode only)
   int2* g_snap;      // [B][L][V] snapshot stack
   int2* g_best;      // [B][V]
+  unsigned* g_dirty; // [B][2][dirty_words] workgroup teams with the event fixpoint (layout 5, r06): the dirty bitmaps of a team (its leader's slab); nullptr otherwise
   int2* g_last;      // [B][V] test aid (tb_config.reserved[0] & 0x800000): the store of each workgroup when it left the kernel
   int* g_path_ub;    // [B][max_depth] same test aid: the objective's upper bound in force when decision i of the stack was taken
   PathHeader* g_path_hdr;  // [B] same test aid

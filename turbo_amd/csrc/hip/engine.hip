@@ -360,14 +360,19 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   // XCD share a store, which then sits in that XCD's L2.  (TB_TEAM=0 switches it off -- the hot tier then --, TB_TEAM=1 takes it wherever it is possible.)
   auto team_mode = [&]() {
     const char* e = std::getenv("TB_TEAM");
-    if (!search || event || lay.compact || T != 1024 || cfg.entailed_prop_removal || (e != nullptr && e[0] == '0')) return false;
+    // (r06: the event fixpoint in teams -- fixpoint_event_team -- is opt-in, TB_TEAM_EVENT=1, until it has been measured against the hot tier)
+    const char* ee = std::getenv("TB_TEAM_EVENT");
+    if (event && !(ee != nullptr && ee[0] == '1')) return false;
+    if (!search || lay.compact || T != 1024 || cfg.entailed_prop_removal || (e != nullptr && e[0] == '0')) return false;
     // r05, same box, synthetic 100k x 500k with the product fast path in: hot tier 9.8e10 propagations/s (wac1) / 8.9e10 (ac1); four teams per XCD 1.09e11 / 1.11e11,
     // eight 1.10e11 / 1.07e11, two 1.02e11 / 1.05e11 -- so teams are the plan wherever the hot tier was (profiles/r05_team_ab.txt)
     return (e != nullptr && e[0] == '1') || n_vars > HOT_VARS;
   };
+  // (teams with the event fixpoint: LDS holds the workgroup's ownership table -- 16 waves x dirty_words -- and the change list; the bitmaps are the team's, in global memory)
+  const size_t team_event_lds = fixed + align16((size_t)16 * (size_t)dirty_words * 4) + align16((size_t)p.chg_cap * 4);
   if (cfg.only_global_memory) {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
-    if (team_mode()) { p.team = true; p.blocks_per_cu = TB_TEAM_WG_PER_CU; }
+    if (team_mode()) { p.team = true; p.blocks_per_cu = TB_TEAM_WG_PER_CU; if (event) p.shared_bytes = (int)team_event_lds; }
     else if (hot_tier()) { p.hot = true; p.blocks_per_cu = 1; p.shared_bytes = (int)(fixed + (size_t)HOT_VARS * 8 + dirty_b); }
   } else if (!event && !lay.compact && lds_footprint(caps, fixed + store_b + props_b) * (size_t)bpc_max <= lds) {
     // (records in LDS: the plain sweeps on small networks only.  The event kernels and the compact layouts have no such instantiation:
@@ -385,7 +390,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
     p.mem_kind = TB_MEM_STORE_SHARED; p.blocks_per_cu = (int)(lds / lds_footprint(caps, fixed + store_b)); p.shared_bytes = (int)(fixed + store_b);
   } else {
     p.mem_kind = TB_MEM_GLOBAL; p.blocks_per_cu = bpc_max; p.shared_bytes = (int)(fixed + dirty_b);
-    if (team_mode()) { p.team = true; p.blocks_per_cu = TB_TEAM_WG_PER_CU; }
+    if (team_mode()) { p.team = true; p.blocks_per_cu = TB_TEAM_WG_PER_CU; if (event) p.shared_bytes = (int)team_event_lds; }
     else if (hot_tier()) { p.hot = true; p.blocks_per_cu = 1; p.shared_bytes = (int)(fixed + (size_t)HOT_VARS * 8 + dirty_b); }
   }
   long long blocks = (long long)p.blocks_per_cu * caps.cus;
@@ -422,7 +427,7 @@ int plan_launch(const tb_config& cfg, const DeviceCaps& caps, const Layout& lay,
   p.snapshot_levels = std::max(1, std::min(L, p.max_depth));
   p.kernel_event = event ? 1 : 0;
   // sweeps: entailed-slice removal (bit 0) or a compact layout (2: COMPACT, 4: COMPACT16) -- not both, to keep the number of kernels down
-  p.kernel_opt = p.team ? TEAM_SWEEP_OPT : (p.hot ? (event ? HOT_EVENT_OPT : HOT_SWEEP_OPT) : (event ? p.compact : (cfg.entailed_prop_removal != 0 ? 1 : p.compact * 2)));
+  p.kernel_opt = p.team ? (event ? TEAM_EVENT_OPT : TEAM_SWEEP_OPT) : (p.hot ? (event ? HOT_EVENT_OPT : HOT_SWEEP_OPT) : (event ? p.compact : (cfg.entailed_prop_removal != 0 ? 1 : p.compact * 2)));
   *plan = p;
   return TB_OK;
 }
@@ -1592,6 +1597,8 @@ int tb_session_create(const tb_config* cfg_in, int32_t n_vars, const tb_itv* roo
   P.team_relaxed = (std::getenv("TB_TEAM_RELAXED") != nullptr && std::getenv("TB_TEAM_RELAXED")[0] == '0') ? 0 : 1;  // (TB_TEAM_RELAXED=0: acq_rel fences around the barrier, -3 .. -4 %)
   { const char* e = std::getenv("TB_TEAM_JOIN_MS"); const long long ms = e ? std::max(1, std::atoi(e)) : 10000; P.team_join_ticks = (int)std::min<long long>(0x7fffffff, ms * (long long)s->caps.wall_khz); }
   if (plan.team && (rc = s->bufs.alloc(&P.teams, 1)) != TB_OK) return rc;
+  P.g_dirty = nullptr;
+  if (plan.team && plan.kernel_event && (rc = s->bufs.alloc(&P.g_dirty, B * 2 * (size_t)plan.dirty_words)) != TB_OK) return rc;
   P.blk_counts = nullptr;
   if (std::getenv("TB_BLOCK_COUNTS") != nullptr) {  // (instrumented build, scripts/instr_blocks.py: per-XCD arrays of basic-block execution counts, zeroed here, written out by tb_session_finish)
     if ((rc = s->bufs.alloc(&P.blk_counts, 8 * BLK_COUNT_STRIDE / sizeof(unsigned))) != TB_OK) return rc;

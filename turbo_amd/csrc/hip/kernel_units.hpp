@@ -16,12 +16,13 @@ struct KernelGrid { int blocks, threads, shared_bytes; hipStream_t stream; };
 constexpr int HOT_EVENT_OPT = 3;    // kernel_opt of a search on the hot tier (event kernel: the layout itself)
 constexpr int HOT_SWEEP_OPT = 6;    // ... sweeps: layout 3 << 1
 constexpr int TEAM_SWEEP_OPT = 10;  // kernel_opt of a plan that searches in workgroup teams (sweeps, layout 5 << 1)
+constexpr int TEAM_EVENT_OPT = 5;   // ... with the event-driven fixpoint (the layout itself; r06, TB_TEAM_EVENT=1)
 
 // 1-5: the search kernel (1: 128-thread event, 2: 256-thread event, 3: 1024-thread event + hot tier, 4: 256-thread sweeps, 5: 1024-thread sweeps + hot tier + teams);
 // 6-9: batch propagation (6: event <= 256, 7: event 1024, 8: sweeps <= 256, 9: sweeps 1024)
 inline int kernel_unit(bool solve, const KernelSel& k) {
   if (solve) {
-    if (k.opt == HOT_EVENT_OPT && k.event) return 3;
+    if ((k.opt == HOT_EVENT_OPT || k.opt == TEAM_EVENT_OPT) && k.event) return 3;
     if ((k.opt == HOT_SWEEP_OPT || k.opt == TEAM_SWEEP_OPT) && !k.event) return 5;
     if (k.tmax == 128) return 1;
     if (k.tmax <= 256) return k.event ? 2 : 4;

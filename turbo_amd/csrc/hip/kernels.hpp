@@ -982,6 +982,7 @@ struct EventState {
   const int4* succ;       // successor records: DevProblem::succ, or their copy in LDS (TCN_SHARED)
   unsigned char* unent;   // behind the store (LDS or HBM slab): one byte per slice for the sweeps (entailed-slice removal), one BIT per slice (32-bit words) for the event fixpoint
   int words, cap;
+  const unsigned* own;    // workgroup teams (layout 5, fixpoint_event_team): LDS table [waves of the workgroup][words], bit s & 31 of word s >> 5 = slice s is this wave's
 };
 
 // `ev`: EV_LB / EV_UB bits (what happened to v); stored in the two top bits of the entry
@@ -990,9 +991,11 @@ __device__ __forceinline__ void note_change(BlockShared& sh, const EventState& e
   append_change(cl, v | (ev << 30));
 }
 
+// (SC: the scope of the bitmap -- a workgroup's LDS, or, for the event fixpoint of a workgroup team (r06), the team's bitmap in global memory: agent scope)
+template <int SC = TB_WG>
 __device__ __forceinline__ void mark_slice(unsigned* dirty, int t) {
   t = TB_IDX(10, t, n_slices);
-  (void)__hip_atomic_fetch_or(&dirty[t >> 5], 1u << (t & 31), TB_RLX, TB_WG);
+  (void)__hip_atomic_fetch_or(&dirty[t >> 5], 1u << (t & 31), TB_RLX, SC);
 }
 
 // Events a variable can undergo: EV_LB its lower bound was raised, EV_UB its upper bound was lowered.  A reader slice is woken
@@ -1000,11 +1003,12 @@ __device__ __forceinline__ void mark_slice(unsigned* dirty, int t) {
 constexpr int EV_LB = 1, EV_UB = 2;
 
 // Up to two successor slices packed with the record (16-bit ids, 0xffff = none; `interest`: 2 bits each).  True when something was marked.
+template <int SC = TB_WG>
 __device__ __forceinline__ bool mark_packed(unsigned* dirty, unsigned packed, int interest, int ev) {
   const unsigned s0 = packed & 0xffffu, s1 = packed >> 16;
   const bool m0 = s0 != 0xffffu && (interest & ev) != 0, m1 = s1 != 0xffffu && ((interest >> 2) & ev) != 0;
-  if (m0) mark_slice(dirty, (int)s0);
-  if (m1) mark_slice(dirty, (int)s1);
+  if (m0) mark_slice<SC>(dirty, (int)s0);
+  if (m1) mark_slice<SC>(dirty, (int)s1);
   return m0 | m1;
 }
 
@@ -1012,6 +1016,7 @@ __device__ __forceinline__ bool mark_packed(unsigned* dirty, unsigned packed, in
 // from the variable's 32-byte adjacency record (DevProblem::var_adj: halfword 0 = number of reader slices, halfwords 1-11 =
 // the first eleven, word 6 = their interests, word 7 = offset of the others in DevProblem::adj_rest).  One L2 round trip
 // whatever the degree up to 11; returns true when the list is longer (mark_tail).
+template <int SC = TB_WG>
 __device__ __forceinline__ bool mark_var(const DevProblem& P, unsigned* dirty, int v, int self, int ev, int& deg_out, int& off_out, bool& did) {
   int4 a = make_int4(0, 0, 0, 0), b = a;
   if (ev) { v = TB_IDX(11, v, adj_vars); a = glob(P.var_adj)[2 * (size_t)v]; b = glob(P.var_adj)[2 * (size_t)v + 1]; }
@@ -1022,13 +1027,14 @@ __device__ __forceinline__ bool mark_var(const DevProblem& P, unsigned* dirty, i
     if (!wave_any(j < deg)) break;  // wave-uniform: most variables have four or five readers, not eleven
     const int hw = j + 1;
     const int t = (int)((hw & 1) ? (w[hw >> 1] >> 16) : (w[hw >> 1] & 0xffffu));
-    if (j < deg && t != self && ((w[6] >> (2 * j)) & (unsigned)ev)) { mark_slice(dirty, t); did = true; }
+    if (j < deg && t != self && ((w[6] >> (2 * j)) & (unsigned)ev)) { mark_slice<SC>(dirty, t); did = true; }
   }
   deg_out = deg;
   off_out = (int)w[7];
   return deg > 11;
 }
 // the tail of the lists longer than 11, cooperatively: one lane at a time is broadcast, the 64 lanes stride over its list
+template <int SC = TB_WG>
 __device__ __forceinline__ bool mark_tail(const DevProblem& P, unsigned* dirty, unsigned long long mask, int deg, int off, int ev, int self) {
   const int lane = here(threadIdx.x) & 63;
   bool did = false;
@@ -1038,7 +1044,7 @@ __device__ __forceinline__ bool mark_tail(const DevProblem& P, unsigned* dirty, 
     const int d = __builtin_amdgcn_readlane(deg, l), o = __builtin_amdgcn_readlane(off, l), e = __builtin_amdgcn_readlane(ev, l);
     for (int j = lane; j < d - 11; j += 64) {
       const int t = glob(P.adj_rest)[TB_IDX(12, o + j, adj_rest)];
-      if ((t & 0x3fffffff) != self && ((t >> 30) & e)) { mark_slice(dirty, t & 0x3fffffff); did = true; }
+      if ((t & 0x3fffffff) != self && ((t >> 30) & e)) { mark_slice<SC>(dirty, t & 0x3fffffff); did = true; }
     }
   }
   return did;
@@ -1109,9 +1115,10 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, BlockShared
 #endif
   // events whose interested readers all sit in the record's two slots are served from there; the others walk the variable's record
   const int ovx = (sc.w & 1) | ((sc.w >> 15) & 2), ovy = ((sc.w >> 1) & 1) | ((sc.w >> 16) & 2), ovz = ((sc.w >> 2) & 1) | ((sc.w >> 17) & 2);
-  if (ex & ~ovx) did |= mark_packed(nxt, (unsigned)sc.x, sc.w >> 4, ex & ~ovx);
-  if (ey & ~ovy) did |= mark_packed(nxt, (unsigned)sc.y, sc.w >> 8, ey & ~ovy);
-  if (ez & ~ovz) did |= mark_packed(nxt, (unsigned)sc.z, sc.w >> 12, ez & ~ovz);
+  constexpr int SC = C == 5 ? TB_AGENT : TB_WG;  // (layout 5: the bitmap of a workgroup team lives in global memory)
+  if (ex & ~ovx) did |= mark_packed<SC>(nxt, (unsigned)sc.x, sc.w >> 4, ex & ~ovx);
+  if (ey & ~ovy) did |= mark_packed<SC>(nxt, (unsigned)sc.y, sc.w >> 8, ey & ~ovy);
+  if (ez & ~ovz) did |= mark_packed<SC>(nxt, (unsigned)sc.z, sc.w >> 12, ez & ~ovz);
   ex &= ovx; ey &= ovy; ez &= ovz;
   if (wave_any((ex | ey | ez) != 0)) {
     TB_REGION(40);
@@ -1123,9 +1130,9 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, BlockShared
     }
 #endif
     int dx = 0, dy = 0, dz = 0, ox = 0, oy = 0, oz = 0;
-    const bool tx = mark_var(P, nxt, var_of<C>(pr.y), s, ex, dx, ox, did);
-    const bool ty = mark_var(P, nxt, var_of<C>(pr.z), s, ey, dy, oy, did);
-    const bool tz = mark_var(P, nxt, var_of<C>(pr.w), s, ez, dz, oz, did);
+    const bool tx = mark_var<SC>(P, nxt, var_of<C>(pr.y), s, ex, dx, ox, did);
+    const bool ty = mark_var<SC>(P, nxt, var_of<C>(pr.z), s, ey, dy, oy, did);
+    const bool tz = mark_var<SC>(P, nxt, var_of<C>(pr.w), s, ez, dz, oz, did);
     const unsigned long long mx = wave_ballot(tx), my = wave_ballot(ty), mz = wave_ballot(tz);
     bool dt = false;
 #ifdef TB_TUNING
@@ -1136,9 +1143,9 @@ __device__ __forceinline__ bool mark_successors(const DevProblem& P, BlockShared
         if (degs[q] > 0) (void)__hip_atomic_fetch_add(&census[degs[q] <= 4 ? 17 : (degs[q] <= 6 ? 18 : (degs[q] <= 11 ? 19 : 20))], 1, TB_RLX, TB_WG);
     }
 #endif
-    if (mx) dt |= mark_tail(P, nxt, mx, dx, ox, ex, s);
-    if (my) dt |= mark_tail(P, nxt, my, dy, oy, ey, s);
-    if (mz) dt |= mark_tail(P, nxt, mz, dz, oz, ez, s);
+    if (mx) dt |= mark_tail<SC>(P, nxt, mx, dx, ox, ex, s);
+    if (my) dt |= mark_tail<SC>(P, nxt, my, dy, oy, ey, s);
+    if (mz) dt |= mark_tail<SC>(P, nxt, mz, dz, oz, ez, s);
     did |= dt;
 #ifdef TB_TUNING
     if (census != nullptr) { const long long t_ = clock64(); if ((threadIdx.x & 63) == 0) census[21] += (int)((t_ - t_var) >> 4); }
@@ -1537,6 +1544,8 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
         const int4 sc = sc_cur;
         if (s_next >= 0) sc_cur = (es.succ + (size_t)s_next * 64)[lane];
 #endif
+        // (r06, measured and dropped: the table in reverse order right below the records, addressed from the record pointer this loop holds anyway -- one dependent scalar
+        //  load fewer per run, ~100 scalar instructions more per node for the 64-bit address: wordpress7_500 6.112e7 -> 6.111e7 nodes/s, trains15 +0.5 %, accap_a3 -0.2 %)
         const int2 info = cst(P.slice_info)[s];
 #if !TB_SC_PREFETCH
         const int4* const succ_slice = es.succ + (size_t)s * 64;  // uniform base + lane: no 64-bit VALU address arithmetic
@@ -1987,6 +1996,160 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
   }
   __syncthreads();
   TB_REGION(24);
+  all_entailed = !ld(&sh.unent[0]);
+  return rounds + 1;
+}
+
+// ---- event-driven fixpoint of a workgroup TEAM (store layout 5; r06) ---------------------------------------------------------------------------
+// The event fixpoint on the hot tier (layout 3: one 1024-thread workgroup per subproblem, an 800 KB store per workgroup of the synthetic 100k x 500k network) is the one kernel
+// of this engine that is limited by the memory side: 256 stores do not fit the L2s (hit rate 0.43, 35 B of fabric reads per propagation).  Here the workgroups of a team search ONE
+// subproblem on ONE store in global memory, as for the sweeps (solve_kernel_team), and share the ROUNDS of the event fixpoint:
+//   * the two dirty bitmaps live in global memory (DevProblem::g_dirty, the slab of the team's leader), touched with agent-scope atomics like the store;
+//   * slice s belongs to wave (s mod G) of the team's G = members x 16 waves (EventState::own: the bits of every bitmap word that are this wave's, built once per kernel in LDS),
+//     which clears the bit before it loads a domain and is the only one to do so -- static ownership, as inside a workgroup;
+//   * a round ends with ONE team barrier that merges "somebody marked a slice for the next round / failed / ran out of time": every member takes the same decision to go on;
+//   * every member applies the same decisions to the shared store; whoever's atomic moved the bound notes the change in ITS list, and every member seeds from its own;
+//   * the all-entailed test (witness) is evaluated by every member on the shared store -- the same propagator, the same answer.
+// Runs are the generic ones (`apply`): a store in global memory keeps the caller's record order, whose slices hold several classes.  Same fixpoint, same tree.
+__device__ __forceinline__ int fixpoint_event_team(const DevProblem& P, BlockShared& sh, int2* store, const int4* props, const EventState& es, ThreadCounters& tc, bool& all_entailed) {
+  constexpr int C = 5;
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = T >> 6;
+  const int M = team_size(sh), m = team_member(sh);
+  const int n = P.n_props, W = es.words, S = P.n_slices;
+  unsigned* const dirty = glob(es.dirty);
+  unsigned* const ubits = glob(reinterpret_cast<unsigned*>(es.unent));  // bit s: some propagator of slice s was not entailed when it last ran (behind the team's store)
+  const unsigned* const own = es.own + wave * W;
+  const int cnt = ld(&sh.chg_count[0]);
+  const bool root_pass = ld(&sh.ev_all) != 0;
+  const bool all = root_pass || cnt > es.cap;
+  const bool drop_entailed = !root_pass;
+  // ---- initial dirty set (bitmap 0)
+  if (all) {
+    for (int i = m * T + tid; i < W; i += M * T) {
+      const int left = S - i * 32;
+      const unsigned v = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+      __hip_atomic_store(&dirty[i], v, TB_RLX, TB_AGENT);
+      if (root_pass) __hip_atomic_store(&ubits[i], v, TB_RLX, TB_AGENT);
+    }
+  } else {
+    // (every member applies the same decisions to the shared store, but only the one whose atomic actually moved a bound notes the change -- the others find it moved already:
+    //  the members' change lists are SUBSETS whose union is complete, so every member seeds its whole list; a mark is an idempotent OR)
+    for (int e0 = wave * 64; e0 < cnt; e0 += T) {
+      const int e = e0 + lane;
+      const int entry = e < cnt ? es.list[TB_IDX(20, e, chg_cap)] : 0;
+      const int ev = e < cnt ? ((entry >> 30) & 3) : 0;
+      int deg = 0, off = 0;
+      bool did = false;
+      const bool more = mark_var<TB_AGENT>(P, dirty, entry & 0x3fffffff, -1, ev, deg, off, did);
+      const unsigned long long mm = wave_ballot(more);
+      if (mm) (void)mark_tail<TB_AGENT>(P, dirty, mm, deg, off, ev, -1);
+    }
+  }
+  if (tid == 0) { st(&sh.unent[0], 0); st(&sh.flag[0], 0); st(&sh.flag[1], 0); st(&sh.flag[2], 0); }
+  (void)team_sync(P, sh, 0u);  // the seeds of every member are in the bitmap (every wave has waited for its own atomics)
+  if (tid == 0) { st(&sh.ev_all, 0); st(&sh.chg_count[0], 0); }
+  int rounds = 0;
+  unsigned wave_iters_total = 0, wave_active_total = 0;
+  for (;; ++rounds) {
+    const int k = rounds % 3;
+    unsigned* const cur = dirty + (rounds & 1) * W;
+    unsigned* const nxt = dirty + ((rounds + 1) & 1) * W;
+    bool marked = false;  // wave-uniform
+    for (int base = 0; base < W; base += 64) {
+      const int wi = base + lane;
+      unsigned w = wi < W ? (__hip_atomic_load(&cur[wi], TB_RLX, TB_AGENT) & own[wi]) : 0u;
+      if (w != 0) (void)__hip_atomic_fetch_and(&cur[wi], ~w, TB_RLX, TB_AGENT);  // mine, cleared before any domain is loaded
+      if (drop_entailed && w != 0) w &= __hip_atomic_load(&ubits[wi], TB_RLX, TB_AGENT);  // entailed-slice removal
+      unsigned long long nz = wave_ballot(w != 0);
+      unsigned word = 0;
+      int wl = 0;
+      auto next_slice = [&]() -> int {
+        while (word == 0) {
+          if (nz == 0) return -1;
+          wl = __builtin_ctzll(nz);
+          nz &= nz - 1;
+          word = (unsigned)__builtin_amdgcn_readlane((int)w, wl);
+        }
+        const int b = __builtin_ctz(word);
+        word &= word - 1;
+        return (base + wl) * 32 + b;
+      };
+      for (int s = next_slice(); s >= 0; s = next_slice()) {
+        if (dead_node(sh)) break;  // the node failed in another wave of this member (the other members learn it at the round's barrier)
+        s = TB_IDX(13, s, n_slices);
+        const int4 pr = props[s * 64 + lane];  // (the arrays are padded to whole slices)
+        const int4 sc = (es.succ + (size_t)s * 64)[lane];
+        const bool act = s * 64 + lane < n;
+        int nar_all = 0;
+        unsigned iters = 0;
+        for (;;) {  // the slice's local fixpoint (WAC1)
+          bool ch = false, un_i = false;
+          int nar = 0;
+          apply<true, C>(pr, act, store, P.n_int, &sh.bot, ch, un_i, tc, 0, &nar);
+          ++iters;
+          nar_all |= nar;
+          if (!wave_any(ch)) {
+            if (!wave_any(un_i) && lane == 0) (void)__hip_atomic_fetch_and(&ubits[s >> 5], ~(1u << (s & 31)), TB_RLX, TB_AGENT);  // 1 -> 0 only: entailment is monotone below a node
+            break;
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the narrowings are agent-scope atomics on the team's store: acknowledged before the next pass reads it)
+          if (ld(&sh.bot)) break;
+          if ((iters % WAVE_WATCHDOG_PERIOD) == 0) {
+            if (lane == 0 && deadline_passed(P)) st(&sh.abort, 1);
+            if (ld(&sh.abort)) break;
+          }
+        }
+        marked |= mark_successors<C>(P, sh, nxt, s, pr, sc, nar_all);
+        wave_iters_total += iters;
+        wave_active_total += iters * (unsigned)__builtin_popcountll(wave_ballot(act));
+      }
+    }
+    // ---- end of the round: one team barrier
+    if (marked && lane == 0) st(&sh.flag[k], 1);
+    if (tid == 0 && (rounds & 255) == 255 && deadline_passed(P)) st(&sh.abort, 1);
+    __syncthreads();
+    const unsigned mine = (ld(&sh.flag[k]) ? TEAM_CHANGED : 0u) | (ld(&sh.bot) ? TEAM_BOT : 0u) | (ld(&sh.abort) ? TEAM_ABORT : 0u);
+    const unsigned agreed = team_sync(P, sh, mine);
+    if (tid == 0) {
+      st(&sh.flag[(k + 1) % 3], 0);
+      if (agreed & TEAM_BOT) st(&sh.bot, 1);
+      if (agreed & TEAM_ABORT) st(&sh.abort, 1);
+    }
+    __syncthreads();
+    if (!(agreed & TEAM_CHANGED) || (agreed & (TEAM_BOT | TEAM_ABORT))) break;
+  }
+  if (lane == 0 && wave_iters_total != 0) { add_deductions(sh, 64ull * wave_iters_total); add_active(sh, (unsigned long long)wave_active_total); }
+  // leave both bitmaps empty for the next node (they are not after a failure); nobody reads them after the last barrier, and the next barrier of the node orders these stores
+  // before the next node's seeds
+  for (int i = m * T + tid; i < 2 * W; i += M * T) __hip_atomic_store(&dirty[i], 0u, TB_RLX, TB_AGENT);
+  // ---- is every propagator entailed?  (the witness of fixpoint_event, evaluated by every member on the shared store)
+  if (wave == 0 && !dead_node(sh)) {
+    auto unentailed_lanes = [&](int first_prop, bool whole_slice) -> unsigned long long {
+      const int i = whole_slice ? first_prop + lane : first_prop;
+      const bool act = i < n;
+      const int4 pr = props[TB_IDX(19, act ? i : 0, records)];
+      const Itv X = load_dom<C>(store, P.n_int, pr.y), Y = load_dom<C>(store, P.n_int, pr.z), Z = load_dom<C>(store, P.n_int, pr.w);
+      const Cand c = whole_slice ? evaluate_single<1>(pr.x, X, Y, Z) : evaluate_packed<1>((pr.x & 0xffff) | ((1 << (__builtin_amdgcn_readfirstlane(pr.x) & 0xf)) << 16), X, Y, Z);
+      return wave_ballot(act && !c.ent);
+    };
+    int wit = __builtin_amdgcn_readfirstlane(ld(&sh.witness));
+    bool confirmed = wit >= 0 && unentailed_lanes(wit, false) != 0;
+    for (int base = 0; !confirmed && base < W; base += 64) {
+      const int wi = base + lane;
+      const unsigned word = wi < W ? __hip_atomic_load(&ubits[wi], TB_RLX, TB_AGENT) : 0u;
+      for (unsigned long long mk = wave_ballot(word != 0); mk && !confirmed; mk &= mk - 1) {
+        const int wl = __builtin_ctzll(mk);
+        for (unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)word, wl); bits && !confirmed; bits &= bits - 1) {
+          const int sl = (base + wl) * 32 + __builtin_ctz(bits);
+          const unsigned long long un = unentailed_lanes(sl * 64, true);
+          if (un) { wit = sl * 64 + __builtin_ctzll(un); confirmed = true; }
+          else if (lane == 0) (void)__hip_atomic_fetch_and(&ubits[sl >> 5], ~(1u << (sl & 31)), TB_RLX, TB_AGENT);  // every propagator of the slice is entailed now
+        }
+      }
+    }
+    if (lane == 0) { st(&sh.witness, confirmed ? wit : -1); st(&sh.unent[0], confirmed ? 1 : 0); }
+  }
+  __syncthreads();
   all_entailed = !ld(&sh.unent[0]);
   return rounds + 1;
 }
@@ -2502,7 +2665,9 @@ __device__ __forceinline__ void propagate_node_impl(const DevProblem& P, BlockSh
   if (tid == 0) { const long long t0 = wall_clock64(); bs.timers[TB_T_SEARCH] += t0 - sh.t_mark; sh.t_mark = t0; }
   bool all_entailed = false;
   int iters;
-  if constexpr (EVENT) {
+  if constexpr (EVENT && C == 5) {
+    iters = fixpoint_event_team(P, sh, store, props, es, tc, all_entailed);
+  } else if constexpr (EVENT) {
     constexpr bool SL = MEM >= TB_MEM_STORE_SHARED, PL = MEM == TB_MEM_TCN_SHARED;
     const FpResult r = fixpoint_event_call<C, MEM, TB>(&P, lds_off(&sh), SL ? lds_off(store) : 0u, SL ? nullptr : store, PL ? lds_off(props) : 0u, PL ? nullptr : props,
                                                    lds_off(es.dirty), lds_off(es.list), tc.writes);
@@ -2987,7 +3152,8 @@ __global__ void __launch_bounds__(TMAX, (EVENT && TMAX == 128) ? (OPT == 4 ? TB_
 // Between "the last read of this node's store" and "the first write for the next node" stands a team barrier: a member that is still selecting a variable must
 // not see the decision a faster member has already applied.
 // (a template only so that it is instantiated by the translation unit that launches it, kernel_units.inc: unit 5)
-template <int WG_PER_CU>
+// EVENT (r06): the members share the rounds of the event-driven fixpoint (fixpoint_event_team) instead of partitioned sweeps.
+template <int WG_PER_CU, bool EVENT = false>
 __global__ void __launch_bounds__(1024, 4 * WG_PER_CU) solve_kernel_team(DevProblem P, Mailbox* mbox) {
   __builtin_amdgcn_s_dcache_inv();
   constexpr int C = 5;
@@ -3021,6 +3187,26 @@ __global__ void __launch_bounds__(1024, 4 * WG_PER_CU) solve_kernel_team(DevProb
   // the team's store and snapshot stack: the slabs of its leader's workgroup (every workgroup has slabs; a team uses one set); the leader's best store is its own slab
   int2* const store = glob(P.g_store) + (size_t)slab * VX;
   int2* const snap = glob(P.g_snap) + (size_t)slab * P.snapshot_levels * VX;
+  if constexpr (EVENT) {
+    // LDS behind the control block: [this workgroup's ownership table: waves x words][change list]; the dirty bitmaps are the team's, in global memory
+    const int W = P.dirty_words, nw = (int)blockDim.x >> 6, G = M * nw;
+    unsigned* own_tab = reinterpret_cast<unsigned*>(smem + SH_BYTES);
+    for (int q = tid; q < nw * W; q += (int)blockDim.x) {
+      const int wv = q / W, wi = q - wv * W, g = m * nw + wv;
+      unsigned bits = 0;
+      for (int bq = (((g - (wi * 32) % G) % G) + G) % G; bq < 32; bq += G) bits |= 1u << bq;  // slices s = 32 wi + bq with s mod G == g
+      own_tab[q] = bits;
+    }
+    es.own = own_tab;
+    es.dirty = glob(P.g_dirty) + (size_t)slab * 2 * (size_t)W;
+    es.list = reinterpret_cast<int*>(smem + SH_BYTES + (((size_t)nw * (size_t)W * 4 + 15) / 16) * 16);
+    es.unent = reinterpret_cast<unsigned char*>(store) + P.unent_off;
+    es.succ = glob(P.succ);
+    es.words = W; es.cap = P.chg_cap;
+    // (the team's bitmaps start empty: the leader's slab is cleared by its members before the first barrier below)
+    for (int q = m * (int)blockDim.x + tid; q < 2 * W; q += M * (int)blockDim.x) __hip_atomic_store(&glob(es.dirty)[q], 0u, TB_RLX, TB_AGENT);
+    __syncthreads();
+  }
   Decision* const dec = glob(P.g_dec) + (size_t)b * P.max_depth;  // (a copy of the decision stack per member: the control is replicated)
   const int4* const props = P.props;
   // rows of a block copy that are this member's (even boundaries: 16-byte granules stay whole)
@@ -3050,6 +3236,7 @@ __global__ void __launch_bounds__(1024, 4 * WG_PER_CU) solve_kernel_team(DevProb
       sh.last_obj_ub = PINF;
       sh.t_dive = wall_clock64();
       if (P.subproblems_power == 0) end_of_dive(P, sh);
+      if (EVENT) { sh.ev_all = P.root_fixpoint ? 0 : 1; sh.chg_count[0] = 0; }  // a root that is not a fixpoint: every slice runs once
     }
     (void)team_sync(P, sh, 0u);
     bool exhausted = false;
@@ -3074,13 +3261,13 @@ __global__ void __launch_bounds__(1024, 4 * WG_PER_CU) solve_kernel_team(DevProb
         if (tid == 0) {
           const int g = (int)(unsigned)team_read(P, sh, 2);
           if (g == NINF) sh.stop = 1;
-          else if (g != PINF) { sh.last_obj_ub = g - 1; (void)embed0<C>(store, P.n_int, &sh.bot, P.obj_var, NINF, g - 1); }
+          else if (g != PINF) { sh.last_obj_ub = g - 1; embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, P.obj_var, NINF, g - 1); }
         }
         (void)team_sync(P, sh, 0u);
         if (sh.stop) break;
       }
       // II. propagate (the sweeps are partitioned, the verdict is everybody's; ends with the team's agreement on stopping)
-      propagate_node_impl<false, C, false, TB_MEM_GLOBAL, 0, true>(P, sh, store, props, es, nullptr, mbox, tc);
+      propagate_node_impl<EVENT, C, false, TB_MEM_GLOBAL, 0, true>(P, sh, store, props, es, nullptr, mbox, tc);
       if (sh.stop) break;
       // III. branch
       if (!sh.leaf) {
@@ -3102,12 +3289,12 @@ __global__ void __launch_bounds__(1024, 4 * WG_PER_CU) solve_kernel_team(DevProb
             --sh.remaining;
             --sh.depth;
             const int bit = (int)((sh.sub_idx >> sh.remaining) & 1ull);
-            (void)embed0<C>(store, P.n_int, &sh.bot, dec[0].var, dec[0].child[bit].x, dec[0].child[bit].y);
+            embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dec[0].var, dec[0].child[bit].x, dec[0].child[bit].y);
             if (sh.remaining == 0) end_of_dive(P, sh);
           } else {
             Decision& dd = dec_at(P, sh, dec, sh.depth - 1);
             const int c = ++dd.cur;
-            (void)embed0<C>(store, P.n_int, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+            embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
             // test aid (tb_session_debug_path): the objective bound in force when this decision was taken (the leader's copy of the stack is the one handed out)
             if (P.g_path_ub != nullptr && lead && sh.depth <= P.max_depth) glob(P.g_path_ub)[(size_t)b * P.max_depth + (sh.depth - 1)] = sh.last_obj_ub;
           }
@@ -3133,12 +3320,13 @@ __global__ void __launch_bounds__(1024, 4 * WG_PER_CU) solve_kernel_team(DevProb
           const int2 ch = di.child[di.cur];
           raise_lb<C>(store, P.n_int, di.var, ch.x);
           lower_ub<C>(store, P.n_int, di.var, ch.y);
+          if (EVENT) note_change(sh, es, var_of<C>(di.var), EV_LB | EV_UB);
         }
         __syncthreads();
         if (tid == 0) {
           Decision& dd = dec_at(P, sh, dec, depth - 1);
           const int c = ++dd.cur;
-          (void)embed0<C>(store, P.n_int, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
+          embed0_mark<EVENT, C>(P, sh, es, store, &sh.bot, dd.var, dd.child[c].x, dd.child[c].y);
           sh.cur_strategy = sh.snap_strategy;
           sh.next_unassigned = sh.snap_next_unassigned;
         }

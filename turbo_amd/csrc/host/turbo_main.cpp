@@ -63,8 +63,6 @@ void print_solve_statistics(const Printer& p, const Options&, const tb_stats& st
   p.u("eps_solved_subproblems", st.eps_solved_subproblems);
   p.u("eps_skipped_subproblems", st.eps_skipped_subproblems);
   p.u("num_blocks_done", st.num_blocks_done);
-  p.u("eps_stolen_subproblems", st.eps_stolen_subproblems);  // engine-specific: work moved between GPUs
-  p.d("wait_for_work_time", to_sec(st.wait_time_ns / nb));
   p.u("fixpoint_iterations", st.fixpoint_iterations);
   p.u("num_deductions", st.num_deductions);
   p.d("cumulative_time_block_sec", to_sec(st.cumulative_time_block_ns));
@@ -79,7 +77,9 @@ void print_solve_statistics(const Printer& p, const Options&, const tb_stats& st
   p.d("dive_time", to_sec(st.timers_ns[TB_T_DIVE] / nb));
   p.d("best_obj_time", to_sec(st.timers_ns[TB_T_LATEST_BEST_OBJ_FOUND]));
   p.d("first_block_idle_time", to_sec(st.timers_ns[TB_T_FIRST_BLOCK_IDLE]));
-  // engine-specific keys (additions, never replacing a reference key)
+  // engine-specific keys: additions BEHIND the reference's block (statistics.hpp:338-371 keeps its sequence), never replacing a reference key
+  p.u("eps_stolen_subproblems", st.eps_stolen_subproblems);  // work moved between GPUs
+  p.d("wait_for_work_time", to_sec(st.wait_time_ns / nb));
   p.d("kernel_time", (double)st.kernel_ns * 1e-9);
   p.d("propagations_per_second", st.kernel_ns > 0 ? (double)st.num_deductions / ((double)st.kernel_ns * 1e-9) : 0.0);
   p.d("nodes_per_second", st.kernel_ns > 0 ? (double)st.nodes / ((double)st.kernel_ns * 1e-9) : 0.0);
