@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_kernel_stats.txt and profiles/<tag>_counters.json from the rocprofv3 databases written by scripts/profile_r04.sh.
+"""profiles/<tag>_kernel_stats.txt and profiles/<tag>_counters.json from the rocprofv3 databases written by scripts/profile_counters.sh.
 
 Per fixpoint mode of the headline workload (and per configuration of the synthetic 100k x 500k one), per launch of tb::solve_kernel (averages
 over the profiled launches of the pass):
@@ -78,12 +78,12 @@ if trace:
             json.dump(line, open(os.path.join(prof, f"{tag}_bench_line_traced.json"), "w"), indent=1)
     print(open(os.path.join(prof, f"{tag}_kernel_stats.txt")).read())
 
-try:  # entries of an earlier run of this tag stay when their passes were not run again (scripts/profile_r04.sh: parts)
+try:  # entries of an earlier run of this tag stay when their passes were not run again (scripts/profile_counters.sh: parts)
     earlier = json.load(open(os.path.join(prof, f"{tag}_counters.json")))
 except Exception:
     earlier = {}
 rec = {"note": "rocprofv3 --pmc passes of `python3 bench.py --steps 2 --warmup 1 --side-steps 0 --other-steps 0 --reference-seconds 0 --no-cpu-baseline --fixpoint <mode>` "
-               "(scripts/profile_r04.sh); one counter set per pass, no tracing domains; per-launch averages of tb::solve_kernel"}
+               "(scripts/profile_counters.sh); one counter set per pass, no tracing domains; per-launch averages of tb::solve_kernel"}
 for fp, key in (("event", "wordpress7_500/event"), ("wac1", "wordpress7_500/wac1"), ("accap_a3", "accap_a3/event"), ("trains15", "trains15/event")):
     sq1, sq2, ic, grbm, fetch, write, tcc = (counters(f"{fp}_{k}") for k in ("sq1", "sq2", "icache", "grbm", "fetch", "write", "tcc"))
     line = bench_line(f"{fp}_sq1.log")
@@ -160,6 +160,19 @@ for i, (fp, what) in enumerate((("wac1", "256 workgroups x 1024 threads in workg
         if pe:
             r["ea_read_requests_per_propagation"] = ea["TCC_EA0_RDREQ_sum"] / pe
             r["ea_read_requests_32B_share"] = ea.get("TCC_EA0_RDREQ_32B_sum", 0.0) / max(1.0, ea["TCC_EA0_RDREQ_sum"])
+    # issue side of the kernels of stores in global memory (r06): the same SQ passes as for the LDS-resident rows
+    sq1, sq2, grbm = (counters(f"syn{i}_{k}") for k in ("sq1", "sq2", "grbm"))
+    if sq1 and grbm:
+        gui = grbm.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        cap = 1024.0 * gui / 4.0
+        bs = bench_line(f"syn{i}_sq1.log")
+        ps, ns = bs.get("balance", {}).get("propagations"), bs.get("balance", {}).get("nodes")
+        r.update({"valu_busy": sq1["SQ_ACTIVE_INST_VALU"] / cap if cap else None, "salu_busy": sq2.get("SQ_ACTIVE_INST_SCA", 0) / cap if cap else None,
+                  "lds_busy": sq2.get("SQ_ACTIVE_INST_LDS", 0) / cap if cap else None,
+                  "wait_any_share": sq1["SQ_WAIT_ANY"] / sq1["SQ_WAVE_CYCLES"], "wait_inst_any_share": sq1["SQ_WAIT_INST_ANY"] / sq1["SQ_WAVE_CYCLES"]})
+        if ps and ns:
+            r.update({"valu_per_64_propagations": sq1["SQ_INSTS_VALU"] / (ps / 64.0), "salu_per_64_propagations": sq1["SQ_INSTS_SALU"] / (ps / 64.0),
+                      "valu_per_node": sq1["SQ_INSTS_VALU"] / ns, "salu_per_node": sq1["SQ_INSTS_SALU"] / ns})
     key = "synthetic/" + fp + ("" if i < 3 or i == 5 else ("_beyond_mall" if i == 3 else ("_hot_tier" if team_round else "_no_hot_tier")))
     rec[key] = r
 for k, v in earlier.items():

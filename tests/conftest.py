@@ -53,6 +53,15 @@ def pytest_collection_modifyitems(config, items):
                 continue
             it.add_marker(pytest.mark.soak)
             soak.append(it)
+    # the 5 layouts x 5 variable orders x 4 value orders of tests/test_gpu_orders.py: every order on the first two layouts, every second order on the others
+    for it in items:
+        cs = getattr(it, "callspec", None)
+        if cs is None or it.originalname != "test_every_order_on_class_pure_networks":
+            continue
+        layout_index = [i for i, x in enumerate(it.module.LAYOUTS) if x == (cs.params["fixpoint"], cs.params["debug"])]
+        if layout_index and layout_index[0] >= 2 and (cs.params["var_order"] + cs.params["val_order"] + layout_index[0]) % 2 == 1:
+            it.add_marker(pytest.mark.soak)
+            soak.append(it)
     wanted = "soak" in (config.getoption("-m") or "") or os.environ.get("TB_SOAK") == "1"
     if soak and not wanted:
         gone = set(id(i) for i in soak)

@@ -165,8 +165,8 @@ def test_bench_contract_line():
     """bench.py prints ONE JSON line with the keys the driver and the judge read."""
     import json
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--side-steps", "1",
-                        "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--side-steps", "1", "--other-steps", "1",
+                        "--reference-seconds", "2", "--sharded-reps", "1", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -182,6 +182,18 @@ def test_bench_contract_line():
     # the store of the headline workload is LDS resident: the fraction is priced against the level that serves the bytes, never above 1
     assert roof["bound"] == "lds" and 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert 0 < roof["records_from_l2"]["frac"] <= 1
+    # r06: every level priced against its own peak, and the rows of stores in global memory name the level the counters show serving them
+    assert set(roof["levels"]) == {"lds", "l2", "hbm"} and 0 < roof["levels"]["lds"]["frac"] <= 1 and 0 < roof["levels"]["l2"]["frac"] <= 1
+    syn = {o["fixpoint"]: o["roofline"] for o in d["other_workloads"] if o["workload"].startswith("synthetic")}
+    assert set(syn) == {"event", "wac1", "ac1"}
+    for fp, ro in syn.items():
+        assert ro["bound"] in ("l2", "hbm") and 0 < ro["frac"] <= 1 and "bound_chosen_by" in ro, (fp, ro)
+    assert syn["wac1"]["bound"] == "l2" and syn["event"]["bound"] == "hbm", {k: v["bound"] for k, v in syn.items()}  # (profiles/r0x_counters.json: L2 hit rate 0.93 against 0.43)
+    # r06: the sharded search itself is in the default line -- a whole search of fixed total work (what SCALE_r*.json needs at N > 1)
+    sh = d["sharded_search"]
+    assert sh["exhaustive"] == 1 and sh["has_solution"] == 0 and sh["every_subproblem_accounted_once"] and sh["eps_solved"] + sh["eps_skipped"] == 1 << sh["subproblems_power"]
+    assert 0 < sh["seconds"] < 30 and sh["scaling"] == "strong" and len(sh["per_rank"]) == 1
+    assert d["cpu_baseline"]["leaf_rule"] == d["config"]["leaf_rule"] == "barebones"
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and "sample" in cpu and "dfs_sample" in cpu
     assert d["value"] > 10 * cpu["value"]  # north star: >= 10x the CPU propagation rate
