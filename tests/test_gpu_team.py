@@ -218,6 +218,38 @@ def test_small_grids_of_real_xcd_teams_keep_to_their_own_slabs(team_env, or_node
                 np.testing.assert_array_equal(best, best_o)
 
 
+_MID_SIZE_PROOF = []
+
+
+def _oracle_proof_of_the_mid_size_network():
+    if not _MID_SIZE_PROOF:  # (7 s of one host core, once for the three modes)
+        tcn = frontend.load_fzn(os.path.join(BENCH, "example_wordpress7_500.fzn"))
+        has, _, st = pyoracle.solve(tcn, subproblems_power=6, fixed_bound=260)
+        _MID_SIZE_PROOF.append((has, st))
+    return _MID_SIZE_PROOF[0]
+
+
+@pytest.mark.parametrize("mode", ["wac1", "ac1", "event"])
+def test_racing_teams_of_the_real_xcds_count_the_oracles_nodes_on_a_mid_size_network(team_env, mode):
+    """VERDICT r05 item 3, last sentence: teams formed from the XCDs the workgroups really run on (no TB_TEAM_ALL; a full grid, four teams per XCD racing through the queue)
+    against the oracle's COUNTERS on a mid-size network -- wordpress7_500 as parsed, 16 963 variables x 45 967 propagators, its store forced into global memory.  The search is
+    the proof of `objective <= 260` over 2^6 subproblems (tb_config.use_fixed_bound: no incumbent is exchanged, so the tree does not depend on which team takes which
+    subproblem when): 2 896 nodes, 1 288 of them failed, every subproblem refuted -- the same numbers from the sequential oracle, the sweeping teams and the event teams."""
+    tcn = frontend.load_fzn(os.path.join(BENCH, "example_wordpress7_500.fzn"))
+    if mode == "event":
+        team_env.setenv("TB_TEAM_EVENT", "1")
+    fixpoint = {"wac1": 1, "ac1": 0, "event": 2}[mode]
+    cfg = dict(subproblems_power=6, use_fixed_bound=1, fixed_bound=260, timeout_ms=240000, fixpoint=fixpoint, **TEAM)
+    plan = plan_of(tcn, **cfg)
+    assert plan["kernel_opt"] == (5 if mode == "event" else 10) and plan["num_blocks"] >= 8, plan
+    has_g, best_g, st_g = capi.solve(tcn, capi.make_config(**cfg))
+    has_o, st_o = _oracle_proof_of_the_mid_size_network()
+    assert not has_o and not has_g and st_g["exhaustive"] == 1
+    assert st_o["nodes"] > 2000 and st_o["eps_solved_subproblems"] == 64
+    for k in ("nodes", "fails", "solutions", "depth_max", "eps_solved_subproblems", "eps_skipped_subproblems"):
+        assert st_g[k] == st_o[k], k
+
+
 JOIN_SCRIPT = r"""
 import os, sys, time
 sys.path.insert(0, os.environ["TB_ROOT"])
