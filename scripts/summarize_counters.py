@@ -73,7 +73,21 @@ if trace:
                                                                      "where name like '%solve_kernel%' group by name, grid_x, workgroup_x, lds_size"):
             f.write(f"# {n[:58]}: grid={gx} workgroup={wx} lds_block_size={lds} scratch={scr} arch_vgpr={vg} accum_vgpr={av} sgpr={sg} launches={cnt} avg_ms={avg / 1e6:.3f}\n")
         line = bench_line("bench_traced.log")
+        # The headline kernel is launched by two parts of the command: the timed loop (warm-up + steps: the node budget of a step) and the `sharded_search` record (a whole
+        # proof under a fixed bound, a different amount of work per launch) -- the table above averages over both; here they are apart, in launch order.
         if line:
+            head = next(iter(r[0] for r in con.execute("select name from kernels where name like '%solve_kernel%' order by start limit 1")), None)  # (the loop runs first)
+            durs = [r[0] / 1e6 for r in con.execute("select (end - start) from kernels where name = ? order by start", (head,))]
+            k = int(line.get("warmup", 0)) + int(line.get("steps", 0))
+            loop, rest = durs[:k], durs[k:]
+            f.write(f"# launches of the headline kernel in order, ms: {' '.join(f'{d:.1f}' for d in durs)}\n")
+            if loop:
+                timed = loop[int(line.get('warmup', 0)):]
+                f.write(f"#   timed loop ({line.get('warmup')} warm-up + {line.get('steps')} steps): average of the {len(timed)} timed launches {sum(timed) / max(1, len(timed)):.3f} ms"
+                        f" -- against roofline.avg_launch_ms of the same run (HIP events in bench.py) {line['roofline']['avg_launch_ms']:.3f} ms\n")
+            if rest:
+                f.write(f"#   sharded_search record (warm-up + runs of the proof under a fixed bound): {len(rest)} launches, average {sum(rest) / len(rest):.3f} ms"
+                        f" (the record's seconds: {line.get('sharded_search', {}).get('seconds')})\n")
             f.write(f"# bench line of the traced run: value={line.get('value'):.4e} propagations/s, nodes_per_sec={line.get('nodes_per_sec'):.4e}, roofline.avg_launch_ms={line['roofline']['avg_launch_ms']:.3f}\n")
             json.dump(line, open(os.path.join(prof, f"{tag}_bench_line_traced.json"), "w"), indent=1)
     print(open(os.path.join(prof, f"{tag}_kernel_stats.txt")).read())
