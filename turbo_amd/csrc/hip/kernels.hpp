@@ -54,9 +54,6 @@
 #ifndef TB_SC_PREFETCH
 #define TB_SC_PREFETCH 0
 #endif
-#ifndef TB_CHAN_EARLY
-#define TB_CHAN_EARLY 1  // joint channelling pass: leave after one vote when no lane has anything to write (0: the pass of r05)
-#endif
 
 #if TB_OUTLINE & 1
 #define TB_FIX_ATTR __noinline__
@@ -1778,14 +1775,9 @@ __device__ __forceinline__ int fixpoint_event(const DevProblem& P, BlockShared& 
                 }
               }
               const bool outside = kc < lb || kc > ub, hit = lb == ub && kc == lb;
-#if TB_CHAN_EARLY
-              // Most passes find nothing to do (a slice woken for a bound that moved over other slices' values, for a b whose value is not on a bound): one vote
-              // and out, before the stores, the wake-ups and the report mask are even set up (r06: ~13 of 25 passes a node on wordpress7_500).
-              if (!wave_any(act && (xb == 3u || lb > ub || lb != Y.lb || ub != Y.ub || (xb == 0u && (outside || hit))))) {
-                un_i = act && !((t && hit) || (f && outside));
-                return;
-              }
-#endif
+              // (r06, dropped: leaving the pass after one vote when no lane has anything to write -- about half of the passes -- ADDS instructions, 7 307 -> 7 416 VALU per
+              // node on wordpress7_500, and costs 5.5 % nodes/s, same box: the stores below are already skipped by their own execution masks, and the extra vote
+              // and its live ranges are paid by every pass.  profiles/r06_ab_chan_early.txt)
               const bool bad = wave_any(act && (xb == 3u || lb > ub));
               un_i = act;
               if (!bad) {
