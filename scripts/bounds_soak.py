@@ -20,7 +20,7 @@ from turbo_amd import capi, preprocess  # noqa: E402
 from turbo_amd.synth import make_synthetic  # noqa: E402
 
 budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "r05_bounds_soak.json")
+out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "r06_bounds_soak.json")
 COMPACT, C16, C8 = 0x100000, 0x10100000, 0x30100000
 LAYOUT = {0: "plain", 1: "COMPACT", 2: "COMPACT16", 3: "HOT", 4: "COMPACT8", 5: "TEAM"}
 
