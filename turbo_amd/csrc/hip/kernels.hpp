@@ -25,7 +25,7 @@
 #define TB_EVENT_WAVES_C8 6  // two-wave workgroups on COMPACT8 slabs: LDS holds eleven or twelve of them per CU (trains15), so 6 waves per SIMD -- 80 VGPRs
 #endif
 #ifndef TB_EVENT_WAVES
-#define TB_EVENT_WAVES 7
+#define TB_EVENT_WAVES 7  // (r06, measured again: 6 -- 80 VGPRs, 6 instead of 12 VGPR spills, 49 instead of 58 SGPRs spilled to lanes, twelve workgroups per CU -- is 3.7 % slower on wordpress7_500)
 #endif
 // Which parts of an event kernel's node are functions of their own (bit 0: the fixpoint, bit 1: node bookkeeping, bit 2: variable
 // selection).  Measured on wordpress7_500: a call costs more than it saves here -- the callee-saved registers go through scratch
