@@ -1366,7 +1366,10 @@ __device__ __forceinline__ unsigned lean_class_run(const RunEnv& E, const int cl
 #define TB_LEAN_SWITCH_C1 0  // (r06, measured: 1 -- per-class pass loops in the COMPACT kernels too -- makes the proof search of the sharded_search record 3.2 % faster (11.5 lean class runs
 #endif                      //  of 33 per node there) and the branch-and-bound step of the headline 0.6 % slower (1.4 of 37): the headline decides.  profiles/r06_ab_lean_switch.txt)
   if constexpr (C == 1 && !TB_LEAN_SWITCH_C1) return lean_class_run_t<C, -1>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
-  else {
+  else if constexpr (C == 1 && TB_LEAN_SWITCH_C1 == 2) {  // (variant: sums only)
+    if (cls == K_ADD) return lean_class_run_t<C, K_ADD>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
+    return lean_class_run_t<C, -1>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
+  } else {
     // (specialising the operand kinds of the commonest signatures as well -- sums of three variables, `c = y + z`, min / max over Booleans -- was
     //  measured: accap_a3 +0.6 %, trains15 -1 %; not kept)
     switch (cls) {
