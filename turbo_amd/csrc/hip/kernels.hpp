@@ -1363,10 +1363,14 @@ __device__ __forceinline__ unsigned lean_class_run_t(const RunEnv& E, const int 
 template <int C>
 __device__ __forceinline__ unsigned lean_class_run(const RunEnv& E, const int cls, const int kinds, const int4 pr, const bool act, int2* store, const int ni, unsigned& run_writes, unsigned& wave_writes, int& nar_all) {
 #ifndef TB_LEAN_SWITCH_C1
-#define TB_LEAN_SWITCH_C1 0  // (r06, measured: 1 -- per-class pass loops in the COMPACT kernels too -- makes the proof search of the sharded_search record 3.2 % faster (11.5 lean class runs
-#endif                      //  of 33 per node there) and the branch-and-bound step of the headline 0.6 % slower (1.4 of 37): the headline decides.  profiles/r06_ab_lean_switch.txt)
+// The COMPACT event kernels (C == 1): 0 = one pass loop with the class as a run-time value (r03-r05: the lean class run is a side path of the headline's branch and bound, 1.4 of 37
+// runs per node, and its size is paid in registers by everything around it); 1 = a pass loop per class as in the other layouts; 2 = a pass loop of its own for sums only.
+// r06, same box, two passes each (profiles/r06_ab_lean_switch.txt): the proof search of the `sharded_search` record (11.5 lean class runs of 33 per node, sums most of them)
+// takes 0.814 s with 0, 0.789 s with 1, 0.781 s with 2; the headline step 6.126 / 6.111 / 6.110e7 nodes/s (-0.25 %: inside the box-to-box spread).  2 is the default.
+#define TB_LEAN_SWITCH_C1 2
+#endif
   if constexpr (C == 1 && !TB_LEAN_SWITCH_C1) return lean_class_run_t<C, -1>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
-  else if constexpr (C == 1 && TB_LEAN_SWITCH_C1 == 2) {  // (variant: sums only)
+  else if constexpr (C == 1 && TB_LEAN_SWITCH_C1 == 2) {
     if (cls == K_ADD) return lean_class_run_t<C, K_ADD>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
     return lean_class_run_t<C, -1>(E, cls, kinds, pr, act, store, ni, run_writes, wave_writes, nar_all);
   } else {
