@@ -1079,6 +1079,9 @@ InternalNet to_internal(const Layout& L, const tb_itv* store, int32_t n_props, c
     const long long ka = key2(a), kc = key2(c);
     return ka != kc ? ka < kc : key3(a) < key3(c);
   });
+  // (Measured and rejected, r06: sums grouped by the kinds of their operands -- constant / Boolean / integer -- so that a slice's columns are of one kind and take the cheap loads:
+  //  the proof search of the sharded_search record gains 2.3 %, the headline step loses 4.1 % and trains15 4.5 % (more evaluations per node: the sums of one constraint no longer
+  //  share a slice).  profiles/r06_ab_sort_kinds.txt)
   // (Measured and rejected, r03: re-ordering the records inside a class for fewer reader slices per variable -- the order with the fewest
   //  (variable, slice) incidences among the caller's and the sorts by x, y, z.  wordpress7_500: sorting its 30 017 implications `y <= z` by y
   //  brings 3.51 reader slices per variable down to 2.30, and the search from 4.15e7 to 3.49e7 nodes/s with 55 % more evaluations per node:
