@@ -342,6 +342,28 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert all(r["nodes"] > 0 for r in rec["multi_gpu"]["per_rank"])
 
 
+def test_bench_with_eight_ranks_on_one_device_links_them_all_and_accounts_the_sharded_search_once():
+    """The world size the driver's scaling run ends with, end to end on a 1-GPU box (r06): `bench.py --gpus 8 --share-device` -- eight processes, each on its 1/8 of the
+    CUs, eight handles over one all_gather, 56 peer mappings, the default line with its `sharded_search` record: the proof of `objective <= 500` on the headline instance,
+    whose 2^21 subproblems must be solved or skipped exactly once whichever rank took (or stole) them, the same 47 162 006 nodes as one rank walks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--share-device", "--nodes-total", "8000000",
+           "--no-cpu-baseline", "--side-steps", "0", "--other-steps", "0", "--reference-seconds", "0", "--sharded-reps", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 8 and rec["value"] > 0
+    m = rec["multi_gpu"]
+    assert m["exchange"] == "peer cells over xGMI" and m["dist"]["world_size"] == 8
+    assert len(m["per_rank"]) == 8 and sum(r["nodes"] > 0 for r in m["per_rank"]) >= 4  # (the group's node budget may be spent before a late rank's kernel starts)
+    ss = rec["sharded_search"]
+    assert ss["linked"] and ss["exhaustive"] == 1 and not ss["has_solution"]
+    assert ss["every_subproblem_accounted_once"] and ss["eps_solved"] + ss["eps_skipped"] == 1 << 21
+    assert ss["nodes"] == 47162006, ss["nodes"]  # (a proof under a constant bound: the tree does not depend on who walks which part)
+    # (a rank whose kernel starts late on the shared device may find its whole share stolen by then -- 1 run in 7 here: that is the stealing doing its job, not an error)
+    assert len(ss["per_rank"]) == 8 and sum(r["eps_solved"] for r in ss["per_rank"]) == ss["eps_solved"] and sum(r["eps_solved"] > 0 for r in ss["per_rank"]) >= 4
+
+
 def test_bench_two_ranks_complete_subproblems_and_steal_inside_a_step():
     """The N > 1 bench path where the queues matter: on the headline instance and on trains15 no workgroup ever finishes a
     subproblem inside a step (measured: 0 solved in 3 M nodes at 2^10 .. 2^16 subproblems), so those steps never touch the work queue after the first
